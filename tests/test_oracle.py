@@ -1,0 +1,236 @@
+"""Pins the CPU oracle: (1) the reference's stored model.summary() (the only reference-owned golden),
+(2) an independent PyTorch-CPU implementation, (3) finite differences.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rvip_oracle as O
+from oracle.torch_ref import TorchUNet
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+TINY = dict(DIM=[16, 16], FILTERS=4, DEPTH=2, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
+            MASK_CLASSES=2, IMG_CHANNELS=1, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-3)
+
+
+def test_graph_matches_reference_summary():
+    fx = json.load(open(os.path.join(GOLD, 'model_summary.json')))
+    layers = O.build_graph(fx['config'])
+    rows = O.summary_rows(layers)
+    assert len(rows) == len(fx['rows']) == 63
+    for (name, ty, shape, params, ins), g in zip(rows, fx['rows']):
+        assert name == g['name']
+        assert ty.startswith(g['type_prefix'])          # Keras truncates long class names in the printout
+        assert list(shape) == g['shape']
+        assert params == g['params']
+        assert list(ins) == g['inputs']
+    tot, tr, ntr = O.count_params(layers)
+    assert (tot, tr, ntr) == (fx['totals']['Total'], fx['totals']['Trainable'], fx['totals']['Non-trainable'])
+    assert tot == 8641730
+
+
+def test_layer_census_and_dropout_schedule():
+    layers = O.build_graph(dict(DIM=[256, 256], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, MASK_CLASSES=2))
+    census = {}
+    for l in layers:
+        census[l['type']] = census.get(l['type'], 0) + 1
+    assert census == {'InputLayer': 1, 'Conv2D': 23, 'BatchNormalization': 18, 'Dropout': 9, 'MaxPooling2D': 4,
+                      'UpSampling2D': 4, 'Concatenate': 4}
+    rates = [l['rate'] for l in layers if l['type'] == 'Dropout']
+    assert rates == [0.3, 0.4, 0.4, 0.5, 0.5, 0.5, 0.4, 0.4, 0.3]        # Unets.py:105-106,800,813,832
+
+
+def test_use_upsample_string_default_is_truthy():
+    # Unets.py:86 default is the STRING 'False' -> UpSampling+Conv path; only boolean False gives ConvTranspose
+    base = dict(DIM=[32, 32], FILTERS=4, DEPTH=2)
+    assert any(l['type'] == 'UpSampling2D' for l in O.build_graph(base))
+    lt = O.build_graph(dict(base, USE_UPSAMPLE=False))
+    assert any(l['type'] == 'Conv2DTranspose' for l in lt) and not any(l['type'] == 'UpSampling2D' for l in lt)
+
+
+def _t(a):
+    return torch.tensor(a, dtype=torch.float64)
+
+
+def test_conv_same_vs_torch():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 9, 7, 3)); w = rng.standard_normal((3, 3, 3, 5)); b = rng.standard_normal(5)
+    dy = rng.standard_normal((2, 9, 7, 5))
+    y = O.conv2d_same_fwd(x, w, b)
+    xt, wt, bt = _t(x).requires_grad_(), _t(w).requires_grad_(), _t(b).requires_grad_()
+    yt = torch.nn.functional.conv2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), bt, padding=1).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(y, yt.detach().numpy(), atol=1e-12)
+    yt.backward(_t(dy))
+    dx, dw, db = O.conv2d_same_bwd(x, w, dy)
+    np.testing.assert_allclose(dx, xt.grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(dw, wt.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(db, bt.grad.numpy(), atol=1e-11)
+
+
+def test_conv_transpose_same_vs_torch_and_adjoint():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 5, 4, 3)); w = rng.standard_normal((3, 3, 6, 3)); b = rng.standard_normal(6)
+    y = O.conv2d_transpose_same_fwd(x, w, b)
+    assert y.shape == (2, 10, 8, 6)
+    xt, wt = _t(x).requires_grad_(), _t(w).requires_grad_()
+    full = torch.nn.functional.conv_transpose2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), _t(b), stride=2)
+    yt = full[:, :, :10, :8].permute(0, 2, 3, 1)
+    np.testing.assert_allclose(y, yt.detach().numpy(), atol=1e-12)
+    dy = rng.standard_normal(y.shape)
+    yt.backward(_t(dy))
+    dx, dw, db = O.conv2d_transpose_same_bwd(x, w, dy)
+    np.testing.assert_allclose(dx, xt.grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(dw, wt.grad.numpy(), atol=1e-11)
+    # definition check: it is the input-gradient of a SAME stride-2 conv (pad_before=0, pad_after=1)
+    wf = w                                             # HWOI of the transpose == HWIO of the forward conv (I=6, O=3)
+    img = rng.standard_normal((2, 10, 8, 6))
+    imgp = np.pad(img, ((0, 0), (0, 1), (0, 1), (0, 0)))
+    fwd = np.zeros((2, 5, 4, 3))
+    for i in range(3):
+        for j in range(3):
+            fwd += imgp[:, i:i + 9:2, j:j + 7:2, :] @ wf[i, j]
+    lhs = (fwd * x).sum()
+    rhs = (img * O.conv2d_transpose_same_fwd(x, w)).sum()
+    assert abs(lhs - rhs) < 1e-9 * max(1, abs(lhs))
+
+
+def test_bn_pool_upsample_vs_torch():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((3, 8, 6, 5)); g = rng.standard_normal(5); b = rng.standard_normal(5)
+    dy = rng.standard_normal(x.shape)
+    y, cache = O.bn_train_fwd(x, g, b)
+    xt, gt, bt = _t(x).requires_grad_(), _t(g).requires_grad_(), _t(b).requires_grad_()
+    mm, mv = torch.zeros(5, dtype=torch.float64), torch.ones(5, dtype=torch.float64)
+    yt = torch.nn.functional.batch_norm(xt.permute(0, 3, 1, 2), mm, mv, gt, bt, True, 0.01, 1e-3).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(y, yt.detach().numpy(), atol=1e-12)
+    yt.backward(_t(dy))
+    dx, dg, db = O.bn_train_bwd(dy, g, cache)
+    np.testing.assert_allclose(dx, xt.grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(dg, gt.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(db, bt.grad.numpy(), atol=1e-11)
+    nm, nv = O.bn_moving_update(np.zeros(5), np.ones(5), cache[2], cache[3], 3 * 8 * 6)
+    np.testing.assert_allclose(nm, mm.numpy(), atol=1e-14)          # unbiased variance in the moving average
+    np.testing.assert_allclose(nv, mv.numpy(), atol=1e-14)
+    # pooling with ties (post-ReLU zeros): first max in row-major window order
+    xr = np.maximum(rng.standard_normal((2, 8, 8, 3)), 0)
+    p, idx = O.maxpool2x2_fwd(xr)
+    xrt = _t(xr).requires_grad_()
+    pt = torch.nn.functional.max_pool2d(xrt.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    np.testing.assert_array_equal(p, pt.detach().numpy())
+    dp = rng.standard_normal(p.shape)
+    pt.backward(_t(dp))
+    np.testing.assert_array_equal(O.maxpool2x2_bwd(dp, idx, xr.shape), xrt.grad.numpy())
+    u = O.upsample_nearest_fwd(x)
+    ut = torch.nn.functional.interpolate(_t(x).permute(0, 3, 1, 2), scale_factor=2.0, mode='nearest').permute(0, 2, 3, 1)
+    np.testing.assert_array_equal(u, ut.numpy())
+    np.testing.assert_allclose(O.upsample_nearest_bwd(u), 4 * x, atol=1e-12)
+
+
+def _compare_grads(cfg, loss, with_dropout=True, batch=3, atol=2e-9):
+    layers = O.build_graph(cfg)
+    p64 = O.init_params(layers, seed=7, dtype=np.float64)
+    rng = np.random.default_rng(5)
+    for k, v in p64.items():                           # non-trivial biases / BN affine so every path is live
+        if len(v) == 2:
+            v[1] = rng.standard_normal(v[1].shape) * 0.1
+        else:
+            v[0] = 1 + 0.2 * rng.standard_normal(v[0].shape); v[1] = 0.1 * rng.standard_normal(v[1].shape)
+    x, y = O.synthetic_batch(batch, cfg['DIM'], cfg.get('MASK_CLASSES', 2), seed=3)
+    masks = O.dropout_keep_masks(layers, batch, seed=11) if with_dropout else None
+    net = O.OracleUNet(cfg, {k: [a.copy() for a in v] for k, v in p64.items()}, dtype=np.float64)
+    ref = TorchUNet(cfg, {k: [a.copy() for a in v] for k, v in p64.items()}, dtype=torch.float64)
+    val, grads, pred, _ = net.loss_and_grads(x.astype(np.float64), y.astype(np.float64), loss, masks)
+    tval, tgrads, tpred = ref.loss_and_grads(x.astype(np.float64), y.astype(np.float64), loss, masks)
+    np.testing.assert_allclose(pred, tpred.numpy(), atol=1e-10)
+    assert abs(val - float(tval)) < 1e-10
+    assert list(grads) == list(tgrads)
+    for k in grads:
+        for a, b in zip(grads[k], tgrads[k]):
+            np.testing.assert_allclose(a, b.numpy(), atol=atol, err_msg=k)
+    return net, ref, x, y, masks
+
+
+@pytest.mark.parametrize('loss', ['mse', 'bce_dice'])
+def test_end_to_end_grads_vs_torch(loss):
+    _compare_grads(TINY, loss)
+
+
+@pytest.mark.parametrize('variant', [dict(BN_FIRST=True), dict(ACTIVATION='elu'), dict(BATCH_NORMALISATION=False),
+                                     dict(USE_UPSAMPLE=False), dict(DEPTH=3, DIM=[24, 16])])
+def test_variants_vs_torch(variant):
+    _compare_grads(dict(TINY, **variant), 'mse')
+
+
+def test_finite_difference_gradient():
+    cfg = dict(TINY, DIM=[8, 8], DEPTH=1, FILTERS=2)
+    layers = O.build_graph(cfg)
+    p = O.init_params(layers, seed=1, dtype=np.float64)
+    x, y = O.synthetic_batch(2, cfg['DIM'], 2, seed=9)
+    x, y = x.astype(np.float64), y.astype(np.float64)
+    masks = O.dropout_keep_masks(layers, 2, seed=4)
+    net = O.OracleUNet(cfg, p, dtype=np.float64)
+    _, grads, _, _ = net.loss_and_grads(x, y, 'mse', masks)
+    rng = np.random.default_rng(0)
+    for name in ['conv2d', 'batch_normalization', 'conv2d_2', 'unet']:
+        for ai in range(2):
+            arr = net.params[name][ai]
+            for _ in range(3):
+                idx = tuple(rng.integers(0, s) for s in arr.shape)
+                old = arr[idx]
+                eps = 1e-6
+                arr[idx] = old + eps; lp = net.loss_and_grads(x, y, 'mse', masks)[0]
+                arr[idx] = old - eps; lm = net.loss_and_grads(x, y, 'mse', masks)[0]
+                arr[idx] = old
+                fd = (lp - lm) / (2 * eps)
+                assert abs(fd - grads[name][ai][idx]) < 1e-6 * max(1.0, abs(fd)) + 1e-9, (name, ai, idx)
+
+
+def test_three_train_steps_vs_torch():
+    net, ref, x, y, masks = _compare_grads(TINY, 'mse')
+    for k, v in ref.params.items():                 # loss_and_grads above already ran torch's BN once in
+        if len(v) == 4:                             # training mode (in-place moving-stat update): reset
+            v[2].zero_(); v[3].fill_(1.0)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    for _ in range(3):
+        lv, _ = net.train_step(x64, y64, 'mse', masks)
+        tv, _ = ref.train_step(x64, y64, 'mse', masks)
+        assert abs(lv - tv) < 1e-10
+    tp = ref.numpy_params()
+    for k, v in net.params.items():
+        for a, b in zip(v, tp[k]):
+            np.testing.assert_allclose(a, b, atol=1e-9, err_msg=k)          # incl. BN moving stats + Keras-Adam
+    assert net.iterations == 3
+
+
+def test_keras_adam_epsilon_placement():
+    th, m, v = O.adam_step(np.array([1.0]), np.array([0.5]), np.zeros(1), np.zeros(1), 1, 1e-3)
+    lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    assert np.allclose(th, 1.0 - lr_t * 0.05 / (np.sqrt(0.001 * 0.25) + 1e-7), rtol=0, atol=1e-15)
+
+
+def test_data_parallel_decomposition_mse():
+    """with the loss pre-divided by the GLOBAL batch, the SUM of per-replica gradients equals
+    the single-replica gradient on the full batch (no BN: its statistics are per replica by design)."""
+    cfg = dict(TINY, BATCH_NORMALISATION=False)
+    layers = O.build_graph(cfg)
+    p = O.init_params(layers, seed=2, dtype=np.float64)
+    x, y = O.synthetic_batch(4, cfg['DIM'], 2, seed=1)
+    x, y = x.astype(np.float64), y.astype(np.float64)
+    full = O.OracleUNet(cfg, p, dtype=np.float64).loss_and_grads(x, y, 'mse')
+    parts = [O.OracleUNet(cfg, p, dtype=np.float64).loss_and_grads(x[r * 2:(r + 1) * 2], y[r * 2:(r + 1) * 2], 'mse',
+                                                                    global_batch=4) for r in range(2)]
+    assert abs(full[0] - (parts[0][0] + parts[1][0])) < 1e-12
+    for k in full[1]:
+        for i in range(2):
+            np.testing.assert_allclose(full[1][k][i], parts[0][1][k][i] + parts[1][1][k][i], atol=1e-12)
+
+
+def test_landmark_helpers():
+    h = np.zeros((1, 4, 5, 2), np.float32)
+    h[0, 2, 3, 0] = 0.9; h[0, 1, 1, 1] = 0.7; h[0, 3, 4, 1] = 0.7       # tie -> first in row-major order
+    assert O.landmark_argmax(h).tolist() == [[2 * 5 + 3, 1 * 5 + 1]]
+    c = O.centroid_landmarks(h)
+    assert c[0, 0].tolist() == [2.0, 3.0] and c[0, 1].tolist() == [2.0, 2.5]
