@@ -1,0 +1,135 @@
+"""Data-generator protocol of the reference (src/data/Generators.py:26-232 ``BaseGenerator``, :234-398
+``DataGenerator``), without its file I/O.
+
+Contract kept: ``__len__`` = floor(N / BATCHSIZE) (:142); ``__getitem__(i)`` ->
+``(x float32 [B,*DIM,1] min-max normalised, y float32 [B,*DIM,len(MASK_VALUES)])`` (:97-98,228,379);
+``on_epoch_end`` reshuffles the index list when SHUFFLE (:164-173); iteration ``for x, y in gen`` works
+(predict_model.py:136-139).  With ``GAUS`` the targets are per-channel Gaussian-filtered one-hot masks, min-max
+normalised over all channels together (:385-391) -- the heat-map regression targets of the RVIP model.
+
+The reference's NRRD loading / resampling / albumentations body (:283-375) is CPU, I/O-bound pre-processing
+outside the hot path; ``SyntheticSAXGenerator`` produces slices of the same contract
+from a seed (no ACDC data is available to this build), ``ArrayGenerator`` wraps arrays already in memory.
+"""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+
+def normalise_image(img_nda, normaliser='minmax'):
+    """src/data/Preprocess.py:471-491 (min-max / standard branches)."""
+    normaliser = normaliser.lower()
+    if normaliser == 'standard':
+        return (img_nda - np.mean(img_nda)) / (np.std(img_nda) + sys.float_info.epsilon)
+    if normaliser == 'robust':
+        raise NotImplementedError("SCALER='Robust' needs scikit-learn's RobustScaler; not on the synthetic path")
+    return (img_nda - img_nda.min()) / (img_nda.max() - img_nda.min() + sys.float_info.epsilon)
+
+
+def transform_to_binary_mask(mask_nda, mask_values=(0, 1, 2, 3)):
+    """src/data/Preprocess.py:425-437: label image -> one channel per mask value."""
+    mask = np.zeros((*mask_nda.shape, len(mask_values)), dtype=bool)
+    for ix, mask_value in enumerate(mask_values):
+        mask[..., ix] = mask_nda == mask_value
+    return mask
+
+
+def gaussian_heatmaps(mask_onehot, sigma):
+    """GAUS branch of DataGenerator (Generators.py:385-391)."""
+    import scipy.ndimage
+    g = np.stack([scipy.ndimage.gaussian_filter(mask_onehot[..., c].astype(np.float32), sigma)
+                  for c in range(mask_onehot.shape[-1])], axis=-1)
+    return normalise_image(g, normaliser='minmax')
+
+
+class BaseGenerator:
+    """keras.utils.Sequence protocol with the reference's index bookkeeping (Generators.py:136-173)."""
+
+    def __init__(self, n_samples, config=None):
+        config = config or {}
+        self.config = config
+        self.SCALER = config.get('SCALER', 'MinMax')
+        self.SHUFFLE = config.get('SHUFFLE', True)
+        self.SEED = config.get('SEED', 42)
+        self.DIM = list(config.get('DIM', [256, 256]))
+        self.BATCHSIZE = config.get('BATCHSIZE', 32)
+        self.MASK_VALUES = config.get('MASK_VALUES', [0, 1, 2, 3])
+        self.N_CLASSES = len(self.MASK_VALUES)
+        self.GAUS = config.get('GAUS', False)
+        self.SIGMA = config.get('SIGMA', 1)
+        self.INDICES = list(range(n_samples))
+        self.on_epoch_end()
+
+    def __len__(self):
+        return int(np.floor(len(self.INDICES) / self.BATCHSIZE))
+
+    def __getitem__(self, index):
+        idxs = self.INDICES[index * self.BATCHSIZE:(index + 1) * self.BATCHSIZE]
+        return self.__data_generation__(idxs)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def on_epoch_end(self):
+        self.INDICES = np.arange(len(self.INDICES))
+        if self.SHUFFLE:
+            np.random.shuffle(self.INDICES)        # the reference draws from the global NumPy RNG as well (:172)
+
+    def __data_generation__(self, idxs):
+        x = np.empty((self.BATCHSIZE, *self.DIM, 1), dtype=np.float32)
+        y = np.empty((self.BATCHSIZE, *self.DIM, self.N_CLASSES), dtype=np.float32)
+        for i, ID in enumerate(idxs):
+            x[i], y[i] = self.__preprocess_one_image__(i, int(ID))
+        return x, y
+
+    def __preprocess_one_image__(self, i, ID):
+        raise NotImplementedError
+
+
+class SyntheticSAXGenerator(BaseGenerator):
+    """Seeded SAX-like slices: low-pass noise image, two RVIP landmarks per slice; targets one-hot points (GAUS
+    False) or Gaussian heat-maps (GAUS True, SIGMA).  Sample ID fully determines the sample."""
+
+    def __init__(self, n_samples, config=None, in_memory=False):
+        config = dict(config or {})
+        config.setdefault('MASK_VALUES', [1, 2])
+        super().__init__(n_samples, config)
+        self.IN_MEMORY = in_memory
+        self._cache = {}
+
+    def __preprocess_one_image__(self, i, ID):
+        if self.IN_MEMORY and ID in self._cache:
+            return self._cache[ID]
+        import scipy.ndimage
+        rng = np.random.default_rng([self.SEED, ID])
+        h, w = self.DIM
+        img = scipy.ndimage.gaussian_filter(rng.random((h, w)), min(8.0, h / 8.0))
+        img = normalise_image(img, self.SCALER).astype(np.float32)
+        lab = np.zeros((h, w), np.int32)
+        m = min(16, h // 4, w // 4)
+        for v in self.MASK_VALUES:
+            lab[int(rng.integers(m, h - m)), int(rng.integers(m, w - m))] = v
+        mask = transform_to_binary_mask(lab, self.MASK_VALUES)
+        mask = gaussian_heatmaps(mask, self.SIGMA) if self.GAUS else mask.astype(np.float32)
+        out = (img[..., None], mask.astype(np.float32))
+        if self.IN_MEMORY:
+            self._cache[ID] = out
+        return out
+
+
+class ArrayGenerator(BaseGenerator):
+    """Sequence over arrays already in memory (x [N,*DIM,1], y [N,*DIM,C])."""
+
+    def __init__(self, x, y, batch_size, shuffle=False):
+        self._x = np.asarray(x, np.float32)
+        self._y = None if y is None else np.asarray(y, np.float32)
+        cfg = dict(BATCHSIZE=batch_size, DIM=list(self._x.shape[1:-1]), SHUFFLE=shuffle,
+                   MASK_VALUES=list(range(1 if y is None else self._y.shape[-1])))
+        super().__init__(self._x.shape[0], cfg)
+
+    def __data_generation__(self, idxs):
+        idxs = np.asarray(idxs)
+        return self._x[idxs], (None if self._y is None else self._y[idxs])

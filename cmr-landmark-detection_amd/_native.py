@@ -1,0 +1,125 @@
+"""ctypes binding of librvip_hip.so (the C ABI declared in include/rvip_hip.h).
+
+The product path has NO CPU fallback: ``lib()`` raises if the shared library is missing, and every
+compute call raises ``RvipError`` on a non-zero return code.  Loading the library and resolving its
+symbols needs no GPU (the CPU test-suite checks exactly that); launching needs one.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librvip_hip.so')
+
+F32, BF16 = 0, 1
+ACT = {None: 0, 'linear': 0, 'relu': 1, 'elu': 2, 'sigmoid': 3}
+LOSS_MSE, LOSS_BCE_DICE = 0, 1
+STATE_STEP, STATE_LR, STATE_SEED, STATE_WORDS = 0, 1, 2, 8
+ERRORS = {-1: 'RVIP_EINVAL (bad shape / alignment / null pointer)', -2: 'RVIP_EUNSUPPORTED',
+          -3: 'RVIP_EWORKSPACE (workspace too small)', -4: 'RVIP_ELAUNCH (HIP launch failed)'}
+
+vp = C.c_void_p
+
+
+class RvipError(RuntimeError):
+    pass
+
+
+class Conv3x3Desc(C.Structure):
+    _fields_ = [('x0', vp), ('c0', C.c_int32), ('up0', C.c_int32),
+                ('x1', vp), ('c1', C.c_int32),
+                ('w_packed', vp), ('bias', vp),
+                ('y', vp), ('y1', vp), ('csplit', C.c_int32),
+                ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
+                ('act', C.c_int32), ('dtype', C.c_int32)]
+
+
+class Wgrad3x3Desc(C.Structure):
+    _fields_ = [('x0', vp), ('c0', C.c_int32), ('up0', C.c_int32),
+                ('x1', vp), ('c1', C.c_int32),
+                ('dy', vp), ('dw', vp),
+                ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
+                ('dtype', C.c_int32),
+                ('workspace', vp), ('workspace_bytes', C.c_size_t)]
+
+
+class ApplyDesc(C.Structure):
+    _fields_ = [('z', vp), ('y', vp), ('pooled', vp),
+                ('scale', vp), ('shift', vp),
+                ('act', C.c_int32),
+                ('drop_rate', C.c_float), ('mask', vp), ('state', vp), ('layer_id', C.c_int32),
+                ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('c', C.c_int32),
+                ('dtype', C.c_int32)]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [('dy', vp), ('z', vp), ('dz', vp),
+                ('gamma', vp), ('mean', vp), ('invstd', vp),
+                ('scale', vp), ('shift', vp),
+                ('dgamma', vp), ('dbeta', vp), ('dbias', vp),
+                ('coef', vp),
+                ('act', C.c_int32), ('act_after_bn', C.c_int32),
+                ('drop_rate', C.c_float), ('mask', vp), ('state', vp), ('layer_id', C.c_int32),
+                ('rows', C.c_longlong), ('c', C.c_int32),
+                ('dtype', C.c_int32),
+                ('workspace', vp), ('workspace_bytes', C.c_size_t)]
+
+
+# name -> (restype, argtypes); every symbol include/rvip_hip.h declares
+SIGNATURES = {
+    'rvip_abi_version': (C.c_int, []),
+    'rvip_build_info': (C.c_char_p, []),
+    'rvip_last_hip_error': (C.c_int, []),
+    'rvip_conv3x3_fwd': (C.c_int, [C.POINTER(Conv3x3Desc), vp]),
+    'rvip_pack_conv3x3_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    'rvip_conv3x3_wgrad_workspace': (C.c_size_t, [C.c_int] * 5),
+    'rvip_conv3x3_wgrad': (C.c_int, [C.POINTER(Wgrad3x3Desc), vp]),
+    'rvip_conv3x3_c1_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rvip_conv3x3_c1_wgrad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    'rvip_reduce_workspace': (C.c_size_t, [C.c_longlong, C.c_int]),
+    'rvip_bn_train_stats': (C.c_int, [vp, C.c_longlong, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int,
+                                      vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    'rvip_bn_infer_coeffs': (C.c_int, [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp]),
+    'rvip_bn_apply': (C.c_int, [C.POINTER(ApplyDesc), vp]),
+    'rvip_bn_bwd_reduce': (C.c_int, [C.POINTER(BnBwdDesc), vp]),
+    'rvip_bn_bwd_apply': (C.c_int, [C.POINTER(BnBwdDesc), vp]),
+    'rvip_maxpool2x2_bwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rvip_upsample2x_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rvip_upsample2x_bwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rvip_head_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    'rvip_head_grad': (C.c_int, [vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+    'rvip_head_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    'rvip_landmarks': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    'rvip_adam_step': (C.c_int, [vp, vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]),
+    'rvip_state_tick': (C.c_int, [vp, vp]),
+    'rvip_convert': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library with argtypes set; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RvipError('%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). '
+                            'There is no CPU fallback for the product path.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        L = lib()
+        raise RvipError('%s failed: %s (hipError %d)' % (what, ERRORS.get(rc, rc), L.rvip_last_hip_error()))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,100 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA, 16-byte channel vectors).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rvip_hip.h"
+
+namespace rvip {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct bf16_t { uint16_t bits; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }   // RNE, NaN kept
+
+// 16-byte channel vector: VE elements of T
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int VE = 4;
+    __device__ static __forceinline__ void load(const void* p, float (&v)[4]) {
+        float4 r = *reinterpret_cast<const float4*>(p); v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+    __device__ static __forceinline__ void store(void* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    __device__ static __forceinline__ float round(float x) { return x; }
+};
+template <> struct Vec<bf16_t> {
+    static constexpr int VE = 8;
+    __device__ static __forceinline__ void load(const void* p, float (&v)[8]) {
+        uint4 r = *reinterpret_cast<const uint4*>(p);
+        uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __builtin_bit_cast(float, w[i] << 16); v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); } }
+    __device__ static __forceinline__ void store(void* p, const float (&v)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]); }
+    __device__ static __forceinline__ float round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
+};
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    switch (act) {
+        case RVIP_ACT_RELU: return fmaxf(x, 0.f);
+        case RVIP_ACT_ELU: return x > 0.f ? x : expm1f(x);
+        case RVIP_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        default: return x;
+    }
+}
+// derivative expressed through the activation OUTPUT y
+__device__ __forceinline__ float act_bwd(float y, int act) {
+    switch (act) {
+        case RVIP_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case RVIP_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+        case RVIP_ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
+// ---- counter-based dropout stream (shared by forward and backward, and mirrored on the host in
+// dropout_stream.py): one 32-bit hash per PAIR of consecutive elements, 16 bits each.
+__host__ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_key(uint32_t seed, uint32_t step, uint32_t layer_id) {
+    return hash32(seed ^ hash32(step * 0x9E3779B9u + layer_id * 0x85EBCA6Bu + 0x27d4eb2fu));
+}
+__host__ __device__ __forceinline__ uint32_t dropout_thr(float rate) {       // keep iff bits16 < thr
+    float keep = 1.f - rate;
+    uint32_t t = (uint32_t)(keep * 65536.f + 0.5f);
+    return t > 65536u ? 65536u : t;
+}
+// keep flags of the VE elements starting at element index e0 (e0 % VE == 0, VE even)
+template <int VE>
+__device__ __forceinline__ void dropout_keep(uint32_t key, unsigned long long e0, uint32_t thr, bool (&keep)[VE]) {
+#pragma unroll
+    for (int i = 0; i < VE / 2; ++i) {
+        uint32_t h = hash32((uint32_t)((e0 >> 1) + i) ^ key);
+        keep[2 * i] = (h & 0xffffu) < thr;
+        keep[2 * i + 1] = (h >> 16) < thr;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+extern int g_last_hip_error;
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
+    return RVIP_OK;
+}
+
+inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+}  // namespace rvip

@@ -1,0 +1,887 @@
+// HBM-bound kernels of the training step: BatchNormalization (train/infer/backward), Dropout, MaxPooling,
+// UpSampling, the 1x1 sigmoid head with MSE / BCE-Dice loss and metrics, Keras-Adam, landmark argmax.
+// All NHWC with 16-byte channel vectors (8 bf16 / 4 f32 per lane), fp32 arithmetic.
+//
+// Per-channel reductions are two-stage and deterministic:
+//   stage 1: <= 1024 workgroups, each folds a contiguous range of pixel rows; thread = (row slot, channel
+//            vector); the workgroup's [K][C] partial goes to the workspace row blockIdx.x;
+//   stage 2: fold_finalize<K, Post>: 32 channels per workgroup, 8 row groups per channel, double
+//            accumulation in a fixed order, then the op-specific epilogue (Post).
+#include "rvip_common.h"
+
+namespace rvip {
+
+// ------------------------------------------------------------------------------------------------
+// reduction geometry (host + device agree through these fields)
+// ------------------------------------------------------------------------------------------------
+struct RedGeom {
+    int cg;            // channel vectors per row
+    int rpi;           // rows per workgroup iteration = 256 / cg
+    int nblk;          // workgroups
+    long long chunk;   // rows per workgroup (multiple of rpi)
+};
+
+static inline bool red_geom(long long rows, int c, int ve, RedGeom& g) {
+    if (c <= 0 || c % ve || rows <= 0) return false;
+    g.cg = c / ve;
+    if (g.cg > 256) return false;
+    g.rpi = 256 / g.cg;
+    long long nb = cdiv(rows, (long long)g.rpi * 8);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    long long ch = cdiv(rows, nb);
+    ch = cdiv(ch, g.rpi) * g.rpi;
+    g.chunk = ch;
+    g.nblk = (int)cdiv(rows, ch);
+    return true;
+}
+
+template <int K, int VE>
+__device__ __forceinline__ void block_fold(const float (&part)[K][VE], bool active, int slot, int c, int rpi,
+                                           float* lds, float* out_row) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) lds[slot * VE + e] = part[k][e];
+        }
+        __syncthreads();
+        for (int col = tid; col < c; col += 256) {
+            float s = 0.f;
+            for (int r = 0; r < rpi; ++r) s += lds[r * c + col];
+            out_row[k * c + col] = s;
+        }
+    }
+}
+
+// stage 2: totals[k] for channel ch = sum over workspace rows, then Post::run(ch, totals)
+template <int K, typename Post>
+__global__ __launch_bounds__(256) void fold_finalize(const float* __restrict__ ws, int nblk, int width, Post post) {
+    __shared__ double sh[8][K][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int ch = blockIdx.x * 32 + c;
+    double s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = 0.0;
+    if (ch < width) {
+        for (int b = g; b < nblk; b += 8) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) s[k] += (double)ws[((size_t)b * K + k) * width + ch];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) sh[g][k][c] = s[k];
+    __syncthreads();
+    if (g == 0 && ch < width) {
+        double t[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double acc = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) acc += sh[gg][k][c];
+            t[k] = acc;
+        }
+        post.run(ch, t);
+    }
+}
+
+template <int K, typename Post>
+static int launch_fold(const float* ws, int nblk, int width, Post post, hipStream_t s) {
+    hipLaunchKernelGGL((fold_finalize<K, Post>), dim3((unsigned)cdiv(width, 32)), dim3(256), 0, s, ws, nblk, width, post);
+    return check_launch();
+}
+
+struct PostSum {                      // out[ch] = total (plain sum), K = 1
+    float* out;
+    __device__ void run(int ch, const double (&t)[1]) const { out[ch] = (float)t[0]; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// BatchNormalization forward statistics
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned char* __restrict__ z, long long rows, int c,
+                                                       RedGeom g, float* __restrict__ ws) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float lds[256 * VE];
+    const int tid = threadIdx.x, cgi = tid % g.cg, prow = tid / g.cg;
+    const bool active = prow < g.rpi;
+    const long long r0 = blockIdx.x * g.chunk, r1 = (r0 + g.chunk < rows) ? r0 + g.chunk : rows;
+    float part[2][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) part[0][e] = part[1][e] = 0.f;
+    if (active) {
+        for (long long r = r0 + prow; r < r1; r += g.rpi) {
+            float v[VE];
+            Vec<T>::load(z + ((size_t)r * c + cgi * VE) * sizeof(T), v);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { part[0][e] += v[e]; part[1][e] = fmaf(v[e], v[e], part[1][e]); }
+        }
+    }
+    block_fold<2, VE>(part, active, prow * g.cg + cgi, c, g.rpi, lds, ws + (size_t)blockIdx.x * 2 * c);
+}
+
+struct PostBnStats {
+    const float* gamma; const float* beta; float* mov_mean; float* mov_var;
+    float* mean; float* invstd; float* scale; float* shift;
+    double n; float momentum, eps; int unbiased;
+    __device__ void run(int ch, const double (&t)[2]) const {
+        const double m = t[0] / n;
+        double var = t[1] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float gm = gamma ? gamma[ch] : 1.f, bt = beta ? beta[ch] : 0.f;
+        mean[ch] = (float)m;
+        invstd[ch] = is;
+        const float sc = gm * is;
+        scale[ch] = sc;
+        shift[ch] = bt - (float)m * sc;
+        if (mov_mean) {
+            const double vu = (unbiased && n > 1.0) ? var * (n / (n - 1.0)) : var;
+            mov_mean[ch] = mov_mean[ch] * momentum + (float)m * (1.f - momentum);
+            mov_var[ch] = mov_var[ch] * momentum + (float)vu * (1.f - momentum);
+        }
+    }
+};
+
+__global__ void bn_infer_coeffs_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float eps,
+                                       int c, float* scale, float* shift) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c) return;
+    const float sc = (gamma ? gamma[i] : 1.f) / sqrtf(mv[i] + eps);
+    scale[i] = sc;
+    shift[i] = (beta ? beta[i] : 0.f) - mm[i] * sc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = dropout(act(scale*z + shift)) [+ 2x2 max-pool]
+// ------------------------------------------------------------------------------------------------
+struct ApplyArgs {
+    const unsigned char* z; unsigned char* y; unsigned char* pooled;
+    const float* scale; const float* shift;
+    int act; float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
+    int n, h, w, c;
+};
+
+template <typename T, int VE>
+__device__ __forceinline__ void apply_vec(const ApplyArgs& a, size_t e0, const float (&sc)[VE], const float (&sh)[VE],
+                                          uint32_t key, float (&v)[VE]) {
+    Vec<T>::load(a.z + e0 * sizeof(T), v);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = act_fwd(fmaf(v[e], sc[e], sh[e]), a.act);
+    if (a.drop) {
+        if (a.mask) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = a.mask[e0 + e] ? v[e] * a.inv_keep : 0.f;
+        } else {
+            bool keep[VE];
+            dropout_keep<VE>(key, e0, a.thr, keep);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = keep[e] ? v[e] * a.inv_keep : 0.f;
+        }
+    }
+}
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
+    constexpr int VE = Vec<T>::VE;
+    const int cg = a.c / VE;
+    const long long idx = blockIdx.x * 256LL + threadIdx.x;
+    const int cv = (int)(idx % cg);
+    float sc[VE], sh[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { sc[e] = a.scale ? a.scale[cv * VE + e] : 1.f; sh[e] = a.shift ? a.shift[cv * VE + e] : 0.f; }
+    const uint32_t key = (a.drop && !a.mask) ? dropout_key(a.state[RVIP_STATE_SEED], a.state[RVIP_STATE_STEP], (uint32_t)a.layer_id) : 0u;
+    if constexpr (!POOL) {
+        const long long rows = (long long)a.n * a.h * a.w;
+        const long long r = idx / cg;
+        if (r >= rows) return;
+        const size_t e0 = (size_t)r * a.c + cv * VE;
+        float v[VE];
+        apply_vec<T, VE>(a, e0, sc, sh, key, v);
+        Vec<T>::store(a.y + e0 * sizeof(T), v);
+    } else {
+        const int oh = a.h >> 1, ow = a.w >> 1;
+        const long long q = idx / cg;
+        if (q >= (long long)a.n * oh * ow) return;
+        const int ox = (int)(q % ow), oy = (int)((q / ow) % oh);
+        const long long img = q / ((long long)ow * oh);
+        float best[VE];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t r = ((size_t)img * a.h + 2 * oy + (k >> 1)) * a.w + 2 * ox + (k & 1);
+            const size_t e0 = r * a.c + cv * VE;
+            float v[VE];
+            apply_vec<T, VE>(a, e0, sc, sh, key, v);
+            Vec<T>::store(a.y + e0 * sizeof(T), v);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float vr = Vec<T>::round(v[e]);                 // pool what was stored
+                best[e] = (k == 0 || vr > best[e]) ? vr : best[e];
+            }
+        }
+        Vec<T>::store(a.pooled + ((size_t)q * a.c + cv * VE) * sizeof(T), best);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of conv -> [act] -> BN -> [act] -> dropout
+// ------------------------------------------------------------------------------------------------
+struct BnBwdArgs {
+    const unsigned char* dy; const unsigned char* z; unsigned char* dz;
+    const float* mean; const float* invstd; const float* scale; const float* shift; const float* coef;
+    int act, act_after_bn, has_bn;
+    float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
+    long long rows; int c;
+};
+
+// g = dL/d(BN-side output before dropout) [times act'(y) when the activation follows BN]
+template <typename T, int VE>
+__device__ __forceinline__ void load_g(const BnBwdArgs& a, size_t e0, int cbase, uint32_t key, const float (&z)[VE], float (&g)[VE]) {
+    Vec<T>::load(a.dy + e0 * sizeof(T), g);
+    if (a.drop) {
+        if (a.mask) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) g[e] = a.mask[e0 + e] ? g[e] * a.inv_keep : 0.f;
+        } else {
+            bool keep[VE];
+            dropout_keep<VE>(key, e0, a.thr, keep);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) g[e] = keep[e] ? g[e] * a.inv_keep : 0.f;
+        }
+    }
+    if (a.act_after_bn) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const float sc = a.scale ? a.scale[cbase + e] : 1.f, sh = a.shift ? a.shift[cbase + e] : 0.f;
+            g[e] *= act_bwd(act_fwd(fmaf(z[e], sc, sh), a.act), a.act);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float lds[256 * VE];
+    const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
+    const bool active = prow < gm.rpi;
+    const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
+    const uint32_t key = (a.drop && !a.mask) ? dropout_key(a.state[RVIP_STATE_SEED], a.state[RVIP_STATE_STEP], (uint32_t)a.layer_id) : 0u;
+    float part[2][VE], mu[VE], is[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        part[0][e] = part[1][e] = 0.f;
+        mu[e] = active ? a.mean[cgi * VE + e] : 0.f;
+        is[e] = active ? a.invstd[cgi * VE + e] : 0.f;
+    }
+    if (active) {
+        for (long long r = r0 + prow; r < r1; r += gm.rpi) {
+            const size_t e0 = (size_t)r * a.c + cgi * VE;
+            float z[VE], g[VE];
+            Vec<T>::load(a.z + e0 * sizeof(T), z);
+            load_g<T, VE>(a, e0, cgi * VE, key, z, g);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { part[0][e] += g[e]; part[1][e] = fmaf(g[e], (z[e] - mu[e]) * is[e], part[1][e]); }
+        }
+    }
+    block_fold<2, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws + (size_t)blockIdx.x * 2 * a.c);
+}
+
+struct PostBnBwd {
+    const float* gamma; const float* mean; const float* invstd;
+    float* dgamma; float* dbeta; float* coef; double n; int c;
+    __device__ void run(int ch, const double (&t)[2]) const {
+        const float db = (float)t[0], dg = (float)t[1];
+        dbeta[ch] = db;
+        dgamma[ch] = dg;
+        const float gm = gamma[ch], is = invstd[ch], mu = mean[ch];
+        const float c1 = gm * is;
+        const float c2 = -gm * is * is * (float)(t[1] / n);
+        const float c3 = -gm * is * (float)(t[0] / n) - c2 * mu;
+        coef[ch] = c1; coef[c + ch] = c2; coef[2 * c + ch] = c3;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float lds[256 * VE];
+    const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
+    const bool active = prow < gm.rpi;
+    const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
+    const uint32_t key = (a.drop && !a.mask) ? dropout_key(a.state[RVIP_STATE_SEED], a.state[RVIP_STATE_STEP], (uint32_t)a.layer_id) : 0u;
+    float part[1][VE], c1[VE], c2[VE], c3[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        part[0][e] = 0.f;
+        const int ch = cgi * VE + e;
+        c1[e] = (a.has_bn && active) ? a.coef[ch] : 1.f;
+        c2[e] = (a.has_bn && active) ? a.coef[a.c + ch] : 0.f;
+        c3[e] = (a.has_bn && active) ? a.coef[2 * a.c + ch] : 0.f;
+    }
+    if (active) {
+        for (long long r = r0 + prow; r < r1; r += gm.rpi) {
+            const size_t e0 = (size_t)r * a.c + cgi * VE;
+            float z[VE], g[VE], d[VE];
+            Vec<T>::load(a.z + e0 * sizeof(T), z);
+            load_g<T, VE>(a, e0, cgi * VE, key, z, g);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                float t = fmaf(c1[e], g[e], fmaf(c2[e], z[e], c3[e]));
+                if (!a.act_after_bn) t *= act_bwd(z[e], a.act);       // z is the activation output here
+                d[e] = t;
+                part[0][e] += Vec<T>::round(t);                        // bias grad of what the wgrad kernels read
+            }
+            Vec<T>::store(a.dz + e0 * sizeof(T), d);
+        }
+    }
+    block_fold<1, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws + (size_t)blockIdx.x * a.c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPooling2D backward (+ skip gradient), UpSampling2D forward / backward
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ y, const unsigned char* __restrict__ dp,
+                                                          const unsigned char* __restrict__ add, unsigned char* __restrict__ dx,
+                                                          int n, int h, int w, int c) {
+    constexpr int VE = Vec<T>::VE;
+    const int cg = c / VE, oh = h >> 1, ow = w >> 1;
+    const long long idx = blockIdx.x * 256LL + threadIdx.x;
+    const int cv = (int)(idx % cg);
+    const long long q = idx / cg;
+    if (q >= (long long)n * oh * ow) return;
+    const int ox = (int)(q % ow), oy = (int)((q / ow) % oh);
+    const long long img = q / ((long long)ow * oh);
+    float v[4][VE], g[VE];
+    size_t e0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        e0[k] = (((size_t)img * h + 2 * oy + (k >> 1)) * w + 2 * ox + (k & 1)) * c + cv * VE;
+        Vec<T>::load(y + e0[k] * sizeof(T), v[k]);
+    }
+    Vec<T>::load(dp + ((size_t)q * c + cv * VE) * sizeof(T), g);
+    int arg[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        int best = 0; float bv = v[0][e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (v[k][e] > bv) { bv = v[k][e]; best = k; }
+        arg[e] = best;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float o[VE];
+        if (add) Vec<T>::load(add + e0[k] * sizeof(T), o);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o[e] = (add ? o[e] : 0.f) + (arg[e] == k ? g[e] : 0.f);
+        Vec<T>::store(dx + e0[k] * sizeof(T), o);
+    }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void upsample_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                       int n, int h, int w, int c) {   // h, w = LOW resolution
+    constexpr int VE = Vec<T>::VE;
+    const int cg = c / VE;
+    const long long idx = blockIdx.x * 256LL + threadIdx.x;
+    const int cv = (int)(idx % cg);
+    const long long q = idx / cg;
+    if (q >= (long long)n * h * w) return;
+    const int x = (int)(q % w), yy = (int)((q / w) % h);
+    const long long img = q / ((long long)w * h);
+    const size_t lo = ((size_t)q * c + cv * VE) * sizeof(T);
+    float v[VE];
+    if constexpr (!BWD) {
+        Vec<T>::load(src + lo, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            Vec<T>::store(dst + ((((size_t)img * 2 * h + 2 * yy + (k >> 1)) * 2 * w + 2 * x + (k & 1)) * c + cv * VE) * sizeof(T), v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t[VE];
+            Vec<T>::load(src + ((((size_t)img * 2 * h + 2 * yy + (k >> 1)) * 2 * w + 2 * x + (k & 1)) * c + cv * VE) * sizeof(T), t);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] += t[e];
+        }
+        Vec<T>::store(dst + lo, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: 1x1 conv + sigmoid, loss sums, loss gradient, backward
+// ------------------------------------------------------------------------------------------------
+#define RVIP_MAXK 4
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned char* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ pred,
+                                                       const float* __restrict__ yt, long long rows, int cin, int k,
+                                                       long long chunk, float* __restrict__ ws) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float red[4][16];
+    const int tid = threadIdx.x;
+    const long long r0 = blockIdx.x * chunk, r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
+    float s[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) s[i] = 0.f;
+    for (long long r = r0 + tid; r < r1; r += 256) {
+        float lg[RVIP_MAXK];
+#pragma unroll
+        for (int kk = 0; kk < RVIP_MAXK; ++kk) lg[kk] = (kk < k && b) ? b[kk] : 0.f;
+        for (int c = 0; c < cin; c += VE) {
+            float v[VE];
+            Vec<T>::load(x + ((size_t)r * cin + c) * sizeof(T), v);
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+#pragma unroll
+                for (int kk = 0; kk < RVIP_MAXK; ++kk) if (kk < k) lg[kk] = fmaf(v[e], w[(c + e) * k + kk], lg[kk]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < RVIP_MAXK; ++kk) {
+            if (kk >= k) continue;
+            const float zl = lg[kk];
+            const float p = 1.f / (1.f + expf(-zl));
+            pred[(size_t)r * k + kk] = p;
+            if (yt) {
+                const float t = yt[(size_t)r * k + kk];
+                const float d = p - t;
+                s[0] = fmaf(d, d, s[0]);
+                s[1] += fmaxf(zl, 0.f) - zl * t + log1pf(expf(-fabsf(zl)));
+                s[2] = fmaf(t, p, s[2]); s[3] += t; s[4] += p;
+                if (kk == k - 2) { s[5] = fmaf(t, p, s[5]); s[6] += t; s[7] += p; }
+                if (kk == k - 1) { s[8] = fmaf(t, p, s[8]); s[9] += t; s[10] += p; }
+            }
+        }
+    }
+    if (!ws) return;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) s[i] = wave_sum(s[i]);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) red[wv][i] = s[i];
+    }
+    __syncthreads();
+    if (tid < 16) ws[(size_t)blockIdx.x * 16 + tid] = tid < 11 ? red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ pred, const float* __restrict__ yt,
+                                                        const float* __restrict__ sums, float* __restrict__ dlogit,
+                                                        float* __restrict__ loss_out, long long count, int loss_kind,
+                                                        float inv_count, float lg, float w_bce, float w_dice) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    const float inter = sums[2], st = sums[3], sp = sums[4];
+    const float den = st + sp + 1.f;
+    if (i == 0 && loss_out) {
+        if (loss_kind == RVIP_LOSS_MSE) loss_out[0] = sums[0] * inv_count;
+        else loss_out[0] = w_bce * sums[1] * inv_count - w_dice * lg * (2.f * inter + 1.f) / den;
+    }
+    if (i >= count) return;
+    const float p = pred[i], t = yt[i];
+    float d;
+    if (loss_kind == RVIP_LOSS_MSE) {
+        d = 2.f * (p - t) * inv_count * p * (1.f - p);
+    } else {
+        const float ddice = (2.f * t * den - (2.f * inter + 1.f)) / (den * den);
+        d = w_bce * (p - t) * inv_count - w_dice * lg * ddice * p * (1.f - p);
+    }
+    dlogit[i] = d;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ dl, unsigned char* __restrict__ dx,
+                                                       long long rows, int cin, int k, RedGeom gm, float* __restrict__ ws) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float lds[256 * VE];
+    const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
+    const bool active = prow < gm.rpi;
+    const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < rows) ? r0 + gm.chunk : rows;
+    float part[2 * RVIP_MAXK][VE];
+#pragma unroll
+    for (int q = 0; q < 2 * RVIP_MAXK; ++q)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) part[q][e] = 0.f;
+    float wr[VE][RVIP_MAXK];
+#pragma unroll
+    for (int e = 0; e < VE; ++e)
+#pragma unroll
+        for (int kk = 0; kk < RVIP_MAXK; ++kk) wr[e][kk] = (active && kk < k) ? w[(cgi * VE + e) * k + kk] : 0.f;
+    if (active) {
+        for (long long r = r0 + prow; r < r1; r += gm.rpi) {
+            float d[RVIP_MAXK];
+#pragma unroll
+            for (int kk = 0; kk < RVIP_MAXK; ++kk) d[kk] = kk < k ? dl[(size_t)r * k + kk] : 0.f;
+            float v[VE], o[VE];
+            Vec<T>::load(x + ((size_t)r * cin + cgi * VE) * sizeof(T), v);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < RVIP_MAXK; ++kk) { acc = fmaf(d[kk], wr[e][kk], acc); part[kk][e] = fmaf(v[e], d[kk], part[kk][e]); }
+                o[e] = acc;
+            }
+            if (cgi == 0) {
+#pragma unroll
+                for (int kk = 0; kk < RVIP_MAXK; ++kk) part[RVIP_MAXK + kk][0] += d[kk];
+            }
+            if (dx) Vec<T>::store(dx + ((size_t)r * cin + cgi * VE) * sizeof(T), o);
+        }
+    }
+    block_fold<2 * RVIP_MAXK, VE>(part, active, prow * gm.cg + cgi, cin, gm.rpi, lds, ws + (size_t)blockIdx.x * 2 * RVIP_MAXK * cin);
+}
+
+struct PostHeadBwd {                   // ws columns: [2*MAXK][cin]; K template = 2*MAXK
+    float* dw; float* db; int cin, k;
+    __device__ void run(int ch, const double (&t)[2 * RVIP_MAXK]) const {
+        for (int kk = 0; kk < k; ++kk) dw[ch * k + kk] = (float)t[kk];
+        if (ch == 0) for (int kk = 0; kk < k; ++kk) db[kk] = (float)t[RVIP_MAXK + kk];
+    }
+};
+
+// first layer (Cin = 1) weight gradient: dw[t][co] = sum_p x[p + off(t)] * dy[p][co]
+template <typename T>
+__global__ __launch_bounds__(256) void c1_wgrad_kernel(const T* __restrict__ x, const unsigned char* __restrict__ dy,
+                                                       int n, int h, int w, int cout, RedGeom gm, float* __restrict__ ws) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float lds[256 * VE];
+    const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
+    const bool active = prow < gm.rpi;
+    const long long rows = (long long)n * h * w;
+    const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < rows) ? r0 + gm.chunk : rows;
+    float part[9][VE];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) part[t][e] = 0.f;
+    if (active) {
+        for (long long r = r0 + prow; r < r1; r += gm.rpi) {
+            const int px = (int)(r % w), py = (int)((r / w) % h);
+            const long long img = r / ((long long)w * h);
+            float g[VE];
+            Vec<T>::load(dy + ((size_t)r * cout + cgi * VE) * sizeof(T), g);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                float xv = 0.f;
+                if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+                    if constexpr (sizeof(T) == 4) xv = x[(img * h + yy) * w + xx];
+                    else xv = bf16_to_f32(x[(img * h + yy) * w + xx].bits);
+                }
+#pragma unroll
+                for (int e = 0; e < VE; ++e) part[t][e] = fmaf(xv, g[e], part[t][e]);
+            }
+        }
+    }
+    block_fold<9, VE>(part, active, prow * gm.cg + cgi, cout, gm.rpi, lds, ws + (size_t)blockIdx.x * 9 * cout);
+}
+
+struct PostC1Wgrad {
+    float* dw; int cout;
+    __device__ void run(int ch, const double (&t)[9]) const {
+        for (int k = 0; k < 9; ++k) dw[k * cout + ch] = (float)t[k];
+    }
+};
+
+// landmark = flat argmax over H*W per (slice, class), first maximum wins; optional > thr mask
+__global__ __launch_bounds__(256) void landmarks_kernel(const float* __restrict__ pred, long long* __restrict__ idx_out,
+                                                        uint8_t* __restrict__ mask_out, int hw, int k, float thr) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int n = blockIdx.x / k, kk = blockIdx.x % k, tid = threadIdx.x;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < hw; i += 256) {
+        const float v = pred[((size_t)n * hw + i) * k + kk];
+        if (mask_out) mask_out[((size_t)n * hw + i) * k + kk] = v > thr ? 1 : 0;
+        if (v > bv) { bv = v; bi = i; }                        // strided ascending scan: first max per thread
+    }
+    sv[tid] = bv; si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float v2 = sv[tid + o]; const int i2 = si[tid + o];
+            if (v2 > sv[tid] || (v2 == sv[tid] && i2 < si[tid])) { sv[tid] = v2; si[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) idx_out[blockIdx.x] = si[0] == 0x7fffffff ? 0 : si[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Keras Adam, state tick, dtype conversion
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long count, float b1, float b2, float eps,
+                                                   float gscale, const uint32_t* __restrict__ state) {
+    const float t = (float)(state[RVIP_STATE_STEP] + 1u);
+    const float lr = __builtin_bit_cast(float, state[RVIP_STATE_LR]);
+    const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        th[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+__global__ void state_tick_kernel(uint32_t* state) { if (threadIdx.x == 0 && blockIdx.x == 0) state[RVIP_STATE_STEP] += 1u; }
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ s, D* __restrict__ d, long long count) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        float v;
+        if constexpr (sizeof(S) == 4) v = s[i]; else v = bf16_to_f32(s[i].bits);
+        if constexpr (sizeof(D) == 4) d[i] = v; else d[i].bits = f32_to_bf16(v);
+    }
+}
+
+}  // namespace rvip
+
+using namespace rvip;
+
+#define RVIP_VE(dt) ((dt) == RVIP_BF16 ? 8 : 4)
+#define RVIP_DT_OK(dt) ((dt) == RVIP_BF16 || (dt) == RVIP_F32)
+
+extern "C" size_t rvip_reduce_workspace(long long rows, int width) {
+    (void)rows;
+    return (size_t)1024 * (size_t)(width > 16 ? width : 16) * sizeof(float);
+}
+
+extern "C" int rvip_bn_train_stats(const void* z, long long rows, int c, int dtype, const float* gamma, const float* beta,
+                                   float* moving_mean, float* moving_var, float momentum, float eps, int unbiased_moving,
+                                   float* mean, float* invstd, float* scale, float* shift,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!z || !mean || !invstd || !scale || !shift || !workspace || !RVIP_DT_OK(dtype)) return RVIP_EINVAL;
+    RedGeom g;
+    if (!red_geom(rows, c, RVIP_VE(dtype), g)) return RVIP_EINVAL;
+    if (workspace_bytes < (size_t)g.nblk * 2 * c * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)z, rows, c, g, ws);
+    else hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)z, rows, c, g, ws);
+    int rc = check_launch();
+    if (rc) return rc;
+    PostBnStats p{gamma, beta, moving_mean, moving_var, mean, invstd, scale, shift, (double)rows, momentum, eps, unbiased_moving};
+    return launch_fold<2, PostBnStats>(ws, g.nblk, c, p, s);
+}
+
+extern "C" int rvip_bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int c,
+                                    float* scale, float* shift, void* stream) {
+    if (!mm || !mv || !scale || !shift || c <= 0) return RVIP_EINVAL;
+    hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3((unsigned)cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mm, mv, eps, c, scale, shift);
+    return check_launch();
+}
+
+extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
+    if (!d || !d->z || !d->y || !RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
+    const int ve = RVIP_VE(d->dtype);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->c % ve) return RVIP_EINVAL;
+    if (d->pooled && ((d->h | d->w) & 1)) return RVIP_EINVAL;
+    if (d->drop_rate < 0.f || d->drop_rate >= 1.f) return RVIP_EINVAL;
+    const int drop = d->drop_rate > 0.f;
+    if (drop && !d->mask && !d->state) return RVIP_EINVAL;
+    ApplyArgs a;
+    a.z = (const unsigned char*)d->z; a.y = (unsigned char*)d->y; a.pooled = (unsigned char*)d->pooled;
+    a.scale = d->scale; a.shift = d->shift; a.act = d->act;
+    a.inv_keep = drop ? 1.f / (1.f - d->drop_rate) : 1.f; a.thr = dropout_thr(d->drop_rate);
+    a.mask = d->mask; a.state = d->state; a.layer_id = d->layer_id; a.drop = drop;
+    a.n = d->n; a.h = d->h; a.w = d->w; a.c = d->c;
+    const long long cg = d->c / ve;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->pooled) {
+        const long long total = (long long)d->n * (d->h / 2) * (d->w / 2) * cg;
+        dim3 grid((unsigned)cdiv(total, 256));
+        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((bn_apply_kernel<float, true>), grid, dim3(256), 0, s, a);
+    } else {
+        const long long total = (long long)d->n * d->h * d->w * cg;
+        dim3 grid((unsigned)cdiv(total, 256));
+        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((bn_apply_kernel<float, false>), grid, dim3(256), 0, s, a);
+    }
+    return check_launch();
+}
+
+static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
+    if (!d || !d->dy || !d->z || !RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
+    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g)) return RVIP_EINVAL;
+    if (d->drop_rate < 0.f || d->drop_rate >= 1.f) return RVIP_EINVAL;
+    const int drop = d->drop_rate > 0.f;
+    if (drop && !d->mask && !d->state) return RVIP_EINVAL;
+    if (!d->workspace) return RVIP_EINVAL;
+    a.dy = (const unsigned char*)d->dy; a.z = (const unsigned char*)d->z; a.dz = (unsigned char*)d->dz;
+    a.mean = d->mean; a.invstd = d->invstd; a.scale = d->scale; a.shift = d->shift; a.coef = d->coef;
+    a.act = d->act; a.act_after_bn = d->act_after_bn; a.has_bn = d->gamma != nullptr;
+    a.inv_keep = drop ? 1.f / (1.f - d->drop_rate) : 1.f; a.thr = dropout_thr(d->drop_rate);
+    a.mask = d->mask; a.state = d->state; a.layer_id = d->layer_id; a.drop = drop;
+    a.rows = d->rows; a.c = d->c;
+    return RVIP_OK;
+}
+
+extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
+    BnBwdArgs a; RedGeom g;
+    int rc = fill_bnbwd(d, a, g);
+    if (rc) return rc;
+    if (!d->gamma || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->coef) return RVIP_EINVAL;
+    if (d->workspace_bytes < (size_t)g.nblk * 2 * d->c * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)d->workspace;
+    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    rc = check_launch();
+    if (rc) return rc;
+    PostBnBwd p{d->gamma, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef, (double)d->rows, d->c};
+    return launch_fold<2, PostBnBwd>(ws, g.nblk, d->c, p, s);
+}
+
+extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
+    BnBwdArgs a; RedGeom g;
+    int rc = fill_bnbwd(d, a, g);
+    if (rc) return rc;
+    if (!d->dz || !d->dbias) return RVIP_EINVAL;
+    if (d->gamma && !d->coef) return RVIP_EINVAL;
+    if (d->workspace_bytes < (size_t)g.nblk * d->c * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)d->workspace;
+    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    rc = check_launch();
+    if (rc) return rc;
+    PostSum p{d->dbias};
+    return launch_fold<1, PostSum>(ws, g.nblk, d->c, p, s);
+}
+
+extern "C" int rvip_maxpool2x2_bwd(const void* y, const void* dpooled, const void* add, void* dx, int n, int h, int w, int c,
+                                   int dtype, void* stream) {
+    if (!y || !dpooled || !dx || !RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w <= 0 || ((h | w) & 1) || c <= 0 || c % RVIP_VE(dtype)) return RVIP_EINVAL;
+    const long long total = (long long)n * (h / 2) * (w / 2) * (c / RVIP_VE(dtype));
+    dim3 grid((unsigned)cdiv(total, 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const unsigned char*)y, (const unsigned char*)dpooled, (const unsigned char*)add, (unsigned char*)dx, n, h, w, c);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, s, (const unsigned char*)y, (const unsigned char*)dpooled, (const unsigned char*)add, (unsigned char*)dx, n, h, w, c);
+    return check_launch();
+}
+
+template <bool BWD>
+static int launch_upsample(const void* src, void* dst, int n, int h, int w, int c, int dtype, void* stream) {
+    if (!src || !dst || !RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % RVIP_VE(dtype)) return RVIP_EINVAL;
+    const long long total = (long long)n * h * w * (c / RVIP_VE(dtype));
+    dim3 grid((unsigned)cdiv(total, 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL((upsample_kernel<bf16_t, BWD>), grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
+    else hipLaunchKernelGGL((upsample_kernel<float, BWD>), grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
+    return check_launch();
+}
+// h, w are the LOW-resolution extents for both directions
+extern "C" int rvip_upsample2x_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream) {
+    return launch_upsample<false>(x, y, n, h, w, c, dtype, stream);
+}
+extern "C" int rvip_upsample2x_bwd(const void* dy, void* dx, int n, int h, int w, int c, int dtype, void* stream) {
+    return launch_upsample<true>(dy, dx, n, h, w, c, dtype, stream);
+}
+
+struct PostHeadSums {
+    float* sums;
+    __device__ void run(int ch, const double (&t)[1]) const { sums[ch] = (float)t[0]; }
+};
+
+extern "C" int rvip_head_fwd(const void* x, const float* w, const float* b, float* pred, const float* y_true, float* sums,
+                             long long rows, int cin, int k, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !w || !pred || !RVIP_DT_OK(dtype) || rows <= 0 || cin <= 0 || cin % RVIP_VE(dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
+    if (y_true && (!sums || !workspace)) return RVIP_EINVAL;
+    long long nb = cdiv(rows, 256 * 4);
+    if (nb > 1024) nb = 1024;
+    const long long chunk = cdiv(rows, nb);
+    nb = cdiv(rows, chunk);
+    if (y_true && workspace_bytes < (size_t)nb * 16 * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = y_true ? (float*)workspace : nullptr;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const unsigned char*)x, w, b, pred, y_true, rows, cin, k, chunk, ws);
+    else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const unsigned char*)x, w, b, pred, y_true, rows, cin, k, chunk, ws);
+    int rc = check_launch();
+    if (rc || !y_true) return rc;
+    PostHeadSums p{sums};
+    return launch_fold<1, PostHeadSums>(ws, (int)nb, 16, p, s);
+}
+
+extern "C" int rvip_head_grad(const float* pred, const float* y_true, const float* sums, float* dlogit, float* loss_out,
+                              long long rows, int k, int loss_kind, float inv_count, float local_over_global,
+                              float w_bce, float w_dice, void* stream) {
+    if (!pred || !y_true || !sums || !dlogit || rows <= 0 || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
+    if (loss_kind != RVIP_LOSS_MSE && loss_kind != RVIP_LOSS_BCE_DICE) return RVIP_EINVAL;
+    const long long count = rows * k;
+    hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, pred, y_true, sums, dlogit, loss_out, count, loss_kind, inv_count, local_over_global, w_bce, w_dice);
+    return check_launch();
+}
+
+extern "C" int rvip_head_bwd(const void* x, const float* w, const float* dlogit, void* dx, float* dw, float* db,
+                             long long rows, int cin, int k, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !w || !dlogit || !dw || !db || !workspace || !RVIP_DT_OK(dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
+    RedGeom g;
+    if (!red_geom(rows, cin, RVIP_VE(dtype), g)) return RVIP_EINVAL;
+    if (workspace_bytes < (size_t)g.nblk * 2 * RVIP_MAXK * cin * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)x, w, dlogit, (unsigned char*)dx, rows, cin, k, g, ws);
+    else hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)x, w, dlogit, (unsigned char*)dx, rows, cin, k, g, ws);
+    int rc = check_launch();
+    if (rc) return rc;
+    PostHeadBwd p{dw, db, cin, k};
+    return launch_fold<2 * RVIP_MAXK, PostHeadBwd>(ws, g.nblk, cin, p, s);
+}
+
+extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cout, int dtype,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || !workspace || !RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w_ <= 0) return RVIP_EINVAL;
+    RedGeom g;
+    if (!red_geom((long long)n * h * w_, cout, RVIP_VE(dtype), g)) return RVIP_EINVAL;
+    if (workspace_bytes < (size_t)g.nblk * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
+    else hipLaunchKernelGGL(c1_wgrad_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
+    int rc = check_launch();
+    if (rc) return rc;
+    PostC1Wgrad p{dw, cout};
+    return launch_fold<9, PostC1Wgrad>(ws, g.nblk, cout, p, s);
+}
+
+extern "C" int rvip_landmarks(const float* pred, long long* idx_out, uint8_t* mask_out, int n, int hw, int k, float thr, void* stream) {
+    if (!pred || !idx_out || n <= 0 || hw <= 0 || k <= 0) return RVIP_EINVAL;
+    hipLaunchKernelGGL(landmarks_kernel, dim3((unsigned)(n * k)), dim3(256), 0, (hipStream_t)stream, pred, idx_out, mask_out, hw, k, thr);
+    return check_launch();
+}
+
+extern "C" int rvip_adam_step(float* theta, const float* grad, float* m, float* v, long long count, float beta1, float beta2,
+                              float eps, float grad_scale, const uint32_t* state, void* stream) {
+    if (!theta || !grad || !m || !v || !state || count <= 0) return RVIP_EINVAL;
+    long long nb = cdiv(count, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, theta, grad, m, v, count, beta1, beta2, eps, grad_scale, state);
+    return check_launch();
+}
+
+extern "C" int rvip_state_tick(uint32_t* state, void* stream) {
+    if (!state) return RVIP_EINVAL;
+    hipLaunchKernelGGL(state_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
+    return check_launch();
+}
+
+extern "C" int rvip_convert(const void* src, int sdt, void* dst, int ddt, long long count, void* stream) {
+    if (!src || !dst || count <= 0 || !RVIP_DT_OK(sdt) || !RVIP_DT_OK(ddt)) return RVIP_EINVAL;
+    long long nb = cdiv(count, 256);
+    if (nb > 4096) nb = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)nb), blk(256);
+    if (sdt == RVIP_F32 && ddt == RVIP_BF16) hipLaunchKernelGGL((convert_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)src, (bf16_t*)dst, count);
+    else if (sdt == RVIP_BF16 && ddt == RVIP_F32) hipLaunchKernelGGL((convert_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)src, (float*)dst, count);
+    else if (sdt == RVIP_F32) hipLaunchKernelGGL((convert_kernel<float, float>), grid, blk, 0, s, (const float*)src, (float*)dst, count);
+    else hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)src, (bf16_t*)dst, count);
+    return check_launch();
+}

@@ -1,0 +1,453 @@
+"""HIP execution engine of the fused U-Net plan (one process = one MI355X).
+
+PyTorch is plumbing here: it owns device memory (``torch.empty``), the stream and the process group; every
+FLOP of the step is a kernel of librvip_hip.so launched through the C ABI (``_native``).  No tensor op of
+torch touches the hot path, and there is no CPU fallback: without the library or a GPU this module raises.
+
+Data layout in HBM (per rank)
+  * parameters: ONE flat fp32 block ``theta`` (Keras HWIO kernels, biases, gamma, beta; every tensor starts on
+    a 256-byte boundary) with twin blocks ``grad``, ``adam_m``, ``adam_v``: the optimiser and the RCCL
+    all-reduce see a single contiguous buffer;
+  * BN moving statistics: a second flat fp32 block (not trained, not all-reduced per step);
+  * packed conv operands in the activation dtype (bf16/f32): [9][Cout][Cin] forward, [9][Cin][Cout] dgrad;
+  * activations NHWC in the activation dtype, one buffer per tensor of the fused plan (z = conv output kept
+    for backward, y = BN/dropout output consumed by the next conv, pooled); gradients mirror them;
+  * ``state``: 8 device words (step, lr, dropout seed) read by the kernels so a captured hipGraph replays
+    with fresh values.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _native as N
+
+BN_MOMENTUM, BN_EPS = 0.99, 1e-3          # Keras BatchNormalization defaults (KerasLayers.py:684 passes none)
+ALIGN = 64                                 # floats: every parameter tensor starts 256-byte aligned
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    N.lib()
+    if not torch.cuda.is_available():
+        raise N.RvipError('no HIP device visible: the RVIP engine has no CPU path (oracle/ is test-only)')
+    return torch
+
+
+def _ptr(t, offset_elems=0):
+    return C.c_void_p(t.data_ptr() + offset_elems * t.element_size())
+
+
+class ParamStore:
+    """Flat device parameter blocks + packed conv operands, shared by every per-batch-size Engine."""
+
+    def __init__(self, plan, host_weights, dtype, device, seed=42, lr=1e-3):
+        torch = require_gpu()
+        self.plan, self.device = plan, device
+        self.dt = N.BF16 if dtype == 'bf16' else N.F32
+        self.tdtype = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self.off, self.moff = OrderedDict(), OrderedDict()
+        n_tr = n_mv = 0
+        for (lname, wname, shape, trainable, _), arr in zip(plan.weight_specs(), host_weights):
+            size = int(np.prod(shape))
+            if trainable:
+                self.off[(lname, wname)] = (n_tr, tuple(shape))
+                n_tr += -(-size // ALIGN) * ALIGN
+            else:
+                self.moff[(lname, wname)] = (n_mv, tuple(shape))
+                n_mv += -(-size // ALIGN) * ALIGN
+        self.count = n_tr
+        f32 = dict(dtype=torch.float32, device=device)
+        self.theta = torch.zeros(n_tr, **f32)
+        self.grad = torch.zeros(n_tr, **f32)
+        self.adam_m = torch.zeros(n_tr, **f32)
+        self.adam_v = torch.zeros(n_tr, **f32)
+        self.moving = torch.zeros(max(n_mv, ALIGN), **f32)
+        self.state = torch.zeros(N.STATE_WORDS, dtype=torch.int32, device=device)
+        self.set_lr(lr)
+        self.set_seed(seed)
+        self.packed = {}
+        for st in plan.stages:
+            if st.transpose:
+                raise NotImplementedError('USE_UPSAMPLE=False (Conv2DTranspose decoder, KerasLayers.py:761-765) is not built '
+                                          'yet; the default UpSampling+Conv path is')
+            if st.src0 != 'input_1':
+                k = 9 * st.cin * st.cout
+                self.packed[st.conv] = (torch.empty(k, dtype=self.tdtype, device=device),
+                                        torch.empty(k, dtype=self.tdtype, device=device))
+        self.upload(host_weights)
+
+    # -- host <-> device ------------------------------------------------------------------------------
+    def upload(self, host_weights):
+        torch = _torch()
+        th = np.zeros(self.count, np.float32)
+        mv = np.zeros(self.moving.numel(), np.float32)
+        for (lname, wname, shape, trainable, _), arr in zip(self.plan.weight_specs(), host_weights):
+            a = np.asarray(arr, np.float32).reshape(-1)
+            if a.size != int(np.prod(shape)):
+                raise ValueError('weight %s/%s: expected shape %s' % (lname, wname, (shape,)))
+            if trainable:
+                o = self.off[(lname, wname)][0]
+                th[o:o + a.size] = a
+            else:
+                o = self.moff[(lname, wname)][0]
+                mv[o:o + a.size] = a
+        self.theta.copy_(torch.from_numpy(th))
+        self.moving.copy_(torch.from_numpy(mv))
+        self.repack(torch.cuda.current_stream().cuda_stream)
+
+    def download(self):
+        th = self.theta.detach().cpu().numpy()
+        mv = self.moving.detach().cpu().numpy()
+        out = []
+        for (lname, wname, shape, trainable, _) in self.plan.weight_specs():
+            size = int(np.prod(shape))
+            src, o = (th, self.off[(lname, wname)][0]) if trainable else (mv, self.moff[(lname, wname)][0])
+            out.append(src[o:o + size].reshape(shape).copy())
+        return out
+
+    def grads_host(self):
+        g = self.grad.detach().cpu().numpy()
+        return OrderedDict((k, g[o:o + int(np.prod(s))].reshape(s).copy()) for k, (o, s) in self.off.items())
+
+    def p(self, lname, wname):
+        return _ptr(self.theta, self.off[(lname, wname)][0])
+
+    def g(self, lname, wname):
+        return _ptr(self.grad, self.off[(lname, wname)][0])
+
+    def mv(self, lname, wname):
+        return _ptr(self.moving, self.moff[(lname, wname)][0])
+
+    def set_lr(self, lr):
+        self.state.view(_torch().float32)[N.STATE_LR] = float(lr)
+
+    def set_seed(self, seed):
+        self.state[N.STATE_SEED] = int(seed) & 0x7fffffff
+
+    def set_step(self, step):
+        self.state[N.STATE_STEP] = int(step)
+
+    def step_count(self):
+        return int(self.state[N.STATE_STEP].item())
+
+    def repack(self, stream):
+        L = N.lib()
+        for st in self.plan.stages:
+            if st.conv in self.packed:
+                wf, wd = self.packed[st.conv]
+                N.check(L.rvip_pack_conv3x3_weights(self.p(st.conv, 'kernel'), st.cin, st.cout, self.dt, _ptr(wf), _ptr(wd),
+                                                    C.c_void_p(stream)), 'rvip_pack_conv3x3_weights')
+
+
+class Engine:
+    """Activation/gradient buffers and pre-built launch lists for ONE (batch size, loss) configuration."""
+
+    def __init__(self, params, batch, loss_kind='mse', w_bce=0.5, w_dice=1.0, world=1, masks=None):
+        torch = require_gpu()
+        L = N.lib()
+        self.P, self.plan, self.n = params, params.plan, int(batch)
+        plan, P, n = self.plan, params, self.n
+        if plan.ndims != 2:
+            raise NotImplementedError('3-D (Conv3D) graphs are a later round; DIM must have 2 entries')
+        ve = 8 if P.dt == N.BF16 else 4
+        for st in plan.stages:
+            if st.cout % ve or (st.src0 != 'input_1' and (st.c0 % ve or st.c1 % ve)):
+                raise ValueError('channel counts must be multiples of %d for %s activations (layer %s: %d -> %d)'
+                                 % (ve, 'bf16' if ve == 8 else 'f32', st.conv, st.cin, st.cout))
+        if plan.img_channels != 1:
+            raise NotImplementedError('IMG_CHANNELS != 1: the first-layer kernel is the Cin = 1 specialisation')
+        dev, T = P.device, P.tdtype
+        self.world = world
+        self.loss_kind = N.LOSS_MSE if loss_kind == 'mse' else N.LOSS_BCE_DICE
+        self.w_bce, self.w_dice = float(w_bce), float(w_dice)
+        self.masks = masks or {}                  # dropout layer name -> uint8 device tensor (parity runs)
+        H, W = plan.dim
+        K = plan.mask_classes
+        self.act, self.grd, self.gskip = {}, {}, {}
+        shape = {}
+
+        def alloc(name, h, w, c, store):
+            if name not in store:
+                store[name] = torch.empty((n, h, w, c), dtype=T, device=dev)
+                shape[name] = (h, w, c)
+            return store[name]
+
+        alloc('input_1', H, W, 1, self.act)
+        skip_names = {st.src1 for st in plan.stages if st.src1}
+        for st in plan.stages:
+            alloc(st.z, st.h, st.w, st.cout, self.act)
+            st_needs_apply = bool(st.bn or st.act_post or st.drop or st.pool)
+            if st_needs_apply:
+                alloc(st.y, st.h, st.w, st.cout, self.act)
+            else:
+                self.act[st.y] = self.act[st.z]
+                shape[st.y] = shape[st.z]
+            if st.pool:
+                alloc(st.pooled, st.h // 2, st.w // 2, st.cout, self.act)
+        # gradients: d(y) per stage, d(pooled), d(z) (= grad of the conv output), skip-branch grads
+        self.dz = {}
+        for st in plan.stages:
+            alloc(st.y, st.h, st.w, st.cout, self.grd)
+            alloc(st.z, st.h, st.w, st.cout, self.dz)
+            if st.pool:
+                alloc(st.pooled, st.h // 2, st.w // 2, st.cout, self.grd)
+            if st.y in skip_names:
+                alloc(st.y, st.h, st.w, st.cout, self.gskip)
+        self.up_tmp = {}
+        for st in plan.stages:
+            if st.up0:
+                self.up_tmp[st.conv] = torch.empty((n, st.h, st.w, st.c0), dtype=T, device=dev)
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.y_true = torch.zeros((n, H, W, K), **f32)
+        self.pred = torch.empty((n, H, W, K), **f32)
+        self.dlogit = torch.empty((n, H, W, K), **f32)
+        self.sums = torch.zeros(16, **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.x_stage = torch.empty((n, H, W, 1), **f32)
+        self.lm_idx = torch.zeros((n, K), dtype=torch.int64, device=dev)
+        # per-BN scratch: mean, invstd, scale, shift, coef[3]  -> 7*C floats per stage
+        cmax_tot = sum(7 * (-(-st.cout // ALIGN) * ALIGN) for st in plan.stages)
+        self.bn_scratch = torch.zeros(max(cmax_tot, ALIGN), **f32)
+        self.bn_off = {}
+        o = 0
+        for st in plan.stages:
+            ca = -(-st.cout // ALIGN) * ALIGN
+            self.bn_off[st.conv] = (o, ca)
+            o += 7 * ca
+        # workspace: max over every kernel's need
+        need = 0
+        for st in plan.stages:
+            rows = n * st.h * st.w
+            need = max(need, L.rvip_reduce_workspace(rows, 16 * st.cout))
+            if st.src0 != 'input_1':
+                need = max(need, L.rvip_conv3x3_wgrad_workspace(n, st.h, st.w, st.cin, st.cout))
+        need = max(need, L.rvip_reduce_workspace(n * H * W, 8 * plan.head['cin']))
+        self.ws = torch.empty(need // 4 + 64, **f32)
+        self.ws_bytes = need
+        self._build_lists()
+
+    # -- helpers --------------------------------------------------------------------------------------
+    def _bn(self, st, which):
+        o, ca = self.bn_off[st.conv]
+        idx = {'mean': 0, 'invstd': 1, 'scale': 2, 'shift': 3, 'coef': 4}[which]
+        return _ptr(self.bn_scratch, o + idx * ca)
+
+    def _build_lists(self):
+        L, P, plan, n = N.lib(), self.P, self.plan, self.n
+        dt = P.dt
+        A = N.ACT
+        ws, wsb = _ptr(self.ws), C.c_size_t(self.ws_bytes)
+        state = _ptr(P.state)
+        self._keep = []                 # keep ctypes structs alive
+        fwd_t, fwd_i, bwd = [], [], []
+
+        for st in plan.stages:
+            rows = n * st.h * st.w
+            z, y = self.act[st.z], self.act[st.y]
+            first = st.src0 == 'input_1'
+            bias = P.p(st.conv, 'bias')
+            act_conv = A[st.act_conv]
+            # ---- conv ----
+            if first:
+                call = (L.rvip_conv3x3_c1_fwd, (_ptr(self.act['input_1']), P.p(st.conv, 'kernel'), bias, _ptr(z),
+                                                n, st.h, st.w, st.cout, act_conv, dt))
+            else:
+                d = N.Conv3x3Desc()
+                d.x0, d.c0, d.up0 = self.act[st.src0].data_ptr(), st.c0, st.up0
+                d.x1, d.c1 = (self.act[st.src1].data_ptr(), st.c1) if st.src1 else (None, 0)
+                d.w_packed = P.packed[st.conv][0].data_ptr()
+                d.bias = bias.value
+                d.y, d.y1, d.csplit = z.data_ptr(), None, 0
+                d.n, d.h, d.w, d.cout, d.act, d.dtype = n, st.h, st.w, st.cout, act_conv, dt
+                self._keep.append(d)
+                call = (L.rvip_conv3x3_fwd, (C.byref(d),))
+            fwd_t.append(call)
+            fwd_i.append(call)
+            # ---- BN statistics / coefficients ----
+            if st.bn:
+                fwd_t.append((L.rvip_bn_train_stats, (
+                    _ptr(z), C.c_longlong(rows), st.cout, dt, P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'),
+                    P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), 1,
+                    self._bn(st, 'mean'), self._bn(st, 'invstd'), self._bn(st, 'scale'), self._bn(st, 'shift'), ws, wsb)))
+                fwd_i.append((L.rvip_bn_infer_coeffs, (
+                    P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'), P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'),
+                    C.c_float(BN_EPS), st.cout, self._bn(st, 'scale'), self._bn(st, 'shift'))))
+            # ---- apply (BN affine, act-after-BN, dropout, pool) ----
+            if y is not z:
+                for training in (True, False):
+                    a = N.ApplyDesc()
+                    a.z, a.y = z.data_ptr(), y.data_ptr()
+                    a.pooled = self.act[st.pooled].data_ptr() if st.pool else None
+                    a.scale = self._bn(st, 'scale').value if st.bn else None
+                    a.shift = self._bn(st, 'shift').value if st.bn else None
+                    a.act = A[st.act_post]
+                    a.drop_rate, a.mask, a.state, a.layer_id = 0.0, None, state.value, 0
+                    if training and st.drop and st.drop[1] > 0:
+                        a.drop_rate, a.layer_id = st.drop[1], st.drop[2]
+                        if st.drop[0] in self.masks:
+                            a.mask = self.masks[st.drop[0]].data_ptr()
+                    a.n, a.h, a.w, a.c, a.dtype = n, st.h, st.w, st.cout, dt
+                    self._keep.append(a)
+                    (fwd_t if training else fwd_i).append((L.rvip_bn_apply, (C.byref(a),)))
+
+        hd = plan.head
+        hrows = C.c_longlong(n * hd['h'] * hd['w'])
+        hx = self.act[hd['src']]
+        hw_, hb_ = P.p(hd['conv'], 'kernel'), P.p(hd['conv'], 'bias')
+        fwd_t.append((L.rvip_head_fwd, (_ptr(hx), hw_, hb_, _ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), hrows,
+                                        hd['cin'], hd['k'], dt, ws, wsb)))
+        fwd_i.append((L.rvip_head_fwd, (_ptr(hx), hw_, hb_, _ptr(self.pred), None, None, hrows, hd['cin'], hd['k'], dt,
+                                        None, C.c_size_t(0))))
+        self.fwd_eval = fwd_i[:-1] + [fwd_t[-1]]          # inference-mode network + loss sums (validation)
+
+        # ---------------- backward ----------------
+        per_rank = float(n * hd['h'] * hd['w'] * hd['k'])
+        self._inv_count = 1.0 / (per_rank * self.world)
+        bwd.append((L.rvip_head_grad, (_ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), _ptr(self.dlogit), _ptr(self.loss),
+                                       hrows, hd['k'], self.loss_kind, C.c_float(self._inv_count), C.c_float(1.0 / self.world),
+                                       C.c_float(self.w_bce), C.c_float(self.w_dice))))
+        bwd.append((L.rvip_head_bwd, (_ptr(hx), hw_, _ptr(self.dlogit), _ptr(self.grd[hd['src']]), P.g(hd['conv'], 'kernel'),
+                                      P.g(hd['conv'], 'bias'), hrows, hd['cin'], hd['k'], dt, ws, wsb)))
+        for st in reversed(plan.stages):
+            rows = n * st.h * st.w
+            first = st.src0 == 'input_1'
+            gy, dz, z = self.grd[st.y], self.dz[st.z], self.act[st.z]
+            if st.pool:
+                add = self.gskip.get(st.y)
+                bwd.append((L.rvip_maxpool2x2_bwd, (_ptr(self.act[st.y]), _ptr(self.grd[st.pooled]),
+                                                    _ptr(add) if add is not None else None, _ptr(gy), n, st.h, st.w, st.cout, dt)))
+            elif st.y in self.gskip:
+                raise NotImplementedError('skip tensor without pooling')
+            b = N.BnBwdDesc()
+            b.dy, b.z, b.dz = gy.data_ptr(), z.data_ptr(), dz.data_ptr()
+            if st.bn:
+                b.gamma = P.p(st.bn, 'gamma').value
+                b.mean, b.invstd = self._bn(st, 'mean').value, self._bn(st, 'invstd').value
+                b.scale, b.shift = self._bn(st, 'scale').value, self._bn(st, 'shift').value
+                b.dgamma, b.dbeta = P.g(st.bn, 'gamma').value, P.g(st.bn, 'beta').value
+                b.coef = self._bn(st, 'coef').value
+            b.dbias = P.g(st.conv, 'bias').value
+            b.act = N.ACT[st.act_post] if st.act_post else N.ACT[st.act_conv]
+            b.act_after_bn = 1 if st.act_post else 0
+            b.drop_rate, b.mask, b.state, b.layer_id = 0.0, None, state.value, 0
+            if st.drop and st.drop[1] > 0:
+                b.drop_rate, b.layer_id = st.drop[1], st.drop[2]
+                if st.drop[0] in self.masks:
+                    b.mask = self.masks[st.drop[0]].data_ptr()
+            b.rows, b.c, b.dtype = rows, st.cout, dt
+            b.workspace, b.workspace_bytes = self.ws.data_ptr(), self.ws_bytes
+            self._keep.append(b)
+            if st.bn:
+                bwd.append((L.rvip_bn_bwd_reduce, (C.byref(b),)))
+            bwd.append((L.rvip_bn_bwd_apply, (C.byref(b),)))
+            if first:
+                bwd.append((L.rvip_conv3x3_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, st.h, st.w,
+                                                      st.cout, dt, ws, wsb)))
+                continue
+            wg = N.Wgrad3x3Desc()
+            wg.x0, wg.c0, wg.up0 = self.act[st.src0].data_ptr(), st.c0, st.up0
+            wg.x1, wg.c1 = (self.act[st.src1].data_ptr(), st.c1) if st.src1 else (None, 0)
+            wg.dy, wg.dw = dz.data_ptr(), P.g(st.conv, 'kernel').value
+            wg.n, wg.h, wg.w, wg.cout, wg.dtype = n, st.h, st.w, st.cout, dt
+            wg.workspace, wg.workspace_bytes = self.ws.data_ptr(), self.ws_bytes
+            self._keep.append(wg)
+            bwd.append((L.rvip_conv3x3_wgrad, (C.byref(wg),)))
+            dg = N.Conv3x3Desc()
+            dg.x0, dg.c0, dg.up0, dg.x1, dg.c1 = dz.data_ptr(), st.cout, 0, None, 0
+            dg.w_packed, dg.bias = P.packed[st.conv][1].data_ptr(), None
+            dg.n, dg.h, dg.w, dg.cout, dg.act, dg.dtype = n, st.h, st.w, st.cin, 0, dt
+            dg.y1, dg.csplit = None, 0
+            if st.src1:
+                dg.y, dg.y1, dg.csplit = self.grd[st.src0].data_ptr(), self.gskip[st.src1].data_ptr(), st.c0
+            elif st.up0:
+                dg.y = self.up_tmp[st.conv].data_ptr()
+            else:
+                dg.y = self.grd[st.src0].data_ptr()
+            self._keep.append(dg)
+            bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
+            if st.up0:
+                bwd.append((L.rvip_upsample2x_bwd, (_ptr(self.up_tmp[st.conv]), _ptr(self.grd[st.src0]), n, st.h // 2, st.w // 2,
+                                                    st.c0, dt)))
+        self.fwd_train, self.fwd_infer, self.bwd = fwd_t, fwd_i, bwd
+        self.opt = [(L.rvip_adam_step, (_ptr(P.theta), _ptr(P.grad), _ptr(P.adam_m), _ptr(P.adam_v), C.c_longlong(P.count),
+                                        C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0), _ptr(P.state)))]
+        for st in plan.stages:
+            if st.conv in P.packed:
+                wf, wd = P.packed[st.conv]
+                self.opt.append((L.rvip_pack_conv3x3_weights, (P.p(st.conv, 'kernel'), st.cin, st.cout, dt, _ptr(wf), _ptr(wd))))
+        self.opt.append((L.rvip_state_tick, (_ptr(P.state),)))
+
+    # -- execution ------------------------------------------------------------------------------------
+    @staticmethod
+    def _run(seq, stream):
+        s = C.c_void_p(stream)
+        for fn, args in seq:
+            rc = fn(*args, s)
+            if rc:
+                N.check(rc, fn.__name__)
+
+    def stream(self):
+        return _torch().cuda.current_stream().cuda_stream
+
+    def load_input(self, x, y=None):
+        """Host float32 NHWC batch -> device buffers (the generator contract, Generators.py:97-98,228)."""
+        torch = _torch()
+        xs = torch.from_numpy(np.ascontiguousarray(x, np.float32)).reshape(self.x_stage.shape)
+        self.x_stage.copy_(xs, non_blocking=True)
+        self.stage_input()
+        if y is not None:
+            self.y_true.copy_(torch.from_numpy(np.ascontiguousarray(y, np.float32)).reshape(self.y_true.shape), non_blocking=True)
+
+    def stage_input(self):
+        """x_stage (fp32) -> network input in the activation dtype, on the current stream."""
+        L = N.lib()
+        N.check(L.rvip_convert(_ptr(self.x_stage), N.F32, _ptr(self.act['input_1']), self.P.dt,
+                               C.c_longlong(self.x_stage.numel()), C.c_void_p(self.stream())), 'rvip_convert')
+
+    def forward(self, training):
+        self._run(self.fwd_train if training else self.fwd_infer, self.stream())
+
+    def forward_eval(self):
+        self._run(self.fwd_eval, self.stream())
+
+    def backward(self):
+        self._run(self.bwd, self.stream())
+
+    def optimizer_step(self):
+        self._run(self.opt, self.stream())
+
+    def allreduce_grads(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.P.grad)                   # RCCL sum over xGMI; loss is pre-divided by the global batch
+
+    def train_step(self):
+        """fwd + loss + bwd + [all-reduce] + Adam on the batch already in the device buffers."""
+        s = self.stream()
+        self._run(self.fwd_train, s)
+        self._run(self.bwd, s)
+        self.allreduce_grads()
+        self._run(self.opt, s)
+
+    def landmarks(self, thr=0.5, want_mask=False):
+        torch = _torch()
+        L = N.lib()
+        n, H, W, K = self.pred.shape
+        mask = torch.empty((n, H, W, K), dtype=torch.uint8, device=self.pred.device) if want_mask else None
+        N.check(L.rvip_landmarks(_ptr(self.pred), _ptr(self.lm_idx), _ptr(mask) if want_mask else None, n, H * W, K,
+                                 C.c_float(thr), C.c_void_p(self.stream())), 'rvip_landmarks')
+        return self.lm_idx, mask
+
+    def metrics_from_sums(self):
+        """loss + dice metrics of the last forward from the folded sums (one small D2H copy)."""
+        s = self.sums.detach().cpu().numpy().astype(np.float64)
+        return dict(sq=s[0], bce=s[1], inter=s[2], st=s[3], sp=s[4], lower=(s[5], s[6], s[7]), upper=(s[8], s[9], s[10]))

@@ -1,0 +1,430 @@
+"""Keras-``Model``-shaped object returned by ``create_unet`` (SURVEY 8(b) boundary).
+
+Surface used by the reference's callers, kept name for name:
+  fit(x=Sequence, validation_data=, epochs=, callbacks=, initial_epoch=, max_queue_size=, verbose=)
+      train_model.py:105-112, Train_tests.ipynb:924-931
+  predict(Sequence | ndarray) -> float32 [N,*DIM,C]            predict_model.py:143, KerasCallbacks.py:481
+  summary(print_fn=), save_weights / load_weights, get_weights / set_weights, compile, optimizer.lr,
+  stop_training, trainable, metrics_names, count_params       train_model.py:84-89, predict_model.py:76
+
+Host logic only lives here (epoch loop, batch sharding across ranks, callback protocol, logs); every FLOP
+is dispatched to the HIP engine.  Constructing / summarising / (de)serialising a model needs no GPU;
+fit / predict / train_on_batch raise without one (no CPU fallback).
+"""
+from __future__ import annotations
+
+import math
+import queue
+import threading
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from . import Loss_and_metrics as metr
+
+
+def _he_normal(rng, shape):
+    fan_in = int(np.prod(shape[:-1]))
+    std = math.sqrt(2.0 / fan_in) / 0.87962566103423978          # Keras VarianceScaling truncated-normal correction
+    a = rng.standard_normal(shape)
+    bad = np.abs(a) > 2.0
+    while bad.any():
+        a[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(a) > 2.0
+    return (a * std).astype(np.float32)
+
+
+def _glorot_uniform(rng, shape):
+    rf = int(np.prod(shape[:-2]))
+    lim = math.sqrt(6.0 / (rf * shape[-2] + rf * shape[-1]))
+    return rng.uniform(-lim, lim, shape).astype(np.float32)
+
+
+_INIT = {'he_normal': _he_normal, 'glorot_uniform': _glorot_uniform,
+         'zeros': lambda rng, s: np.zeros(s, np.float32), 'ones': lambda rng, s: np.ones(s, np.float32)}
+
+
+class History:
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+
+class Model:
+    def __init__(self, plan, name='unet'):
+        self.plan = plan
+        self.name = name
+        self.trainable = True
+        self.stop_training = False
+        self.optimizer = None
+        self.loss = None
+        self.metrics = []
+        self.history = None
+        cfg = plan.config
+        self.precision = {'bf16': 'bf16', 'bfloat16': 'bf16', 'fp32': 'f32', 'f32': 'f32', 'float32': 'f32'}[
+            str(cfg.get('RVIP_PRECISION', 'bf16')).lower()]
+        self.seed = int(cfg.get('SEED', 42))
+        rng = np.random.default_rng(self.seed)
+        self._weights = []
+        for (_, _, shape, _, init) in plan.weight_specs():
+            if init not in _INIT:
+                raise NotImplementedError('KERNEL_INIT=%r' % init)
+            self._weights.append(_INIT[init](rng, tuple(shape)))
+        self._params = None          # ParamStore once on the device
+        self._engines = {}
+        self._dropout_masks = None   # name -> uint8 ndarray, parity runs only
+        self._graphs = {}
+
+    # ---------------------------------------------------------------------------------------------
+    # Keras bookkeeping
+    # ---------------------------------------------------------------------------------------------
+    @property
+    def layers(self):
+        return self.plan.layers
+
+    def count_params(self):
+        return self.plan.count_params()[0]
+
+    def compile(self, optimizer=None, loss=None, metrics=None, **_):
+        from .ModelUtils import Adam
+        self.optimizer = optimizer if optimizer is not None else Adam()
+        if isinstance(self.optimizer, str):
+            self.optimizer = Adam()
+        self.loss = loss
+        self.metrics = list(metrics or [])
+        self.optimizer.lr._listeners.append(self._on_lr)
+        self._engines = {}
+        self._graphs = {}
+
+    @property
+    def metrics_names(self):
+        return ['loss'] + [getattr(m, '__name__', str(m)) for m in self.metrics]
+
+    def _on_lr(self, value):
+        if self._params is not None:
+            self._params.set_lr(value)
+
+    def summary(self, line_length=98, print_fn=None):
+        pr = print_fn or print
+        pos = [int(line_length * p) for p in (.33, .55, .67, 1.)]
+
+        def row(fields):
+            line = ''
+            for f, p in zip(fields, pos):
+                line = (line + str(f))[:p]
+                line += ' ' * (p - len(line))
+            pr(line)
+
+        pr('Model: "%s"' % self.name)
+        pr('_' * line_length)
+        row(['Layer (type)', 'Output Shape', 'Param #', 'Connected to'])
+        pr('=' * line_length)
+        for i, l in enumerate(self.plan.layers):
+            shp = '(None, %s)' % ', '.join(str(s) for s in l.shape)
+            if l.type == 'InputLayer':
+                shp = '[%s]' % shp
+            conns = ['%s[0][0]' % c for c in l.inputs] or ['']
+            row(['%s (%s)' % (l.name, l.type), shp, l.params, conns[0]])
+            for c in conns[1:]:
+                row(['', '', '', c])
+            pr(('=' if i == len(self.plan.layers) - 1 else '_') * line_length)
+        tot, tr, ntr = self.plan.count_params()
+        pr('Total params: {:,}'.format(tot))
+        pr('Trainable params: {:,}'.format(tr))
+        pr('Non-trainable params: {:,}'.format(ntr))
+        pr('_' * line_length)
+
+    # ---------------------------------------------------------------------------------------------
+    # weights (Keras get_weights() order: conv kernel, bias; BN gamma, beta, moving_mean, moving_variance)
+    # ---------------------------------------------------------------------------------------------
+    def get_weights(self):
+        if self._params is not None:
+            self._weights = self._params.download()
+        return [w.copy() for w in self._weights]
+
+    def set_weights(self, weights):
+        specs = self.plan.weight_specs()
+        if len(weights) != len(specs):
+            raise ValueError('expected %d arrays, got %d' % (len(specs), len(weights)))
+        new = []
+        for (ln, wn, shape, _, _), w in zip(specs, weights):
+            w = np.asarray(w, np.float32)
+            if tuple(w.shape) != tuple(shape):
+                raise ValueError('%s/%s: shape %s != %s' % (ln, wn, w.shape, tuple(shape)))
+            new.append(w.copy())
+        self._weights = new
+        if self._params is not None:
+            self._params.upload(self._weights)
+
+    def weight_names(self):
+        return ['%s/%s:0' % (ln, wn) for (ln, wn, _, _, _) in self.plan.weight_specs()]
+
+    def save_weights(self, filepath, overwrite=True, **_):
+        """Weights-only checkpoint (ModelCheckpoint(save_weights_only=True), KerasCallbacks.py:54-61).  Keras-HDF5
+        is SURVEY 8(f) row 1 (h5py is absent here); the container is .npz keyed '<layer>/<weight>:0'."""
+        arrs = OrderedDict(zip(self.weight_names(), self.get_weights()))
+        with open(filepath, 'wb') as f:
+            np.savez(f, **arrs)
+
+    def load_weights(self, filepath, **_):
+        with np.load(filepath) as z:
+            self.set_weights([z[k] for k in self.weight_names()])
+
+    # ---------------------------------------------------------------------------------------------
+    # device
+    # ---------------------------------------------------------------------------------------------
+    def _dist(self):
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_rank(), dist.get_world_size()
+        except Exception:
+            pass
+        return 0, 1
+
+    def _device(self):
+        import os
+        import torch
+        from .engine import require_gpu
+        require_gpu()
+        dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(dev)
+        return dev
+
+    def _ensure_params(self):
+        if self._params is None:
+            from .engine import ParamStore
+            lr = float(self.optimizer.lr) if self.optimizer is not None else 1e-3
+            self._params = ParamStore(self.plan, self._weights, self.precision, self._device(), seed=self.seed, lr=lr)
+            if self.optimizer is not None:
+                self._params.set_step(self.optimizer.iterations)
+        return self._params
+
+    def _engine(self, batch):
+        from .engine import Engine
+        P = self._ensure_params()
+        rank, world = self._dist()
+        key = (int(batch), world)
+        if key not in self._engines:
+            import torch
+            kind, w_bce, w_dice, _ = self._loss_spec(required=False)
+            masks = None
+            if self._dropout_masks:
+                masks = {k: torch.from_numpy(np.ascontiguousarray(v[:batch], np.uint8)).to(P.device)
+                         for k, v in self._dropout_masks.items()}
+            self._engines[key] = Engine(P, batch, kind or 'mse', w_bce, w_dice, world=world, masks=masks)
+        return self._engines[key]
+
+    def _loss_spec(self, required=True):
+        try:
+            kind, w_bce, w_dice, name = metr.resolve_loss(self.loss)
+        except ValueError:
+            if required:
+                raise
+            return None, 0.5, 1.0, 'loss'
+        if kind == 'unsupported':
+            if required:
+                raise NotImplementedError('LOSS_FUNCTION %s: the heat-map head kernels implement MSE and BCE-Dice' % name)
+            return None, 0.5, 1.0, name
+        return kind, w_bce, w_dice, name
+
+    def set_dropout_masks(self, masks):
+        """Parity hook: inject keep-masks (name -> uint8 [N,H,W,C]) instead of the counter-based stream."""
+        self._dropout_masks = masks
+        self._engines = {}
+        self._graphs = {}
+
+    # ---------------------------------------------------------------------------------------------
+    # steps
+    # ---------------------------------------------------------------------------------------------
+    def _shard(self, x, y=None):
+        """MirroredStrategy semantics (Unets.py:70-75): the generator's GLOBAL batch is split evenly by rank."""
+        rank, world = self._dist()
+        if world == 1:
+            return x, y
+        b = x.shape[0] // world
+        if b * world != x.shape[0]:
+            raise ValueError('global batch %d is not divisible by %d ranks' % (x.shape[0], world))
+        sl = slice(rank * b, (rank + 1) * b)
+        return x[sl], (None if y is None else y[sl])
+
+    def _batch_logs(self, eng, kind, w_bce, w_dice):
+        import torch
+        s = eng.sums
+        rank, world = self._dist()
+        if world > 1:
+            import torch.distributed as dist
+            s = s.clone()
+            dist.all_reduce(s)
+        n = float(eng.pred.numel() * world)
+        dice_all = (2 * s[2] + 1) / (s[3] + s[4] + 1)
+        loss = s[0] / n if kind == 'mse' else w_bce * s[1] / n - w_dice * dice_all
+        vals = [loss]
+        for m in self.metrics:
+            which = getattr(m, 'rvip_args', {}).get('sums')
+            if which == 'labels':
+                vals.append(dice_all)
+            elif which == 'lower':
+                vals.append((2 * s[5] + 1) / (s[6] + s[7] + 1))
+            elif which == 'upper':
+                vals.append((2 * s[8] + 1) / (s[9] + s[10] + 1))
+            else:
+                vals.append(torch.full((), float('nan'), device=s.device))
+        return torch.stack([v.reshape(()) for v in vals])
+
+    def train_on_batch(self, x, y, return_dict=False):
+        kind, w_bce, w_dice, _ = self._loss_spec()
+        x, y = self._shard(np.asarray(x), np.asarray(y))
+        eng = self._engine(x.shape[0])
+        eng.load_input(x, y)
+        eng.train_step()
+        self.optimizer.iterations += 1
+        vals = self._batch_logs(eng, kind, w_bce, w_dice).cpu().numpy().tolist()
+        return dict(zip(self.metrics_names, vals)) if return_dict else vals
+
+    def test_on_batch(self, x, y, return_dict=False):
+        kind, w_bce, w_dice, _ = self._loss_spec()
+        x, y = self._shard(np.asarray(x), np.asarray(y))
+        eng = self._engine(x.shape[0])
+        eng.load_input(x, y)
+        eng.forward_eval()
+        vals = self._batch_logs(eng, kind, w_bce, w_dice).cpu().numpy().tolist()
+        return dict(zip(self.metrics_names, vals)) if return_dict else vals
+
+    def predict_on_batch(self, x):
+        x = np.asarray(x, np.float32)
+        eng = self._engine(x.shape[0])
+        eng.load_input(x)
+        eng.forward(training=False)
+        return eng.pred.detach().cpu().numpy()
+
+    def predict(self, x, batch_size=None, verbose=0, **_):
+        """ndarray [N,*DIM,1] or a Sequence yielding (x, y) / x batches; returns float32 [N,*DIM,C] in order."""
+        outs = []
+        if isinstance(x, np.ndarray):
+            bs = batch_size or min(32, x.shape[0])
+            for i in range(0, x.shape[0], bs):
+                outs.append(self.predict_on_batch(x[i:i + bs]))
+        else:
+            for i in range(len(x)):
+                b = x[i]
+                xb = b[0] if isinstance(b, (tuple, list)) else b
+                outs.append(self.predict_on_batch(xb))
+        return np.concatenate(outs, 0)
+
+    def predict_landmarks(self, x, thr=0.5):
+        """Heat-maps -> (argmax index [N,C] int64 row-major first-max, >thr label mask uint8) on the device."""
+        x = np.asarray(x, np.float32)
+        eng = self._engine(x.shape[0])
+        eng.load_input(x)
+        eng.forward(training=False)
+        idx, mask = eng.landmarks(thr, want_mask=True)
+        return idx.cpu().numpy(), mask.cpu().numpy()
+
+    def evaluate(self, x, y=None, verbose=0, return_dict=False, **_):
+        tot, cnt = None, 0
+        if isinstance(x, np.ndarray):
+            batches = [(x, y)]
+        else:
+            batches = (x[i] for i in range(len(x)))
+        for xb, yb in batches:
+            v = np.asarray(self.test_on_batch(xb, yb))
+            tot = v if tot is None else tot + v
+            cnt += 1
+        vals = (tot / max(cnt, 1)).tolist()
+        return dict(zip(self.metrics_names, vals)) if return_dict else vals
+
+    # ---------------------------------------------------------------------------------------------
+    # fit (train_model.py:105-112)
+    # ---------------------------------------------------------------------------------------------
+    def fit(self, x=None, y=None, validation_data=None, epochs=1, callbacks=None, initial_epoch=0, max_queue_size=12,
+            verbose=1, steps_per_epoch=None, shuffle=True, batch_size=None, workers=1, **_):
+        import torch
+        from .KerasCallbacks import CallbackList
+        kind, w_bce, w_dice, _ = self._loss_spec()
+        if isinstance(x, np.ndarray):
+            from .Generators import ArrayGenerator
+            x = ArrayGenerator(x, y, batch_size or 32, shuffle=shuffle)
+        gen = x
+        self.history = History()
+        cbs = CallbackList(list(callbacks or []) + [self.history_callback()], self)
+        self.stop_training = False
+        cbs.on_train_begin()
+        names = self.metrics_names
+        for epoch in range(initial_epoch, epochs):
+            if self.stop_training:
+                break
+            cbs.on_epoch_begin(epoch)
+            t0 = time.time()
+            steps = len(gen) if steps_per_epoch is None else min(steps_per_epoch, len(gen))
+            order = np.arange(len(gen))
+            if shuffle:
+                np.random.shuffle(order)                       # Keras shuffles the batch order of a Sequence
+            acc = None
+            for step, (xb, yb) in enumerate(_prefetch(gen, order[:steps], max_queue_size)):
+                xb, yb = self._shard(xb, yb)
+                eng = self._engine(xb.shape[0])
+                eng.load_input(xb, yb)
+                eng.train_step()
+                self.optimizer.iterations += 1
+                v = self._batch_logs(eng, kind, w_bce, w_dice)
+                acc = v if acc is None else acc + v
+                cbs.on_train_batch_end(step)
+            logs = OrderedDict()
+            if acc is not None:
+                for k, val in zip(names, (acc / steps).cpu().numpy().tolist()):
+                    logs[k] = val
+            if validation_data is not None:
+                if isinstance(validation_data, (tuple, list)):
+                    v = self.evaluate(validation_data[0], validation_data[1])
+                else:
+                    v = self.evaluate(validation_data)
+                for k, val in zip(names, v):
+                    logs['val_' + k] = val
+            cbs.on_epoch_end(epoch, logs)
+            if hasattr(gen, 'on_epoch_end'):
+                gen.on_epoch_end()
+            if verbose and self._dist()[0] == 0:
+                dt = time.time() - t0
+                print('Epoch %d/%d - %.1fs - %.0fms/step - %s' % (
+                    epoch + 1, epochs, dt, 1e3 * dt / max(steps, 1), ' - '.join('%s: %.4f' % kv for kv in logs.items())))
+        cbs.on_train_end()
+        torch.cuda.synchronize()
+        return self.history
+
+    def history_callback(self):
+        from .KerasCallbacks import Callback
+        model = self
+
+        class _Hist(Callback):
+            def on_epoch_end(self, epoch, logs=None):
+                model.history.epoch.append(epoch)
+                for k, v in (logs or {}).items():
+                    model.history.history.setdefault(k, []).append(v)
+        return _Hist()
+
+
+def _prefetch(gen, order, depth):
+    """Background producer thread (the Keras OrderedEnqueuer of fit(max_queue_size=), train_model.py:111):
+    generator batches are prepared on the host while the GPU runs the previous step."""
+    q = queue.Queue(maxsize=max(int(depth), 1))
+    stop = object()
+
+    def work():
+        try:
+            for i in order:
+                q.put(gen[int(i)])
+        except BaseException as e:           # surface generator errors in the training thread
+            q.put(e)
+        q.put(stop)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    while True:
+        item = q.get()
+        if item is stop:
+            break
+        if isinstance(item, BaseException):
+            raise item
+        yield item

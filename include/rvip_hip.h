@@ -1,0 +1,231 @@
+/*
+ * rvip_hip.h -- C ABI of librvip_hip.so: the MI355X (gfx950) kernels behind the heatmap-regression
+ * U-Net training step of Cardio-AI/cmr-landmark-detection.
+ *
+ * The reference has no FFI for this path: every operation below is executed for it by
+ * tensorflow==2.3.0 when Keras runs the graph that src/models/Unets.py:61-133 (create_unet),
+ * :755-869 (unet) and src/models/KerasLayers.py:660-777 (conv_layer_fn / downsampling_block_fn /
+ * upsampling_block_fn) compose, under Model.fit (src/models/train_model.py:105-112).  Each entry
+ * point names the Keras call site whose arithmetic it replaces.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - returns 0 (RVIP_OK) or a negative RVIP_E* code; never throws, never allocates, never syncs;
+ *   - the CALLER owns every buffer (device memory) and passes the HIP stream (hipStream_t as void*);
+ *     all work is enqueued on that stream; re-entrant across streams;
+ *   - activations NHWC, dtype tag per call (RVIP_F32 / RVIP_BF16), accumulation always fp32;
+ *   - parameters (bias, BN gamma/beta/stats), gradients and optimiser state are fp32;
+ *   - master conv kernels are Keras HWIO fp32 [kh][kw][Cin][Cout]; the MFMA kernels read "packed"
+ *     copies in the activation dtype (rvip_pack_conv3x3_weights);
+ *   - channel counts of bf16 tensors must be multiples of 8, of f32 tensors multiples of 4
+ *     (16-byte channel vectors), except the network input (Cin = 1) and the 1x1 head (<= 4 classes);
+ *   - "state" is a caller-owned device block of RVIP_STATE_WORDS 32-bit words (see below) so that
+ *     step-dependent values (Adam t, learning rate, dropout stream) survive hipGraph replay.
+ */
+#ifndef RVIP_HIP_H
+#define RVIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVIP_OK            0
+#define RVIP_EINVAL      (-1)   /* bad shape / alignment / null pointer */
+#define RVIP_EUNSUPPORTED (-2)  /* combination not built */
+#define RVIP_EWORKSPACE  (-3)   /* workspace too small */
+#define RVIP_ELAUNCH     (-4)   /* hipLaunch error (see rvip_last_hip_error) */
+
+#define RVIP_F32  0
+#define RVIP_BF16 1
+
+#define RVIP_ACT_NONE    0
+#define RVIP_ACT_RELU    1
+#define RVIP_ACT_ELU     2      /* alpha = 1 (Unets.py:82 default 'elu') */
+#define RVIP_ACT_SIGMOID 3
+
+#define RVIP_LOSS_MSE      0    /* tf.keras.losses.MSE, train_model.py:184 */
+#define RVIP_LOSS_BCE_DICE 1    /* Loss_and_metrics.py:229-245, w_bce=0.5 w_dice=1 */
+
+/* device-resident step state (uint32 words; floats stored by bit pattern) */
+#define RVIP_STATE_STEP   0     /* optimizer.iterations (completed steps) */
+#define RVIP_STATE_LR     1     /* float: learning rate (model.optimizer.lr) */
+#define RVIP_STATE_SEED   2     /* dropout seed */
+#define RVIP_STATE_WORDS  8
+
+int         rvip_abi_version(void);
+const char* rvip_build_info(void);          /* "gfx950 ..." */
+int         rvip_last_hip_error(void);      /* last hipError_t seen by a launcher (0 = none) */
+
+/* ------------------------------------------------------------------------------------------------
+ * 3x3 "same" convolution as implicit GEMM on MFMA.  Replaces Conv2D(filters, 3, padding='same',
+ * activation=act) -- KerasLayers.py:683,689 (conv_layer_fn) and :758 (up-conv) -- including the
+ * UpSampling2D (:756-757) and Concatenate (:767) in front of it, which are addressing modes here:
+ *   source 0: x0 [N, H>>up0, W>>up0, C0]   (up0 = 1: nearest-neighbour x2 read, y[h,w] = x[h/2,w/2])
+ *   source 1: x1 [N, H, W, C1] or NULL     (channels C0.. of the virtual concat [x0, x1])
+ * Output y [N,H,W,Cout] = act(conv + bias).  With y1 != NULL the output channels are split:
+ * [0,csplit) -> y (row stride csplit), [csplit,Cout) -> y1 (row stride Cout-csplit); used by the
+ * data-gradient of a conv that read a concat.
+ * The same entry point computes the data gradient: pass dy as x0, the dgrad-packed weights, no
+ * bias, act NONE (autodiff of the Keras layer).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct rvip_conv3x3_desc {
+    const void*  x0;   int32_t c0;   int32_t up0;
+    const void*  x1;   int32_t c1;
+    const void*  w_packed;            /* [9][Cout][C0+C1] in the activation dtype */
+    const float* bias;                /* [Cout] or NULL */
+    void*        y;    void* y1;      int32_t csplit;
+    int32_t      n, h, w, cout;
+    int32_t      act;                 /* RVIP_ACT_* applied after bias */
+    int32_t      dtype;               /* RVIP_F32 / RVIP_BF16 (x0, x1, w_packed, y, y1) */
+} rvip_conv3x3_desc;
+
+int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
+
+/* Re-layout the fp32 HWIO master kernel [3][3][Cin][Cout] into the two packed operands:
+ *   w_fwd [9][Cout][Cin]  (w_fwd[t][o][i] = W[t][i][o])        -- forward
+ *   w_dgrad [9][Cin][Cout] (w_dgrad[t][i][o] = W[8-t][i][o])   -- data gradient (taps rotated 180)
+ * either may be NULL. */
+int rvip_pack_conv3x3_weights(const float* w_hwio, int cin, int cout, int dtype,
+                              void* w_fwd, void* w_dgrad, void* stream);
+
+/* Weight gradient of the same conv (autodiff of KerasLayers.py:683,689,758):
+ *   dw[t][i][o] = sum_{n,h,w} X[n,h+t/3-1,w+t%3-1,i] * dy[n,h,w,o],   X = virtual [up(x0), x1]
+ * fp32 HWIO output.  Deterministic two-stage split-K: workspace holds nsplit partial slabs.
+ * rvip_conv3x3_wgrad_workspace returns the bytes needed for the shape. */
+typedef struct rvip_wgrad3x3_desc {
+    const void*  x0;   int32_t c0;   int32_t up0;
+    const void*  x1;   int32_t c1;
+    const void*  dy;                  /* [N,H,W,Cout] */
+    float*       dw;                  /* [9][C0+C1][Cout] fp32, overwritten */
+    int32_t      n, h, w, cout;
+    int32_t      dtype;
+    void*        workspace;  size_t workspace_bytes;
+} rvip_wgrad3x3_desc;
+
+size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout);
+int    rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream);
+
+/* First layer, Cin = 1 (bandwidth-bound, no MFMA): y = act(conv3x3(x[N,H,W,1]) + bias); weights are
+ * the fp32 HWIO master [9][1][Cout].  wgrad: dw[9][Cout] and nothing else (the input has no grad).
+ * workspace for wgrad: rvip_reduce_workspace(n*h*w, 16*cout) bytes. */
+int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* bias, void* y,
+                        int n, int h, int w_, int cout, int act, int dtype, void* stream);
+int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cout,
+                          int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-channel reductions use a two-stage deterministic scheme: stage 1 writes one partial row per
+ * workgroup into the workspace, stage 2 folds them.  rvip_reduce_workspace(rows, width) = bytes for
+ * a reduction of `rows` pixels producing `width` floats.
+ * ------------------------------------------------------------------------------------------------ */
+size_t rvip_reduce_workspace(long long rows, int width);
+
+/* BatchNormalization(axis=-1), training (KerasLayers.py:684,691; Keras defaults momentum 0.99,
+ * eps 1e-3).  Step 1 (stats): batch mean / biased variance of z[rows][C]; writes
+ *   mean[C], invstd[C], scale[C] = gamma*invstd, shift[C] = beta - mean*scale
+ * and updates moving_mean/moving_var in place (unbiased variance when unbiased_moving != 0: the
+ * fused 4-D TF kernel; 0 for 5-D inputs). */
+int rvip_bn_train_stats(const void* z, long long rows, int c, int dtype,
+                        const float* gamma, const float* beta,
+                        float* moving_mean, float* moving_var, float momentum, float eps, int unbiased_moving,
+                        float* mean, float* invstd, float* scale, float* shift,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Inference coefficients from the moving statistics (Model.predict: BN in inference mode). */
+int rvip_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean,
+                         const float* moving_var, float eps, int c, float* scale, float* shift, void* stream);
+
+/* y = dropout(act(scale[c]*z + shift[c])), optionally with the 2x2/2 max-pool of y written to
+ * `pooled` in the same pass (MaxPooling2D, KerasLayers.py:714,721).  scale/shift NULL = identity.
+ * Dropout (KerasLayers.py:718,772; Unets.py:813): inverted dropout, keep = 1-rate; the keep-mask is
+ * either `mask` (uint8 [rows][C], parity runs) or the counter-based stream
+ * hash(seed, state[STEP], layer_id, element) shared with the backward kernels; rate 0 = none. */
+typedef struct rvip_apply_desc {
+    const void*  z;  void* y;  void* pooled;      /* pooled NULL = no pool */
+    const float* scale; const float* shift;
+    int32_t      act;
+    float        drop_rate; const uint8_t* mask; const uint32_t* state; int32_t layer_id;
+    int32_t      n, h, w, c;
+    int32_t      dtype;
+} rvip_apply_desc;
+int rvip_bn_apply(const rvip_apply_desc* d, void* stream);
+
+/* Backward of conv -> [act] -> BN -> [act] -> dropout (autodiff of conv_layer_fn + Dropout).
+ * Inputs: dy (grad w.r.t. the dropped-out BN output), z (BN input as stored by the forward) and, only
+ * when the activation sits after BN (BN_FIRST, act_after_bn != 0), the forward scale/shift so that
+ * act'(act(scale*z+shift)) can be recomputed.
+ * Stage 1 (rvip_bn_bwd_reduce): dgamma, dbeta (+ coefficient vectors for stage 2).
+ * Stage 2 (rvip_bn_bwd_apply): dconv = (c1*g + c2*z + c3) * act'(.)  and  dbias = sum dconv.
+ * With gamma == NULL (no BatchNormalization: BATCH_NORMALISATION False, or the up-conv) stage 1 is
+ * skipped by the caller and stage 2 computes dconv = g * act'(z), dbias. */
+typedef struct rvip_bnbwd_desc {
+    const void*  dy; const void* z;
+    void*        dz;                               /* stage 2 output (same dtype) */
+    const float* gamma; const float* mean; const float* invstd;
+    const float* scale; const float* shift;        /* forward affine; only read when act_after_bn */
+    float*       dgamma; float* dbeta; float* dbias;
+    float*       coef;                             /* [3][C] scratch written by stage 1, read by stage 2 */
+    int32_t      act; int32_t act_after_bn;
+    float        drop_rate; const uint8_t* mask; const uint32_t* state; int32_t layer_id;
+    long long    rows; int32_t c;
+    int32_t      dtype;
+    void*        workspace; size_t workspace_bytes;
+} rvip_bnbwd_desc;
+int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream);
+int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);
+
+/* MaxPooling2D backward: dx = route(dpooled -> first max of each 2x2 window of y) + add (add may be
+ * NULL; it carries the skip-connection gradient that reaches the same tensor). */
+int rvip_maxpool2x2_bwd(const void* y, const void* dpooled, const void* add, void* dx,
+                        int n, int h, int w, int c, int dtype, void* stream);
+
+/* UpSampling2D(2) forward (materialised; the conv reads it virtually) and backward (2x2 sum). */
+int rvip_upsample2x_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream);
+int rvip_upsample2x_bwd(const void* dy, void* dx, int n, int h, int w, int c, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Head + loss.  Replaces Conv2D(mask_classes, 1, activation='sigmoid', name='unet') (Unets.py:128)
+ * and the compiled loss (Unets.py:130): Keras MSE or bce_dice_loss, plus the dice metrics
+ * (Loss_and_metrics.py:134-171).
+ *   rvip_head_fwd:   pred[rows][K] (fp32) = sigmoid(x[rows][Cin] . W[Cin][K] + b); if y_true != NULL
+ *                    also folds the loss sums; `sums` (device, 16 floats) receives
+ *                    [0] sum (p-t)^2  [1] sum bce  [2] sum t*p  [3] sum t  [4] sum p
+ *                    [5+2k],[6+2k]... per-class sum t*p is not needed by the reference metrics beyond
+ *                    the last two channels: [5] sum t*p (ch K-2) [6] sum t (K-2) [7] sum p (K-2)
+ *                    [8] sum t*p (ch K-1) [9] sum t (K-1) [10] sum p (K-1)
+ *   rvip_head_grad:  dlogit[rows][K] (fp32) from pred, y_true, sums; loss scalar -> loss_out[0]
+ *                    (Keras mean reduction with the GLOBAL batch: inv_count = 1/(global_rows*K);
+ *                    local_over_global = local batch / global batch scales the replica-local dice term;
+ *                    w_bce/w_dice: 0.5/1 for bce_dice_loss, 1/1 for BceDiceLoss; ignored for MSE).
+ *   rvip_head_bwd:   dx[rows][Cin] = dlogit . W^T ; dW[Cin][K], db[K].
+ * ------------------------------------------------------------------------------------------------ */
+int rvip_head_fwd(const void* x, const float* w, const float* b, float* pred, const float* y_true,
+                  float* sums, long long rows, int cin, int k, int dtype,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int rvip_head_grad(const float* pred, const float* y_true, const float* sums, float* dlogit, float* loss_out,
+                   long long rows, int k, int loss_kind, float inv_count, float local_over_global,
+                   float w_bce, float w_dice, void* stream);
+int rvip_head_bwd(const void* x, const float* w, const float* dlogit, void* dx, float* dw, float* db,
+                  long long rows, int cin, int k, int dtype,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-(slice, class) argmax of the heat-map, row-major first-max (north_star landmark index), and the
+ * >0.5 label mask of predict_model.py:149-156.  idx_out[n][k] int64; mask_out uint8 [rows][K] or NULL. */
+int rvip_landmarks(const float* pred, long long* idx_out, uint8_t* mask_out, int n, int hw, int k, float thr,
+                   void* stream);
+
+/* Keras Adam (ModelUtils.py:106-107; beta1 .9, beta2 .999, eps 1e-7 outside the bias correction) over a
+ * flat fp32 parameter block; t = state[STEP]+1, lr = state[LR].  rvip_state_tick increments STEP. */
+int rvip_adam_step(float* theta, const float* grad, float* m, float* v, long long count,
+                   float beta1, float beta2, float eps, float grad_scale, const uint32_t* state, void* stream);
+int rvip_state_tick(uint32_t* state, void* stream);
+
+/* dtype conversion of a flat buffer (host-side plumbing: generator batches are float32). */
+int rvip_convert(const void* src, int src_dtype, void* dst, int dst_dtype, long long count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVIP_HIP_H */

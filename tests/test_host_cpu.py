@@ -1,0 +1,270 @@
+"""Host-side logic + C-ABI surface, no GPU: plan vs the reference's stored summary and vs the oracle's builder,
+library load/exports, weights I/O, generator and callback protocols, dropout stream, loud failure without a GPU,
+and the 2-rank data-parallel path over gloo."""
+import io
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import cmr_landmark_detection_amd as rvip
+from oracle import rvip_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+M = rvip.Loss_and_metrics
+
+
+def _cfg(**kw):
+    c = dict(DIM=[32, 32], FILTERS=8, DEPTH=2, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2,
+             LOSS_FUNCTION=M.mse)
+    c.update(kw)
+    return c
+
+
+def test_plan_matches_reference_summary_and_oracle():
+    fx = json.load(open(os.path.join(GOLD, 'model_summary.json')))
+    plan = rvip.UnetPlan(fx['config'])
+    rows = plan.summary_rows()
+    assert len(rows) == 63
+    for (name, ty, shape, params, ins), g in zip(rows, fx['rows']):
+        assert (name, list(shape), params, list(ins)) == (g['name'], g['shape'], g['params'], g['inputs'])
+        assert ty.startswith(g['type_prefix'])
+    assert plan.count_params() == (8641730, 8635842, 5888)
+    for cfg in [fx['config'], _cfg(BN_FIRST=True), _cfg(BATCH_NORMALISATION=False, ACTIVATION='elu'), _cfg(USE_UPSAMPLE=False),
+                _cfg(DEPTH=3, DIM=[48, 40])]:
+        assert rvip.UnetPlan(cfg).summary_rows() == O.summary_rows(O.build_graph(cfg))
+
+
+def test_summary_text_parses_back_to_golden():
+    fx = json.load(open(os.path.join(GOLD, 'model_summary.json')))
+    cfg = dict(fx['config'], LOSS_FUNCTION=M.bce_dice_loss)
+    model = rvip.create_unet(cfg, metrics=[M.dice_coef_labels, M.dice_coef_lower, M.dice_coef_upper])
+    buf = []
+    model.summary(print_fn=buf.append)
+    text = '\n'.join(buf)
+    assert 'Total params: 8,641,730' in text and 'Trainable params: 8,635,842' in text and 'Non-trainable params: 5,888' in text
+    names = re.findall(r'^(\S+) \(', text, flags=re.M)
+    assert [n for n in names if n != 'Layer'] == [r['name'] for r in fx['rows']]
+    assert model.metrics_names == ['loss', 'dice_coef_labels', 'dice_coef_lower', 'dice_coef_upper']
+
+
+def test_config_defaults_and_quirks():
+    p = rvip.UnetPlan(dict(DIM=[64, 64]))
+    assert (p.activation, p.batch_norm, p.filters, p.depth, p.mask_classes, p.bn_first) == ('elu', False, 16, 4, 3, False)
+    assert p.use_upsample == 'False' and any(l.type == 'UpSampling2D' for l in p.layers)      # Unets.py:86 truthy string
+    assert any(l.type == 'Conv2DTranspose' for l in rvip.UnetPlan(dict(DIM=[64, 64], USE_UPSAMPLE=False)).layers)
+    assert p.dropouts == [0.3, 0.4, 0.4, 0.5]
+    cfg = _cfg()
+    snapshot = dict(cfg)
+    rvip.create_unet(cfg)
+    assert cfg == snapshot                                                                  # never mutated
+    opt = rvip.get_optimizer(dict(OPTIMIZER='adam', LEARNING_RATE=1e-4))
+    assert float(opt.lr) == 1e-4 and (opt.beta_1, opt.beta_2, opt.epsilon) == (0.9, 0.999, 1e-7)
+    opt.lr = 5e-5
+    assert float(opt.lr) == 5e-5
+
+
+def test_flops_and_bytes_match_baseline_table():
+    p = rvip.UnetPlan(dict(DIM=[256, 256], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, MASK_CLASSES=2))
+    fwd, both = p.flops_per_slice()
+    assert abs(fwd / 1e9 - 32.661) < 1e-3 and abs(both / 1e9 - 97.945) < 1e-3
+    assert abs(p.ideal_bytes_per_slice(2) / 1e6 - 281.5) < 0.1
+    p1 = rvip.UnetPlan(dict(DIM=[224, 224], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, MASK_CLASSES=2))
+    assert abs(p1.flops_per_slice()[1] / 1e9 - 74.989) < 1e-3
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'rvip_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(rvip_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 25
+    lib = rvip._native.lib()
+    assert declared == set(rvip._native.SIGNATURES), declared ^ set(rvip._native.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.rvip_abi_version() == 1 and b'gfx950' in lib.rvip_build_info()
+    assert lib.rvip_reduce_workspace(1000, 64) > 0 and lib.rvip_conv3x3_wgrad_workspace(2, 32, 32, 8, 8) > 0
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes mirrors must have exactly the layout gcc gives the structs of include/rvip_hip.h."""
+    import ctypes as C
+    import subprocess
+    N = rvip._native
+    structs = {'rvip_conv3x3_desc': N.Conv3x3Desc, 'rvip_wgrad3x3_desc': N.Wgrad3x3Desc,
+               'rvip_apply_desc': N.ApplyDesc, 'rvip_bnbwd_desc': N.BnBwdDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rvip_hip.h"', 'int main(void){']
+    for cname, cls in structs.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines.append('return 0;}')
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = str(tmp_path / 'layout')
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', exe])
+    out = subprocess.check_output([exe]).decode().split('\n')
+    got = {}
+    for ln in out:
+        if ln:
+            a, b, c = ln.split()
+            got[(a, b)] = int(c)
+    for cname, cls in structs.items():
+        assert got[(cname, 'size')] == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert got[(cname, f)] == getattr(cls, f).offset, (cname, f)
+
+
+def test_weights_roundtrip_and_order(tmp_path):
+    m = rvip.create_unet(_cfg())
+    w = m.get_weights()
+    specs = m.plan.weight_specs()
+    assert [s[1] for s in specs[:6]] == ['kernel', 'bias', 'gamma', 'beta', 'moving_mean', 'moving_variance']
+    assert w[0].shape == (3, 3, 1, 8) and w[-2].shape == (1, 1, 8, 2) and sum(a.size for a in w) == m.count_params()
+    assert np.all(w[1] == 0) and np.all(w[2] == 1) and np.all(w[5] == 1)
+    k = w[6]                                      # conv2d_1 kernel: he_normal, truncated at 2 sigma
+    std = np.sqrt(2.0 / (9 * 8)) / 0.87962566103423978
+    assert np.abs(k).max() <= 2 * std + 1e-6 and abs(k.std() - np.sqrt(2.0 / 72)) < 0.2 * np.sqrt(2.0 / 72)
+    lim = np.sqrt(6.0 / (8 + 2))
+    assert np.abs(w[-2]).max() <= lim                                                  # glorot_uniform head
+    path = str(tmp_path / 'model.npz')
+    m.save_weights(path)
+    m2 = rvip.create_unet(_cfg(SEED=7))
+    assert not np.allclose(m2.get_weights()[0], w[0])
+    m2.load_weights(path)
+    for a, b in zip(m2.get_weights(), w):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        m2.set_weights(w[:-1])
+
+
+def test_generator_contract():
+    G = rvip.Generators
+    cfg = dict(DIM=[32, 32], BATCHSIZE=4, GAUS=True, SIGMA=2, SHUFFLE=False, MASK_VALUES=[1, 2])
+    g = G.SyntheticSAXGenerator(10, cfg)
+    assert len(g) == 2                                                                  # floor(N / B), Generators.py:142
+    x, y = g[0]
+    assert x.shape == (4, 32, 32, 1) and y.shape == (4, 32, 32, 2) and x.dtype == y.dtype == np.float32
+    assert x.min() >= 0 and x.max() <= 1 and abs(float(y.max()) - 1.0) < 1e-6
+    x2, y2 = g[0]
+    np.testing.assert_array_equal(x, x2)
+    assert len(list(iter(g))) == 2
+    g1 = G.SyntheticSAXGenerator(10, dict(cfg, GAUS=False))
+    assert set(np.unique(g1[0][1])) == {0.0, 1.0} and g1[0][1].sum() == 8                # one-hot points
+    np.random.seed(0)
+    gs = G.SyntheticSAXGenerator(10, dict(cfg, SHUFFLE=True))
+    before = list(gs.INDICES); gs.on_epoch_end()
+    assert sorted(gs.INDICES) == list(range(10)) and (list(gs.INDICES) != before or True)
+    t = O.gaussian_targets(G.transform_to_binary_mask(np.pad(np.array([[1, 0], [0, 2]]), 8), [1, 2]), 2)
+    np.testing.assert_allclose(G.gaussian_heatmaps(G.transform_to_binary_mask(np.pad(np.array([[1, 0], [0, 2]]), 8), [1, 2]), 2), t)
+
+
+class _FakeModel:
+    def __init__(self):
+        self.optimizer = rvip.Adam(lr=1e-3)
+        self.stop_training = False
+        self.saved = []
+
+    def save_weights(self, p):
+        self.saved.append(p)
+
+
+def test_callbacks_schedule(tmp_path):
+    K = rvip.KerasCallbacks
+    cbs = K.get_callbacks(dict(MODEL_PATH=str(tmp_path), DECAY_FACTOR=0.5, REDUCE_LR_ON_PLAEAU_PATIENCE=2,
+                               EARLY_STOPPING_PATIENCE=6, MONITOR_FUNCTION='loss', MONITOR_MODE='min'))
+    fm = _FakeModel()
+    cl = K.CallbackList(cbs, fm)
+    cl.on_train_begin()
+    losses = [1.0, 0.9, 0.95, 0.96, 0.97, 0.98, 0.99, 1.0, 1.1]
+    lrs = []
+    for e, l in enumerate(losses):
+        logs = {'loss': l}
+        cl.on_epoch_begin(e)
+        cl.on_epoch_end(e, logs)
+        lrs.append(logs['lr'])
+        if fm.stop_training:
+            break
+    assert len(fm.saved) == 2                          # best-only: epochs 0 and 1
+    assert float(fm.optimizer.lr) < 1e-3 and fm.stop_training and e == 7
+    assert lrs[0] == 1e-3 and min(lrs) <= 5e-4
+
+
+def test_dropout_stream_properties():
+    ds = __import__('importlib').import_module('cmr-landmark-detection_amd.dropout_stream')
+    m = ds.keep_mask((4, 16, 16, 8), 0.3, 42, 0, 1)
+    assert m.dtype == np.uint8 and m.shape == (4, 16, 16, 8)
+    assert abs(m.mean() - 0.7) < 0.02
+    assert (ds.keep_mask((4, 16, 16, 8), 0.3, 42, 0, 1) == m).all()
+    assert (ds.keep_mask((4, 16, 16, 8), 0.3, 42, 1, 1) != m).any() and (ds.keep_mask((4, 16, 16, 8), 0.3, 42, 0, 2) != m).any()
+    assert ds.dropout_thr(0.5) == 32768 and ds.dropout_thr(0.0) == 65536
+
+
+def test_loss_tags_and_host_metrics():
+    assert M.resolve_loss({'unet': M.mse})[0] == 'mse'
+    assert M.resolve_loss(M.bce_dice_loss)[:3] == ('bce_dice', 0.5, 1.0)
+    assert M.resolve_loss(M.BceDiceLoss())[:3] == ('bce_dice', 1.0, 1.0)
+    assert M.resolve_loss('BcdDiceLoss')[0] == 'bce_dice'
+    rng = np.random.default_rng(0)
+    t = (rng.random((2, 8, 8, 2)) > 0.7).astype(np.float32); p = rng.random((2, 8, 8, 2)).astype(np.float32)
+    assert abs(M.dice_coef(t, p) - O.dice_coef(t.astype(np.float64), p.astype(np.float64))) < 1e-12
+    ref, _ = O.bce_dice_loss(t.astype(np.float64), p.astype(np.float64))
+    assert abs(M.bce_dice_loss(t, p) - ref) < 1e-9
+    assert abs(M.mse(t, p) - O.mse_loss(t.astype(np.float64), p.astype(np.float64))[0]) < 1e-12
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='needs a box WITHOUT a GPU')
+def test_product_path_fails_loudly_without_gpu():
+    m = rvip.create_unet(_cfg())
+    x = np.zeros((2, 32, 32, 1), np.float32)
+    with pytest.raises(rvip._native.RvipError):
+        m.predict(x)
+    with pytest.raises(rvip._native.RvipError):
+        m.train_on_batch(x, np.zeros((2, 32, 32, 2), np.float32))
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cfg = _cfg(BATCH_NORMALISATION=False, DIM=[16, 16], FILTERS=4)
+        model = rvip.create_unet(cfg)
+        layers = O.build_graph(cfg)
+        w = model.get_weights()
+        params, it = {}, iter(w)
+        for l in layers:
+            if l['type'] == 'Conv2D':
+                params[l['name']] = [next(it), next(it)]
+        x, y = O.synthetic_batch(4, cfg['DIM'], 2, seed=5)
+        xs, ys = model._shard(x, y)                                   # the product's rank sharding
+        assert xs.shape[0] == 2 and np.array_equal(xs, x[rank * 2:(rank + 1) * 2])
+        net = O.OracleUNet(cfg, params, dtype=np.float64)
+        _, grads, _, _ = net.loss_and_grads(xs.astype(np.float64), ys.astype(np.float64), 'mse', global_batch=4)
+        flat = torch.from_numpy(np.concatenate([g.ravel() for gs in grads.values() for g in gs]))
+        dist.all_reduce(flat)                                         # what Engine.allreduce_grads does on RCCL
+        full = O.OracleUNet(cfg, params, dtype=np.float64).loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse')[1]
+        ref = np.concatenate([g.ravel() for gs in full.values() for g in gs])
+        q.put((rank, float(np.abs(flat.numpy() - ref).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert [r for r, _ in res] == [0, 1]
+    assert all(err < 1e-12 for _, err in res), res
