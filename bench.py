@@ -1,0 +1,208 @@
+"""Headline benchmark: SAX slices/sec of the full training step (fwd + loss + bwd + [RCCL all-reduce] + Adam) of
+the 256x256 4-level U-Net with 2 heat-maps, bf16 activations / fp32 accumulate, batch 32 per GPU
+(BASELINE.json configs[1]; configs[2] = the same per GPU on N GPUs, weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+           bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  ``value`` = slices all ranks processed / max-over-ranks wall time of exactly K steps
+with the synthetic batch already resident in HBM.  ``roofline`` is for the dominant kernel family (the MFMA
+implicit-GEMM conv, forward + data-gradient launches): achieved = algorithmic conv FLOPs of those launches /
+their summed durations, measured live with HIP events on the launch stream in a separate pass after the timed
+region.  ``cpu_baseline`` (rank 0, N=1 only) times the same training step on the host cores with the PyTorch-CPU
+port in oracle/ (the reference's own TF2-CPU path cannot run here: no TensorFlow) on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # dense MFMA bf16, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='slices per GPU (BASELINE.json: 32)')
+    ap.add_argument('--dim', type=int, default=256)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--cpu-batch', type=int, default=4)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rvip = importlib.import_module('cmr-landmark-detection_amd')
+    M = rvip.Loss_and_metrics
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs the torch.distributed.run launcher (one rank per GPU)' % args.gpus)
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+
+    cfg = dict(DIM=[args.dim, args.dim], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
+               MASK_CLASSES=2, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-4, RVIP_PRECISION=args.precision,
+               LOSS_FUNCTION=M.mse, SEED=42)
+    model = rvip.get_model(cfg, metrics=[])
+    plan = model.plan
+    B = args.batch
+    gen = rvip.Generators.SyntheticSAXGenerator(B, dict(DIM=cfg['DIM'], BATCHSIZE=B, GAUS=True, SIGMA=2, SHUFFLE=False, SEED=42 + rank))
+    x, y = gen[0]
+    eng = model._engine(B)
+    eng.load_input(x, y)                       # synthetic batch resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    def step():
+        eng.stage_input()                      # fp32 slice -> network input dtype (on device)
+        eng.train_step()
+
+    use_graph = (not args.no_graph) and world == 1
+    graph = None
+    for _ in range(min(2, max(args.warmup, 1))):
+        step()
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:                 # capture is an optimisation of the launch path, never required
+            sys.stderr.write('hipGraph capture failed (%s); running eagerly\n' % (e,))
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(eng.loss.item())
+    assert np.isfinite(loss), 'training diverged in the benchmark'
+
+    # ---- roofline pass: HIP events around every launch, eager, on the launch stream -------------------------
+    roof = None
+    per_kernel = {}
+    if rank == 0:
+        import ctypes as C
+        s = torch.cuda.current_stream()
+        L = rvip._native.lib()
+        conv_fn, wgrad_fn = L.rvip_conv3x3_fwd, L.rvip_conv3x3_wgrad
+        reps = 3
+        agg = {}
+        for _ in range(reps):
+            eng.stage_input()
+            for seq in (eng.fwd_train, eng.bwd, eng.opt):
+                for fn, a in seq:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(s)
+                    rc = fn(*a, C.c_void_p(s.cuda_stream))
+                    e1.record(s)
+                    assert rc == 0
+                    flops = 0.0
+                    if fn is conv_fn:
+                        d = a[0]._obj
+                        flops = 2.0 * d.n * d.h * d.w * 9 * (d.c0 + d.c1) * d.cout
+                    elif fn is wgrad_fn:
+                        d = a[0]._obj
+                        flops = 2.0 * d.n * d.h * d.w * 9 * (d.c0 + d.c1) * d.cout
+                    agg.setdefault(fn.__name__, []).append((e0, e1, flops))
+        torch.cuda.synchronize()
+        for name, evs in agg.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            per_kernel[name] = dict(launches_per_step=len(evs) // reps, ms_per_step=round(ms / reps, 4),
+                                    tflops=round(fl / (ms * 1e-3) / 1e12, 2) if (fl > 0 and ms > 0) else None)
+        cv = agg['rvip_conv3x3_fwd']
+        ms = sum(a.elapsed_time(b) for a, b, _ in cv)
+        fl = sum(f for _, _, f in cv)
+        achieved = fl / (ms * 1e-3) / 1e12
+        roof = dict(bound='mfma', kernel='conv3x3_igemm (fwd + dgrad launches)', achieved=round(achieved, 2),
+                    peak=PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3, unit='TFLOP/s',
+                    frac=round(achieved / (PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3), 4),
+                    traffic=None, launches_per_step=len(cv) // reps, avg_launch_ms=round(ms / len(cv), 4),
+                    flops_per_launch=fl / len(cv))
+
+    fwd_flops, step_flops = plan.flops_per_slice()
+    slices = B * world * args.steps
+    value = slices / elapsed
+    out = None
+    if rank == 0:
+        out = {
+            'metric': 'SAX slices/sec (fwd+bwd), 256x256 U-Net 2-heatmap',
+            'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': '4-level 2D U-Net F=32, %dx%d, batch %d per GPU, fwd+loss(MSE)+bwd+Adam%s' % (
+                args.dim, args.dim, B, ' + RCCL grad all-reduce' if world > 1 else ''),
+                'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': 'hipGraph' if graph is not None else 'eager',
+                'gflop_per_slice_fwd_bwd': round(step_flops / 1e9, 3)},
+            'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),
+            'loss': loss,
+            'roofline': roof,
+            'kernels': per_kernel,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_batch)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+def cpu_baseline(cfg, batch):
+    """The same step on the host cores: PyTorch-CPU (oneDNN) fp32 port in oracle/torch_ref.py -- the stand-in for the
+    reference's TF2-CPU path, which cannot be imported here.  Bounded sample: `batch` slices per step, 1 warm-up + 2
+    timed steps (about 10-30 s)."""
+    import torch
+    from oracle import torch_ref
+    cores = len(os.sched_getaffinity(0))
+    cpu_cfg = {k: v for k, v in cfg.items() if k not in ('LOSS_FUNCTION', 'RVIP_PRECISION')}
+    sec = torch_ref.time_train_steps(cpu_cfg, batch, steps=2, warmup=1, threads=cores)
+    return {'value': round(batch / sec, 3), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d slices/step x 2 timed steps of the same %dx%d training step, PyTorch-CPU fp32 (stand-in for TF2-CPU)' % (
+                batch, cfg['DIM'][0], cfg['DIM'][1]), 'threads': torch.get_num_threads()}
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,211 @@
+"""End-to-end parity of the hot path on a real MI355X: get_model(config) -> train steps / predict through the
+engine (every FLOP a HIP kernel behind the C ABI) against the NumPy oracle on identical seeded inputs, with the
+device's own dropout stream reproduced on the host.
+
+north_star bar: fp32 heat-maps within 1e-3 max-abs of the CPU reference, argmax landmark indices bit-exact,
+>0.5 masks identical.  The bf16 path reports its own (looser) error."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import cmr_landmark_detection_amd as rvip
+from oracle import rvip_oracle as O
+
+pytestmark = pytest.mark.gpu
+M = rvip.Loss_and_metrics
+ds = importlib.import_module('cmr-landmark-detection_amd.dropout_stream')
+
+
+def _cfg(**kw):
+    c = dict(DIM=[32, 32], FILTERS=8, DEPTH=2, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2,
+             LEARNING_RATE=1e-3, RVIP_PRECISION='fp32', LOSS_FUNCTION=M.mse, SEED=11)
+    c.update(kw)
+    return c
+
+
+def _oracle_from(model, cfg, dtype=np.float64):
+    layers = O.build_graph(cfg)
+    it = iter(model.get_weights())
+    params = {}
+    for l in layers:
+        if l['type'].startswith('Conv'):
+            params[l['name']] = [next(it), next(it)]
+        elif l['type'] == 'BatchNormalization':
+            params[l['name']] = [next(it) for _ in range(4)]
+    return O.OracleUNet(cfg, params, dtype=dtype), layers
+
+
+def _masks(layers, batch, seed, step):
+    drops = [l for l in layers if l['type'] == 'Dropout']
+    return {l['name']: ds.keep_mask((batch,) + l['shape'], l['rate'], seed, step, i + 1) for i, l in enumerate(drops)}
+
+
+def _flat_grads(grads):
+    return {(k, i): g for k, gs in grads.items() for i, g in enumerate(gs)}
+
+
+VARIANTS = [
+    dict(),
+    dict(BN_FIRST=True),
+    dict(BATCH_NORMALISATION=False, ACTIVATION='elu'),
+    dict(DEPTH=3, DIM=[48, 40], LOSS_FUNCTION=M.bce_dice_loss),
+    dict(LOSS_FUNCTION=M.BceDiceLoss(), FILTERS=12),
+]
+
+
+@pytest.mark.parametrize('variant', VARIANTS, ids=lambda v: ','.join('%s=%s' % (k, getattr(x, '__name__', x)) for k, x in v.items()) or 'default')
+def test_fp32_training_steps_match_oracle(variant):
+    cfg = _cfg(**variant)
+    kind = M.resolve_loss(cfg['LOSS_FUNCTION'])
+    loss_name = kind[0]
+    B = 4
+    model = rvip.get_model(cfg, metrics=[M.dice_coef_labels, M.dice_coef_lower, M.dice_coef_upper])
+    ref, layers = _oracle_from(model, cfg)
+    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=3)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    eng = model._engine(B)
+    wname = {0: 'kernel', 1: 'bias'}
+    for step in range(3):
+        masks = _masks(layers, B, model.seed, step)
+        eng.load_input(x, y)
+        eng.forward(training=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        if loss_name == 'mse':
+            lv, rgrads, rpred, _ = ref.loss_and_grads(x64, y64, 'mse', masks)
+        else:
+            # reference objects differ only in w_bce (0.5 for bce_dice_loss, 1 for BceDiceLoss)
+            rpred, cache = ref.forward(x64, True, masks)
+            lv, dlog = O.bce_dice_loss(y64, rpred, w_bce=kind[1], w_dice=kind[2], logits=cache['logits'])
+            rgrads = ref.backward(cache, dlog, d_is_logit_grad=True)
+        assert abs(float(eng.loss.item()) - lv) <= 2e-5 * max(1.0, abs(lv)), (step, float(eng.loss.item()), lv)
+        np.testing.assert_allclose(eng.pred.cpu().numpy(), rpred, atol=1e-4)
+        got = model._params.grads_host()
+        for (lname, i), g in _flat_grads(rgrads).items():
+            wn = wname[i] if lname.startswith('conv') or lname == 'unet' else ('gamma', 'beta')[i]
+            gg = got[(lname, wn)]
+            tol = 3e-4 * max(float(np.abs(g).max()), 1e-7)
+            assert np.abs(gg - g).max() <= tol, (step, lname, wn, float(np.abs(gg - g).max()), tol)
+        eng.optimizer_step()
+        model.optimizer.iterations += 1
+        # oracle: moving stats + Keras-Adam with ITS OWN gradients
+        if loss_name == 'mse':
+            ref.train_step(x64, y64, 'mse', masks)
+        else:
+            ref.apply_bn_moving(cache)
+            ref.apply_adam(rgrads)
+    torch.cuda.synchronize()
+    assert model._params.step_count() == 3
+    for a, b, (ln, wn, _, _, _) in zip(model.get_weights(), ref.get_weights(), model.plan.weight_specs()):
+        np.testing.assert_allclose(a, b, atol=2e-4, err_msg='%s/%s' % (ln, wn))
+    # inference after training: heat-maps 1e-3, argmax bit-exact, >0.5 masks identical
+    xt, _ = O.synthetic_batch(6, cfg['DIM'], 2, seed=9)
+    pg = model.predict(xt, batch_size=3)
+    pr = ref.predict(xt.astype(np.float64))
+    assert pg.dtype == np.float32 and pg.shape == pr.shape
+    assert np.abs(pg - pr).max() < 1e-3
+    np.testing.assert_array_equal(O.landmark_argmax(pg), O.landmark_argmax(pr.astype(np.float32)))
+    np.testing.assert_array_equal(O.threshold_mask(pg), O.threshold_mask(pr))
+    idx, mask = model.predict_landmarks(xt[:3])
+    np.testing.assert_array_equal(idx, O.landmark_argmax(pg[:3]))
+    np.testing.assert_array_equal(mask.astype(bool), O.threshold_mask(pg[:3]))
+
+
+def test_train_on_batch_logs_and_metrics():
+    cfg = _cfg(LOSS_FUNCTION=M.bce_dice_loss)
+    model = rvip.get_model(cfg, metrics=[M.dice_coef_labels, M.dice_coef_lower, M.dice_coef_upper])
+    ref, layers = _oracle_from(model, cfg)
+    x, y = O.synthetic_batch(4, cfg['DIM'], 2, seed=4)
+    logs = model.train_on_batch(x, y, return_dict=True)
+    rpred, cache = ref.forward(x.astype(np.float64), True, _masks(layers, 4, model.seed, 0))
+    lv, _ = O.bce_dice_loss(y.astype(np.float64), rpred, logits=cache['logits'])
+    dm = O.dice_metrics(y.astype(np.float64), rpred)
+    assert abs(logs['loss'] - lv) < 1e-4
+    for k in ('dice_coef_labels', 'dice_coef_lower', 'dice_coef_upper'):
+        assert abs(logs[k] - dm[k]) < 1e-5, k
+    ev = model.evaluate(x, y, return_dict=True)
+    assert np.isfinite(ev['loss'])
+
+
+def test_reference_default_config_224_fp32_forward():
+    """BASELINE.json configs[0]: template config (224x224, FILTERS 32, depth 4, batch 2), fp32, synthetic slice."""
+    cfg = dict(DIM=[224, 224], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
+               MASK_CLASSES=2, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-4, RVIP_PRECISION='fp32',
+               LOSS_FUNCTION=M.BceDiceLoss(), SEED=42)
+    model = rvip.get_model(cfg)
+    assert model.count_params() == 8641730
+    ref, _ = _oracle_from(model, cfg, dtype=np.float32)
+    x, y = O.synthetic_batch(2, cfg['DIM'], 2, seed=42)
+    pg = model.predict(x)
+    pr = ref.predict(x)
+    assert np.abs(pg - pr).max() < 1e-3
+    np.testing.assert_array_equal(O.landmark_argmax(pg), O.landmark_argmax(pr))
+    np.testing.assert_array_equal(O.threshold_mask(pg), O.threshold_mask(pr))
+    loss = model.train_on_batch(x, y)[0]
+    assert np.isfinite(loss)
+
+
+def test_bf16_path_error_budget():
+    cfg = _cfg(RVIP_PRECISION='bf16', FILTERS=16, DIM=[64, 64])
+    model = rvip.get_model(cfg, metrics=[])
+    ref, layers = _oracle_from(model, cfg)
+    B = 4
+    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=5)
+    eng = model._engine(B)
+    eng.load_input(x, y)
+    eng.forward(training=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    lv, rgrads, rpred, _ = ref.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', _masks(layers, B, model.seed, 0))
+    assert abs(float(eng.loss.item()) - lv) < 2e-2 * lv
+    assert np.abs(eng.pred.cpu().numpy() - rpred).max() < 3e-2
+    got = model._params.grads_host()
+    for lname in ('conv2d_1', 'conv2d_5', 'unet'):
+        g = rgrads[lname][0]
+        rel = np.linalg.norm(got[(lname, 'kernel')] - g) / np.linalg.norm(g)
+        assert rel < 6e-2, (lname, rel)
+
+
+def test_full_size_step_is_deterministic_and_finite():
+    """BASELINE.json configs[1] shape (256x256, F=32, depth 4, batch 32, bf16): size-independent properties --
+    two identical steps from identical state give bit-identical loss, heat-maps and gradients; a further step
+    lowers nothing to NaN."""
+    cfg = dict(DIM=[256, 256], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2,
+               LEARNING_RATE=1e-4, RVIP_PRECISION='bf16', LOSS_FUNCTION=M.mse, SEED=1)
+    model = rvip.get_model(cfg, metrics=[])
+    G = rvip.Generators.SyntheticSAXGenerator(32, dict(DIM=[256, 256], BATCHSIZE=32, GAUS=True, SIGMA=2, SHUFFLE=False))
+    x, y = G[0]
+    eng = model._engine(32)
+    outs = []
+    for _ in range(2):
+        eng.load_input(x, y)
+        eng.forward(training=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        outs.append((eng.loss.clone(), eng.pred.clone(), model._params.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.isfinite(outs[0][2]).all() and float(outs[0][2].abs().max()) > 0
+    l0 = model.train_on_batch(x, y)[0]
+    l1 = model.train_on_batch(x, y)[0]
+    assert np.isfinite(l0) and np.isfinite(l1)
+
+
+def test_fit_with_generator_and_callbacks(tmp_path):
+    cfg = _cfg(RVIP_PRECISION='bf16', DIM=[64, 64], FILTERS=8, LEARNING_RATE=2e-3, MODEL_PATH=str(tmp_path),
+               DROPOUT_MIN=0.0, DROPOUT_MAX=0.0)
+    gcfg = dict(DIM=[64, 64], BATCHSIZE=8, GAUS=True, SIGMA=2, SHUFFLE=True)
+    train = rvip.Generators.SyntheticSAXGenerator(32, gcfg, in_memory=True)
+    val = rvip.Generators.SyntheticSAXGenerator(8, dict(gcfg, SHUFFLE=False), in_memory=True)
+    model = rvip.get_model(cfg, metrics=[M.dice_coef_labels])
+    cbs = rvip.KerasCallbacks.get_callbacks(cfg, train, val)
+    hist = model.fit(x=train, validation_data=val, epochs=6, callbacks=cbs, initial_epoch=0, max_queue_size=4, verbose=0)
+    h = hist.history
+    assert set(h) >= {'loss', 'dice_coef_labels', 'val_loss', 'val_dice_coef_labels', 'lr'}
+    assert len(h['loss']) == 6 and h['loss'][-1] < h['loss'][0]
+    assert (tmp_path / 'model.npz').exists()
+    m2 = rvip.get_model(cfg)
+    m2.load_weights(str(tmp_path / 'model.npz'))
+    xb, _ = val[0]
+    assert m2.predict(xb).shape == (8, 64, 64, 2)

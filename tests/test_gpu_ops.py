@@ -1,0 +1,392 @@
+"""Per-kernel parity on a real MI355X: every entry point of include/rvip_hip.h is called through the C ABI
+(ctypes) and compared with the NumPy oracle on the same seeded inputs.  Tolerances: fp32 path 1e-4 relative
+to the result scale (fp32 MFMA = exact fp32 products, different summation order); bf16 path: inputs are
+rounded to bf16 first, so only accumulation order and the output rounding differ (2^-8 relative)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import cmr_landmark_detection_amd as rvip
+from oracle import rvip_oracle as O
+
+pytestmark = pytest.mark.gpu
+N = rvip._native
+ds = __import__('importlib').import_module('cmr-landmark-detection_amd.dropout_stream')
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def tdt(dtype):
+    return torch.bfloat16 if dtype == 'bf16' else torch.float32
+
+
+def ndt(dtype):
+    return N.BF16 if dtype == 'bf16' else N.F32
+
+
+def rnd(a, dtype):
+    """what the device will actually see: bf16-rounded (as float32) or unchanged"""
+    t = torch.from_numpy(np.ascontiguousarray(a, np.float32))
+    return t.to(torch.bfloat16).to(torch.float32).numpy() if dtype == 'bf16' else t.numpy()
+
+
+def up(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev()).to(tdt(dtype)).contiguous()
+
+
+def f32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+
+
+def down(t):
+    torch.cuda.synchronize()
+    return t.to(torch.float32).cpu().numpy()
+
+
+def close(got, ref, dtype, what=''):
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    tol = (2.0 ** -7 if dtype == 'bf16' else 2e-5) * scale
+    err = float(np.abs(got - ref).max())
+    assert err <= tol, '%s: max err %.3e > tol %.3e (scale %.3e)' % (what, err, tol, scale)
+
+
+def pack(w, dtype):
+    """HWIO fp32 master -> packed forward / dgrad operands via the library"""
+    kh, kw, ci, co = w.shape
+    wm = f32(w)
+    wf = torch.empty(9 * ci * co, dtype=tdt(dtype), device=dev())
+    wd = torch.empty(9 * ci * co, dtype=tdt(dtype), device=dev())
+    N.call('rvip_pack_conv3x3_weights', P(wm), ci, co, ndt(dtype), P(wf), P(wd), stream())
+    return wf, wd
+
+
+def conv_desc(x0, c0, up0, x1, c1, wp, bias, y, y1, csplit, n, h, w, cout, act, dtype):
+    d = N.Conv3x3Desc()
+    d.x0, d.c0, d.up0 = x0.data_ptr(), c0, up0
+    d.x1, d.c1 = (x1.data_ptr() if x1 is not None else None), c1
+    d.w_packed, d.bias = wp.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.y, d.y1, d.csplit = y.data_ptr(), (y1.data_ptr() if y1 is not None else None), csplit
+    d.n, d.h, d.w, d.cout, d.act, d.dtype = n, h, w, cout, act, ndt(dtype)
+    return d
+
+
+SHAPES = [  # n, h, w, cin, cout
+    (2, 24, 40, 8, 8),        # TW=32 tiles with ragged right/bottom edges
+    (1, 16, 16, 16, 40),      # TW=16 tile = whole image, two output-channel tiles with a tail
+    (3, 14, 14, 24, 8),       # TW=16 with masking (the 224-input net reaches 14x14)
+    (1, 40, 72, 72, 64),      # three input-channel chunks incl. a partial one (bf16: 72 = 2*32+8)
+]
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_conv3x3_fwd_dgrad_wgrad(shape, dtype):
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(hash(shape) % 1000)
+    x = rnd(rng.standard_normal((n, h, w, ci)), dtype)
+    wt = rnd(rng.standard_normal((3, 3, ci, co)) * 0.2, dtype)
+    b = rng.standard_normal(co).astype(np.float32)
+    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
+    xd, dyd, bd = up(x, dtype), up(dy, dtype), f32(b)
+    wf, wd = pack(wt, dtype)
+    # forward, relu epilogue
+    y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    d = conv_desc(xd, ci, 0, None, 0, wf, bd, y, None, 0, n, h, w, co, N.ACT['relu'], dtype)
+    N.call('rvip_conv3x3_fwd', C.byref(d), stream())
+    ref = O.act_fwd(O.conv2d_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), 'relu')
+    close(down(y), ref, dtype, 'fwd')
+    # data gradient = same kernel on dy with the rotated/transposed operand
+    dx = torch.empty((n, h, w, ci), dtype=tdt(dtype), device=dev())
+    d2 = conv_desc(dyd, co, 0, None, 0, wd, None, dx, None, 0, n, h, w, ci, 0, dtype)
+    N.call('rvip_conv3x3_fwd', C.byref(d2), stream())
+    rdx, rdw, _ = O.conv2d_same_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64))
+    close(down(dx), rdx, dtype, 'dgrad')
+    # weight gradient (fp32 HWIO out, deterministic split-K)
+    L = N.lib()
+    wsb = L.rvip_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.full((3, 3, ci, co), 7.0, dtype=torch.float32, device=dev())
+    g = N.Wgrad3x3Desc()
+    g.x0, g.c0, g.up0, g.x1, g.c1 = xd.data_ptr(), ci, 0, None, 0
+    g.dy, g.dw = dyd.data_ptr(), dw.data_ptr()
+    g.n, g.h, g.w, g.cout, g.dtype = n, h, w, co, ndt(dtype)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
+    N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+    got = down(dw)
+    scale = float(np.abs(rdw).max())
+    assert np.abs(got - rdw).max() <= (2e-3 if dtype == 'bf16' else 2e-5) * scale, np.abs(got - rdw).max() / scale
+    dw2 = torch.empty_like(dw)
+    g.dw = dw2.data_ptr()
+    N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+    assert torch.equal(dw, dw2)                               # bitwise reproducible reduction
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv3x3_virtual_upsample_concat_and_split(dtype):
+    """UpSampling2D + Conv2D and Concatenate + Conv2D as addressing modes; dgrad of the concat conv writes the
+    two halves of the gradient to separate tensors."""
+    n, h, w = 2, 16, 32
+    c0, c1, co = 16, 8, 24
+    rng = np.random.default_rng(3)
+    lo = rnd(rng.standard_normal((n, h // 2, w // 2, c0)), dtype)
+    sk = rnd(rng.standard_normal((n, h, w, c1)), dtype)
+    wt = rnd(rng.standard_normal((3, 3, c0 + c1, co)) * 0.2, dtype)
+    wf, wd = pack(wt, dtype)
+    y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    d = conv_desc(up(lo, dtype), c0, 1, up(sk, dtype), c1, wf, None, y, None, 0, n, h, w, co, 0, dtype)
+    N.call('rvip_conv3x3_fwd', C.byref(d), stream())
+    xcat = np.concatenate([O.upsample_nearest_fwd(lo), sk], -1).astype(np.float64)
+    close(down(y), O.conv2d_same_fwd(xcat, wt.astype(np.float64)), dtype, 'up+concat fwd')
+    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
+    g0 = torch.empty((n, h, w, c0), dtype=tdt(dtype), device=dev())
+    g1 = torch.empty((n, h, w, c1), dtype=tdt(dtype), device=dev())
+    d2 = conv_desc(up(dy, dtype), co, 0, None, 0, wd, None, g0, g1, c0, n, h, w, c0 + c1, 0, dtype)
+    N.call('rvip_conv3x3_fwd', C.byref(d2), stream())
+    rdx, rdw, _ = O.conv2d_same_bwd(xcat, wt.astype(np.float64), dy.astype(np.float64))
+    close(down(g0), rdx[..., :c0], dtype, 'split dgrad 0')
+    close(down(g1), rdx[..., c0:], dtype, 'split dgrad 1')
+    glo = torch.empty((n, h // 2, w // 2, c0), dtype=tdt(dtype), device=dev())
+    N.call('rvip_upsample2x_bwd', P(g0), P(glo), n, h // 2, w // 2, c0, ndt(dtype), stream())
+    close(down(glo), O.upsample_nearest_bwd(rnd(down(g0), dtype).astype(np.float64)), dtype, 'upsample bwd')
+    L = N.lib()
+    wsb = L.rvip_conv3x3_wgrad_workspace(n, h, w, c0 + c1, co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.empty((3, 3, c0 + c1, co), dtype=torch.float32, device=dev())
+    lod, skd, dyd = up(lo, dtype), up(sk, dtype), up(dy, dtype)
+    g = N.Wgrad3x3Desc()
+    g.x0, g.c0, g.up0, g.x1, g.c1 = lod.data_ptr(), c0, 1, skd.data_ptr(), c1
+    g.dy, g.dw = dyd.data_ptr(), dw.data_ptr()
+    g.n, g.h, g.w, g.cout, g.dtype = n, h, w, co, ndt(dtype)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
+    N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+    scale = float(np.abs(rdw).max())
+    assert np.abs(down(dw) - rdw).max() <= (2e-3 if dtype == 'bf16' else 2e-5) * scale
+    ups = torch.empty((n, h, w, c0), dtype=tdt(dtype), device=dev())
+    N.call('rvip_upsample2x_fwd', P(lod), P(ups), n, h // 2, w // 2, c0, ndt(dtype), stream())
+    np.testing.assert_array_equal(down(ups), O.upsample_nearest_fwd(lo))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_first_layer_c1(dtype):
+    n, h, w, co = 2, 20, 36, 16
+    rng = np.random.default_rng(4)
+    x = rnd(rng.random((n, h, w, 1)), dtype)
+    wt = (rng.standard_normal((3, 3, 1, co)) * 0.5).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    xd = up(x, dtype)
+    y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    N.call('rvip_conv3x3_c1_fwd', P(xd), P(f32(wt)), P(f32(b)), P(y), n, h, w, co, N.ACT['elu'], ndt(dtype), stream())
+    ref = O.act_fwd(O.conv2d_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), 'elu')
+    close(down(y), ref, dtype, 'c1 fwd')
+    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
+    L = N.lib()
+    wsb = L.rvip_reduce_workspace(n * h * w, 16 * co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.empty((3, 3, 1, co), dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_c1_wgrad', P(xd), P(up(dy, dtype)), P(dw), n, h, w, co, ndt(dtype), P(ws), C.c_size_t(wsb), stream())
+    _, rdw, _ = O.conv2d_same_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64))
+    assert np.abs(down(dw) - rdw).max() <= 2e-5 * np.abs(rdw).max()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('act_after', [0, 1])
+def test_batchnorm_dropout_pool_forward_backward(dtype, act_after):
+    n, h, w, c = 3, 12, 20, 16
+    rows = n * h * w
+    rng = np.random.default_rng(5)
+    pre = rng.standard_normal((n, h, w, c)) * 1.5 + 0.3
+    z = rnd(pre if act_after else np.maximum(pre, 0), dtype)          # act before BN: z is the post-ReLU tensor
+    gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    mm0, mv0 = rng.standard_normal(c).astype(np.float32), (1 + rng.random(c)).astype(np.float32)
+    L = N.lib()
+    wsb = L.rvip_reduce_workspace(rows, 16 * c)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    zd, gd, bd, mm, mv = up(z, dtype), f32(gamma), f32(beta), f32(mm0), f32(mv0)
+    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(4))
+    N.call('rvip_bn_train_stats', P(zd), C.c_longlong(rows), c, ndt(dtype), P(gd), P(bd), P(mm), P(mv), 0.99, 1e-3, 1,
+           P(mean), P(invstd), P(scale), P(shift), P(ws), C.c_size_t(wsb), stream())
+    z64 = z.astype(np.float64)
+    ybn, cache = O.bn_train_fwd(z64, gamma.astype(np.float64), beta.astype(np.float64))
+    np.testing.assert_allclose(down(mean), cache[2], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(down(invstd), cache[1], rtol=2e-6)
+    rm, rv = O.bn_moving_update(mm0.astype(np.float64), mv0.astype(np.float64), cache[2], cache[3], rows)
+    np.testing.assert_allclose(down(mm), rm, atol=1e-6)
+    np.testing.assert_allclose(down(mv), rv, atol=1e-6)
+    # apply: BN affine (+ReLU after BN) + dropout(stream) + 2x2 max-pool in one pass
+    state = torch.zeros(8, dtype=torch.int32, device=dev())
+    state[N.STATE_SEED], state[N.STATE_STEP] = 1234, 7
+    rate, lid = 0.4, 3
+    y = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
+    pooled = torch.empty((n, h // 2, w // 2, c), dtype=tdt(dtype), device=dev())
+    a = N.ApplyDesc()
+    a.z, a.y, a.pooled = zd.data_ptr(), y.data_ptr(), pooled.data_ptr()
+    a.scale, a.shift, a.act = scale.data_ptr(), shift.data_ptr(), (N.ACT['relu'] if act_after else 0)
+    a.drop_rate, a.mask, a.state, a.layer_id = rate, None, state.data_ptr(), lid
+    a.n, a.h, a.w, a.c, a.dtype = n, h, w, c, ndt(dtype)
+    N.call('rvip_bn_apply', C.byref(a), stream())
+    keep = ds.keep_mask((n, h, w, c), rate, 1234, 7, lid).astype(np.float64)
+    yact = np.maximum(ybn, 0) if act_after else ybn
+    yref = yact * keep / np.float32(1 - rate)
+    close(down(y), yref, dtype, 'apply')
+    yq = down(y).astype(np.float64)
+    pref, idx = O.maxpool2x2_fwd(yq)
+    np.testing.assert_array_equal(down(pooled), pref)                   # pool of what was stored: exact
+    # injected mask gives the same result as the stream
+    md = torch.from_numpy(keep.astype(np.uint8)).to(dev())
+    y2 = torch.empty_like(y)
+    a.y, a.pooled, a.mask = y2.data_ptr(), None, md.data_ptr()
+    N.call('rvip_bn_apply', C.byref(a), stream())
+    assert torch.equal(y, y2)
+    # backward: maxpool route (+skip add) -> BN backward
+    dp = rnd(rng.standard_normal((n, h // 2, w // 2, c)), dtype)
+    addg = rnd(rng.standard_normal((n, h, w, c)), dtype)
+    gy = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
+    N.call('rvip_maxpool2x2_bwd', P(y), P(up(dp, dtype)), P(up(addg, dtype)), P(gy), n, h, w, c, ndt(dtype), stream())
+    gref = O.maxpool2x2_bwd(dp.astype(np.float64), idx, yq.shape) + addg
+    close(down(gy), gref, dtype, 'maxpool bwd')
+    g_in = rnd(down(gy), dtype).astype(np.float64)                      # what the BN backward kernels read
+    dz = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
+    dgamma, dbeta, dbias = (torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(3))
+    coef = torch.empty(3 * c, dtype=torch.float32, device=dev())
+    b = N.BnBwdDesc()
+    b.dy, b.z, b.dz = gy.data_ptr(), zd.data_ptr(), dz.data_ptr()
+    b.gamma, b.mean, b.invstd = gd.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    b.scale, b.shift = scale.data_ptr(), shift.data_ptr()
+    b.dgamma, b.dbeta, b.dbias, b.coef = dgamma.data_ptr(), dbeta.data_ptr(), dbias.data_ptr(), coef.data_ptr()
+    b.act, b.act_after_bn = N.ACT['relu'], act_after
+    b.drop_rate, b.mask, b.state, b.layer_id = rate, None, state.data_ptr(), lid
+    b.rows, b.c, b.dtype = rows, c, ndt(dtype)
+    b.workspace, b.workspace_bytes = ws.data_ptr(), wsb
+    N.call('rvip_bn_bwd_reduce', C.byref(b), stream())
+    N.call('rvip_bn_bwd_apply', C.byref(b), stream())
+    g = g_in * keep / np.float32(1 - rate)
+    if act_after:
+        g = g * (yact > 0)
+    dxr, dgr, dbr = O.bn_train_bwd(g, gamma.astype(np.float64), cache)
+    dconv = dxr if act_after else dxr * (z64 > 0)
+    tolr = 1e-2 if dtype == 'bf16' else 1e-4
+    np.testing.assert_allclose(down(dgamma), dgr, atol=tolr * np.abs(dgr).max())
+    np.testing.assert_allclose(down(dbeta), dbr, atol=tolr * np.abs(dbr).max())
+    close(down(dz), dconv, dtype, 'bn bwd dz')
+    np.testing.assert_allclose(down(dbias), rnd(down(dz), dtype).astype(np.float64).sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
+    # no-BN path (up-conv / BATCH_NORMALISATION False): dconv = g * act'(z)
+    b.gamma, b.coef, b.act_after_bn = None, None, 0
+    N.call('rvip_bn_bwd_apply', C.byref(b), stream())
+    z_act = np.maximum(z64, 0)
+    close(down(dz), g_in * keep / np.float32(1 - rate) * (z64 > 0), dtype, 'act bwd (no BN)')
+    # inference coefficients
+    N.call('rvip_bn_infer_coeffs', P(gd), P(bd), P(mm), P(mv), 1e-3, c, P(scale), P(shift), stream())
+    sc = gamma / np.sqrt(down(mv) + 1e-3)
+    np.testing.assert_allclose(down(scale), sc, rtol=1e-5)
+    np.testing.assert_allclose(down(shift), beta - down(mm) * sc, rtol=1e-4, atol=1e-6)
+    assert z_act is not None
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('loss', ['mse', 'bce_dice'])
+def test_head_loss_and_backward(dtype, loss):
+    n, h, w, cin, k = 3, 16, 24, 16, 2
+    rows = n * h * w
+    rng = np.random.default_rng(6)
+    x = rnd(rng.standard_normal((n, h, w, cin)), dtype)
+    wt = (rng.standard_normal((1, 1, cin, k)) * 0.4).astype(np.float32)
+    b = (rng.standard_normal(k) * 0.1).astype(np.float32)
+    _, yt = O.synthetic_batch(n, (h, w), k, seed=2)
+    L = N.lib()
+    wsb = L.rvip_reduce_workspace(rows, 8 * cin)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    xd, wd_, bd, ytd = up(x, dtype), f32(wt), f32(b), f32(yt)
+    pred = torch.empty((n, h, w, k), dtype=torch.float32, device=dev())
+    sums = torch.zeros(16, dtype=torch.float32, device=dev())
+    N.call('rvip_head_fwd', P(xd), P(wd_), P(bd), P(pred), P(ytd), P(sums), C.c_longlong(rows), cin, k, ndt(dtype), P(ws),
+           C.c_size_t(wsb), stream())
+    logits = O.conv2d_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    pref = O.act_fwd(logits, 'sigmoid')
+    np.testing.assert_allclose(down(pred), pref, atol=2e-6)
+    s = down(sums).astype(np.float64)
+    t64 = yt.astype(np.float64)
+    np.testing.assert_allclose(s[0], ((pref - t64) ** 2).sum(), rtol=1e-4)
+    np.testing.assert_allclose(s[2:5], [(t64 * pref).sum(), t64.sum(), pref.sum()], rtol=1e-4)
+    np.testing.assert_allclose(s[8:11], [(t64[..., -1] * pref[..., -1]).sum(), t64[..., -1].sum(), pref[..., -1].sum()], rtol=1e-4)
+    world = 2.0                                                         # pretend 2 ranks: global-batch scaling
+    dlogit = torch.empty((n, h, w, k), dtype=torch.float32, device=dev())
+    lossd = torch.zeros(1, dtype=torch.float32, device=dev())
+    kind = N.LOSS_MSE if loss == 'mse' else N.LOSS_BCE_DICE
+    N.call('rvip_head_grad', P(pred), P(ytd), P(sums), P(dlogit), P(lossd), C.c_longlong(rows), k, kind,
+           1.0 / (rows * k * world), 1.0 / world, 0.5, 1.0, stream())
+    if loss == 'mse':
+        lv, dpred = O.mse_loss(t64, pref, global_batch=int(n * world))
+        dl_ref = dpred * pref * (1 - pref)
+    else:
+        lv, dl_ref = O.bce_dice_loss(t64, pref, logits=logits, global_batch=int(n * world))
+    np.testing.assert_allclose(float(down(lossd)[0]), lv, rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(down(dlogit), dl_ref, atol=1e-4 * np.abs(dl_ref).max())
+    dx = torch.empty((n, h, w, cin), dtype=tdt(dtype), device=dev())
+    dw = torch.empty((1, 1, cin, k), dtype=torch.float32, device=dev())
+    db = torch.empty(k, dtype=torch.float32, device=dev())
+    N.call('rvip_head_bwd', P(xd), P(wd_), P(dlogit), P(dx), P(dw), P(db), C.c_longlong(rows), cin, k, ndt(dtype), P(ws),
+           C.c_size_t(wsb), stream())
+    dl = down(dlogit).astype(np.float64)
+    rdx, rdw, rdb = O.conv2d_same_bwd(x.astype(np.float64), wt.astype(np.float64), dl)
+    close(down(dx), rdx, dtype, 'head dx')
+    np.testing.assert_allclose(down(dw), rdw, atol=1e-4 * np.abs(rdw).max())
+    np.testing.assert_allclose(down(db), rdb, atol=1e-4 * np.abs(rdb).max())
+    # landmarks: argmax bit-exact incl. ties, > 0.5 mask
+    pr = down(pred)
+    pr[0, 3, 5, 0] = pr[0, 9, 2, 0] = 2.0                               # tie -> first in row-major order
+    prd = f32(pr)
+    idx = torch.zeros((n, k), dtype=torch.int64, device=dev())
+    mask = torch.zeros((n, h, w, k), dtype=torch.uint8, device=dev())
+    N.call('rvip_landmarks', P(prd), P(idx), P(mask), n, h * w, k, 0.5, stream())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(idx.cpu().numpy(), O.landmark_argmax(pr))
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), O.threshold_mask(pr))
+
+
+def test_adam_state_and_convert():
+    rng = np.random.default_rng(7)
+    cnt = 10007
+    th, g = rng.standard_normal(cnt).astype(np.float32), rng.standard_normal(cnt).astype(np.float32)
+    m, v = np.zeros(cnt, np.float32), np.zeros(cnt, np.float32)
+    thd, gd, md, vd = f32(th), f32(g), f32(m), f32(v)
+    state = torch.zeros(8, dtype=torch.int32, device=dev())
+    state.view(torch.float32)[N.STATE_LR] = 1e-3
+    rt, rm, rv = th.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for t in range(1, 4):
+        N.call('rvip_adam_step', P(thd), P(gd), P(md), P(vd), C.c_longlong(cnt), 0.9, 0.999, 1e-7, 1.0, P(state), stream())
+        N.call('rvip_state_tick', P(state), stream())
+        rt, rm, rv = O.adam_step(rt, g.astype(np.float64), rm, rv, t, 1e-3)
+    assert int(state[0].item()) == 3
+    np.testing.assert_allclose(down(thd), rt, atol=2e-6)
+    np.testing.assert_allclose(down(vd), rv, rtol=1e-5, atol=1e-9)
+    a = rng.standard_normal(1000).astype(np.float32)
+    bd = torch.empty(1000, dtype=torch.bfloat16, device=dev())
+    N.call('rvip_convert', P(f32(a)), N.F32, P(bd), N.BF16, C.c_longlong(1000), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(bd.cpu(), torch.from_numpy(a).to(torch.bfloat16))     # RNE like torch
+
+
+def test_bad_arguments_are_refused_not_launched():
+    L = N.lib()
+    x = torch.zeros(64, dtype=torch.float32, device=dev())
+    d = conv_desc(x, 6, 0, None, 0, x, None, x, None, 0, 1, 4, 4, 8, 0, 'f32')       # c0 % 4 != 0
+    assert L.rvip_conv3x3_fwd(C.byref(d), stream()) == -1
+    assert L.rvip_conv3x3_fwd(None, stream()) == -1
+    g = N.Wgrad3x3Desc()
+    g.x0, g.c0, g.dy, g.dw = x.data_ptr(), 8, x.data_ptr(), x.data_ptr()
+    g.n, g.h, g.w, g.cout, g.dtype = 1, 4, 4, 8, N.F32
+    g.workspace, g.workspace_bytes = x.data_ptr(), 16
+    assert L.rvip_conv3x3_wgrad(C.byref(g), stream()) == -3                          # workspace too small
