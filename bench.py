@@ -38,7 +38,7 @@ def main():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
-    ap.add_argument('--cpu-batch', type=int, default=4)
+    ap.add_argument('--cpu-batch', type=int, default=8)
     args = ap.parse_args()
 
     import numpy as np
@@ -197,6 +197,13 @@ def cpu_baseline(cfg, batch):
     import torch
     from oracle import torch_ref
     cores = len(os.sched_getaffinity(0))
+    try:                                       # respect the cgroup CPU quota (the GPU box grants a share of its cores)
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cores = min(cores, int(os.environ.get('RVIP_CPU_BASELINE_THREADS', 16)))
     cpu_cfg = {k: v for k, v in cfg.items() if k not in ('LOSS_FUNCTION', 'RVIP_PRECISION')}
     sec = torch_ref.time_train_steps(cpu_cfg, batch, steps=2, warmup=1, threads=cores)
     return {'value': round(batch / sec, 3), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',

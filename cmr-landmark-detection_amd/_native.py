@@ -106,6 +106,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RvipError('%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). '
                             'There is no CPU fallback for the product path.' % LIB_PATH)
+        try:
+            # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It must be
+            # mapped BEFORE this library so that our NEEDED libamdhip64.so.7 binds to the same runtime; loaded the
+            # other way round the process ends up with two HIP runtimes and launches fail with hipErrorNoDevice.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol

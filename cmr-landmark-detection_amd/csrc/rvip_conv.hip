@@ -290,6 +290,7 @@ extern "C" const char* rvip_build_info(void) { return "rvip_hip gfx950 wave64 mf
 extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
 
 extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
+    (void)hipGetLastError();
     if (!d || !d->x0 || !d->w_packed || !d->y) return RVIP_EINVAL;
     const int ve = d->dtype == RVIP_BF16 ? 8 : 4;
     if (d->dtype != RVIP_BF16 && d->dtype != RVIP_F32) return RVIP_EINVAL;
@@ -312,6 +313,7 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
 }
 
 extern "C" int rvip_pack_conv3x3_weights(const float* w, int cin, int cout, int dtype, void* wf, void* wd, void* stream) {
+    (void)hipGetLastError();
     if (!w || cin <= 0 || cout <= 0 || (!wf && !wd)) return RVIP_EINVAL;
     const long long total = 9LL * cin * cout;
     const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
@@ -324,6 +326,7 @@ extern "C" int rvip_pack_conv3x3_weights(const float* w, int cin, int cout, int 
 
 extern "C" int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* bias, void* y, int n, int h, int w_, int cout,
                                    int act, int dtype, void* stream) {
+    (void)hipGetLastError();
     if (!x || !w || !y || n <= 0 || h <= 0 || w_ <= 0) return RVIP_EINVAL;
     const int ve = dtype == RVIP_BF16 ? 8 : 4;
     if (cout <= 0 || cout % ve) return RVIP_EINVAL;

@@ -657,6 +657,7 @@ extern "C" int rvip_bn_train_stats(const void* z, long long rows, int c, int dty
                                    float* moving_mean, float* moving_var, float momentum, float eps, int unbiased_moving,
                                    float* mean, float* invstd, float* scale, float* shift,
                                    void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
     if (!z || !mean || !invstd || !scale || !shift || !workspace || !RVIP_DT_OK(dtype)) return RVIP_EINVAL;
     RedGeom g;
     if (!red_geom(rows, c, RVIP_VE(dtype), g)) return RVIP_EINVAL;
@@ -673,12 +674,14 @@ extern "C" int rvip_bn_train_stats(const void* z, long long rows, int c, int dty
 
 extern "C" int rvip_bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int c,
                                     float* scale, float* shift, void* stream) {
+    (void)hipGetLastError();
     if (!mm || !mv || !scale || !shift || c <= 0) return RVIP_EINVAL;
     hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3((unsigned)cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mm, mv, eps, c, scale, shift);
     return check_launch();
 }
 
 extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
+    (void)hipGetLastError();
     if (!d || !d->z || !d->y || !RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
     const int ve = RVIP_VE(d->dtype);
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->c % ve) return RVIP_EINVAL;
@@ -725,6 +728,7 @@ static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
 }
 
 extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
+    (void)hipGetLastError();
     BnBwdArgs a; RedGeom g;
     int rc = fill_bnbwd(d, a, g);
     if (rc) return rc;
@@ -741,6 +745,7 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
 }
 
 extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
+    (void)hipGetLastError();
     BnBwdArgs a; RedGeom g;
     int rc = fill_bnbwd(d, a, g);
     if (rc) return rc;
@@ -759,6 +764,7 @@ extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
 
 extern "C" int rvip_maxpool2x2_bwd(const void* y, const void* dpooled, const void* add, void* dx, int n, int h, int w, int c,
                                    int dtype, void* stream) {
+    (void)hipGetLastError();
     if (!y || !dpooled || !dx || !RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w <= 0 || ((h | w) & 1) || c <= 0 || c % RVIP_VE(dtype)) return RVIP_EINVAL;
     const long long total = (long long)n * (h / 2) * (w / 2) * (c / RVIP_VE(dtype));
     dim3 grid((unsigned)cdiv(total, 256));
@@ -780,9 +786,11 @@ static int launch_upsample(const void* src, void* dst, int n, int h, int w, int 
 }
 // h, w are the LOW-resolution extents for both directions
 extern "C" int rvip_upsample2x_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream) {
+    (void)hipGetLastError();
     return launch_upsample<false>(x, y, n, h, w, c, dtype, stream);
 }
 extern "C" int rvip_upsample2x_bwd(const void* dy, void* dx, int n, int h, int w, int c, int dtype, void* stream) {
+    (void)hipGetLastError();
     return launch_upsample<true>(dy, dx, n, h, w, c, dtype, stream);
 }
 
@@ -793,6 +801,7 @@ struct PostHeadSums {
 
 extern "C" int rvip_head_fwd(const void* x, const float* w, const float* b, float* pred, const float* y_true, float* sums,
                              long long rows, int cin, int k, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
     if (!x || !w || !pred || !RVIP_DT_OK(dtype) || rows <= 0 || cin <= 0 || cin % RVIP_VE(dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
     if (y_true && (!sums || !workspace)) return RVIP_EINVAL;
     long long nb = cdiv(rows, 256 * 4);
@@ -813,6 +822,7 @@ extern "C" int rvip_head_fwd(const void* x, const float* w, const float* b, floa
 extern "C" int rvip_head_grad(const float* pred, const float* y_true, const float* sums, float* dlogit, float* loss_out,
                               long long rows, int k, int loss_kind, float inv_count, float local_over_global,
                               float w_bce, float w_dice, void* stream) {
+    (void)hipGetLastError();
     if (!pred || !y_true || !sums || !dlogit || rows <= 0 || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
     if (loss_kind != RVIP_LOSS_MSE && loss_kind != RVIP_LOSS_BCE_DICE) return RVIP_EINVAL;
     const long long count = rows * k;
@@ -822,6 +832,7 @@ extern "C" int rvip_head_grad(const float* pred, const float* y_true, const floa
 
 extern "C" int rvip_head_bwd(const void* x, const float* w, const float* dlogit, void* dx, float* dw, float* db,
                              long long rows, int cin, int k, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
     if (!x || !w || !dlogit || !dw || !db || !workspace || !RVIP_DT_OK(dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
     RedGeom g;
     if (!red_geom(rows, cin, RVIP_VE(dtype), g)) return RVIP_EINVAL;
@@ -838,6 +849,7 @@ extern "C" int rvip_head_bwd(const void* x, const float* w, const float* dlogit,
 
 extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cout, int dtype,
                                      void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
     if (!x || !dy || !dw || !workspace || !RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w_ <= 0) return RVIP_EINVAL;
     RedGeom g;
     if (!red_geom((long long)n * h * w_, cout, RVIP_VE(dtype), g)) return RVIP_EINVAL;
@@ -853,6 +865,7 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
 }
 
 extern "C" int rvip_landmarks(const float* pred, long long* idx_out, uint8_t* mask_out, int n, int hw, int k, float thr, void* stream) {
+    (void)hipGetLastError();
     if (!pred || !idx_out || n <= 0 || hw <= 0 || k <= 0) return RVIP_EINVAL;
     hipLaunchKernelGGL(landmarks_kernel, dim3((unsigned)(n * k)), dim3(256), 0, (hipStream_t)stream, pred, idx_out, mask_out, hw, k, thr);
     return check_launch();
@@ -860,6 +873,7 @@ extern "C" int rvip_landmarks(const float* pred, long long* idx_out, uint8_t* ma
 
 extern "C" int rvip_adam_step(float* theta, const float* grad, float* m, float* v, long long count, float beta1, float beta2,
                               float eps, float grad_scale, const uint32_t* state, void* stream) {
+    (void)hipGetLastError();
     if (!theta || !grad || !m || !v || !state || count <= 0) return RVIP_EINVAL;
     long long nb = cdiv(count, 256);
     if (nb > 4096) nb = 4096;
@@ -868,12 +882,14 @@ extern "C" int rvip_adam_step(float* theta, const float* grad, float* m, float* 
 }
 
 extern "C" int rvip_state_tick(uint32_t* state, void* stream) {
+    (void)hipGetLastError();
     if (!state) return RVIP_EINVAL;
     hipLaunchKernelGGL(state_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
     return check_launch();
 }
 
 extern "C" int rvip_convert(const void* src, int sdt, void* dst, int ddt, long long count, void* stream) {
+    (void)hipGetLastError();
     if (!src || !dst || count <= 0 || !RVIP_DT_OK(sdt) || !RVIP_DT_OK(ddt)) return RVIP_EINVAL;
     long long nb = cdiv(count, 256);
     if (nb > 4096) nb = 4096;

@@ -209,6 +209,7 @@ extern "C" size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int
 }
 
 extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
+    (void)hipGetLastError();
     if (!d || !d->x0 || !d->dy || !d->dw || !d->workspace) return RVIP_EINVAL;
     if (d->dtype != RVIP_BF16 && d->dtype != RVIP_F32) return RVIP_EINVAL;
     const int ve = d->dtype == RVIP_BF16 ? 8 : 4;

@@ -282,7 +282,9 @@ class Engine:
                     P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'), P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'),
                     C.c_float(BN_EPS), st.cout, self._bn(st, 'scale'), self._bn(st, 'shift'))))
             # ---- apply (BN affine, act-after-BN, dropout, pool) ----
-            if y is not z:
+            # (a conv that feeds MaxPooling directly shares one tensor name for z and y: the pass then runs in
+            #  place as an identity and only produces the pooled tensor)
+            if st.bn or st.act_post or st.drop or st.pool:
                 for training in (True, False):
                     a = N.ApplyDesc()
                     a.z, a.y = z.data_ptr(), y.data_ptr()

@@ -435,6 +435,13 @@ def dice_metrics(y_true, y_pred):
     }
 
 
+def bf16_round(a):
+    """Round-to-nearest-even to bfloat16 and back (storage emulation for the bf16 device path)."""
+    import torch
+    a = np.asarray(a)
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy().astype(a.dtype)
+
+
 def landmark_argmax(heat):
     """Flat argmax per (slice, channel), row-major over (H, W), first max wins."""
     n, h, w, c = heat.shape
@@ -492,10 +499,29 @@ def gaussian_targets(mask_onehot, sigma):
 class OracleUNet:
     """Executes build_graph(config) with the primitives above."""
 
-    def __init__(self, config, params=None, seed=42, dtype=np.float32):
+    def __init__(self, config, params=None, seed=42, dtype=np.float32, quant=None):
+        """quant: optional storage-rounding emulation (e.g. ``bf16_round``).  It is applied exactly where the
+        device path materialises a low-precision tensor: network input, packed 3x3 kernels (not the first
+        Cin=1 layer, not the head: those read the fp32 masters), every conv output, the END of each fused
+        BN->[act]->[dropout] chain, and in backward the conv-output gradient and every data-gradient tensor."""
         self.config = dict(config)
         self.layers = build_graph(config)
         self.dtype = dtype
+        self.quant = quant
+        consumers = {}
+        for l in self.layers:
+            for i in l['inputs']:
+                consumers.setdefault(i, []).append(l['type'])
+        self._mat = set()
+        for l in self.layers:
+            t = l['type']
+            if t in ('InputLayer', 'MaxPooling2D') or (t.startswith('Conv') and l['name'] != 'unet'):
+                self._mat.add(l['name'])
+            elif t in ('BatchNormalization', 'Activation', 'Dropout'):
+                if not any(c in ('Activation', 'Dropout') for c in consumers.get(l['name'], [])):
+                    self._mat.add(l['name'])
+        convs = [l['name'] for l in self.layers if l['type'].startswith('Conv')]
+        self._qweights = set(convs[1:-1])
         self.params = params if params is not None else init_params(self.layers, seed, dtype)
         self.params = OrderedDict((k, [np.asarray(a, dtype) for a in v]) for k, v in self.params.items())
         self.lr = float(config.get('LEARNING_RATE', 0.001))
@@ -518,6 +544,8 @@ class OracleUNet:
                 out = x
             elif ty == 'Conv2D':
                 w, b = self.params[name]
+                if self.quant is not None and name in self._qweights:
+                    w = self.quant(w)
                 pre = conv2d_same_fwd(ins[0], w, b)
                 out = act_fwd(pre, l['activation'])
                 if name == 'unet':
@@ -551,6 +579,8 @@ class OracleUNet:
                 out = np.concatenate(ins, axis=-1)
             else:
                 raise NotImplementedError(ty)
+            if self.quant is not None and name in self._mat:
+                out = self.quant(out)
             t[name] = out
         cache['tensors'] = t
         return t['unet'], cache
@@ -576,12 +606,21 @@ class OracleUNet:
                 continue
             dy = dt.pop(name)
             ins = l['inputs']
+            q = self.quant
+            if q is not None and (name in self._mat or ty in ('UpSampling2D', 'Concatenate')):
+                dy = q(dy)                                  # a materialised gradient tensor (sum rounded once)
             if ty == 'InputLayer':
                 continue
             if ty == 'Conv2D':
                 w, _ = self.params[name]
+                if q is not None and name in self._qweights:
+                    w = q(w)
                 dpre = dy if (name == 'unet' and d_is_logit_grad) else act_bwd(t[name], dy, l['activation'])
+                if q is not None and name != 'unet':
+                    dpre = q(dpre)                          # dz: what wgrad / dgrad read
                 dx, dw, db = conv2d_same_bwd(t[ins[0]], w, dpre)
+                if q is not None:
+                    dx = q(dx)
                 grads[name] = [dw, db]
                 acc(ins[0], dx)
             elif ty == 'Conv2DTranspose':

@@ -145,14 +145,16 @@ def test_conv3x3_virtual_upsample_concat_and_split(dtype):
     wt = rnd(rng.standard_normal((3, 3, c0 + c1, co)) * 0.2, dtype)
     wf, wd = pack(wt, dtype)
     y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
-    d = conv_desc(up(lo, dtype), c0, 1, up(sk, dtype), c1, wf, None, y, None, 0, n, h, w, co, 0, dtype)
+    lod, skd = up(lo, dtype), up(sk, dtype)
+    d = conv_desc(lod, c0, 1, skd, c1, wf, None, y, None, 0, n, h, w, co, 0, dtype)
     N.call('rvip_conv3x3_fwd', C.byref(d), stream())
     xcat = np.concatenate([O.upsample_nearest_fwd(lo), sk], -1).astype(np.float64)
     close(down(y), O.conv2d_same_fwd(xcat, wt.astype(np.float64)), dtype, 'up+concat fwd')
     dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
     g0 = torch.empty((n, h, w, c0), dtype=tdt(dtype), device=dev())
     g1 = torch.empty((n, h, w, c1), dtype=tdt(dtype), device=dev())
-    d2 = conv_desc(up(dy, dtype), co, 0, None, 0, wd, None, g0, g1, c0, n, h, w, c0 + c1, 0, dtype)
+    dyd = up(dy, dtype)
+    d2 = conv_desc(dyd, co, 0, None, 0, wd, None, g0, g1, c0, n, h, w, c0 + c1, 0, dtype)
     N.call('rvip_conv3x3_fwd', C.byref(d2), stream())
     rdx, rdw, _ = O.conv2d_same_bwd(xcat, wt.astype(np.float64), dy.astype(np.float64))
     close(down(g0), rdx[..., :c0], dtype, 'split dgrad 0')
@@ -164,7 +166,6 @@ def test_conv3x3_virtual_upsample_concat_and_split(dtype):
     wsb = L.rvip_conv3x3_wgrad_workspace(n, h, w, c0 + c1, co)
     ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
     dw = torch.empty((3, 3, c0 + c1, co), dtype=torch.float32, device=dev())
-    lod, skd, dyd = up(lo, dtype), up(sk, dtype), up(dy, dtype)
     g = N.Wgrad3x3Desc()
     g.x0, g.c0, g.up0, g.x1, g.c1 = lod.data_ptr(), c0, 1, skd.data_ptr(), c1
     g.dy, g.dw = dyd.data_ptr(), dw.data_ptr()
@@ -187,7 +188,8 @@ def test_first_layer_c1(dtype):
     b = rng.standard_normal(co).astype(np.float32)
     xd = up(x, dtype)
     y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
-    N.call('rvip_conv3x3_c1_fwd', P(xd), P(f32(wt)), P(f32(b)), P(y), n, h, w, co, N.ACT['elu'], ndt(dtype), stream())
+    wtd, bd = f32(wt), f32(b)                 # keep device operands alive across the async launch
+    N.call('rvip_conv3x3_c1_fwd', P(xd), P(wtd), P(bd), P(y), n, h, w, co, N.ACT['elu'], ndt(dtype), stream())
     ref = O.act_fwd(O.conv2d_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), 'elu')
     close(down(y), ref, dtype, 'c1 fwd')
     dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
@@ -195,7 +197,8 @@ def test_first_layer_c1(dtype):
     wsb = L.rvip_reduce_workspace(n * h * w, 16 * co)
     ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
     dw = torch.empty((3, 3, 1, co), dtype=torch.float32, device=dev())
-    N.call('rvip_conv3x3_c1_wgrad', P(xd), P(up(dy, dtype)), P(dw), n, h, w, co, ndt(dtype), P(ws), C.c_size_t(wsb), stream())
+    dyd = up(dy, dtype)
+    N.call('rvip_conv3x3_c1_wgrad', P(xd), P(dyd), P(dw), n, h, w, co, ndt(dtype), P(ws), C.c_size_t(wsb), stream())
     _, rdw, _ = O.conv2d_same_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64))
     assert np.abs(down(dw) - rdw).max() <= 2e-5 * np.abs(rdw).max()
 
@@ -254,7 +257,8 @@ def test_batchnorm_dropout_pool_forward_backward(dtype, act_after):
     dp = rnd(rng.standard_normal((n, h // 2, w // 2, c)), dtype)
     addg = rnd(rng.standard_normal((n, h, w, c)), dtype)
     gy = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
-    N.call('rvip_maxpool2x2_bwd', P(y), P(up(dp, dtype)), P(up(addg, dtype)), P(gy), n, h, w, c, ndt(dtype), stream())
+    dpd, addd = up(dp, dtype), up(addg, dtype)
+    N.call('rvip_maxpool2x2_bwd', P(y), P(dpd), P(addd), P(gy), n, h, w, c, ndt(dtype), stream())
     gref = O.maxpool2x2_bwd(dp.astype(np.float64), idx, yq.shape) + addg
     close(down(gy), gref, dtype, 'maxpool bwd')
     g_in = rnd(down(gy), dtype).astype(np.float64)                      # what the BN backward kernels read
@@ -371,10 +375,12 @@ def test_adam_state_and_convert():
         rt, rm, rv = O.adam_step(rt, g.astype(np.float64), rm, rv, t, 1e-3)
     assert int(state[0].item()) == 3
     np.testing.assert_allclose(down(thd), rt, atol=2e-6)
-    np.testing.assert_allclose(down(vd), rv, rtol=1e-5, atol=1e-9)
+    # (1 - beta2) is formed in fp32 on the device (as in TF): 1.f - 0.999f differs from 1e-3 by 1.3e-5 relative
+    np.testing.assert_allclose(down(vd), rv, rtol=5e-5, atol=1e-9)
     a = rng.standard_normal(1000).astype(np.float32)
     bd = torch.empty(1000, dtype=torch.bfloat16, device=dev())
-    N.call('rvip_convert', P(f32(a)), N.F32, P(bd), N.BF16, C.c_longlong(1000), stream())
+    ad = f32(a)
+    N.call('rvip_convert', P(ad), N.F32, P(bd), N.BF16, C.c_longlong(1000), stream())
     torch.cuda.synchronize()
     assert torch.equal(bd.cpu(), torch.from_numpy(a).to(torch.bfloat16))     # RNE like torch
 
