@@ -27,7 +27,7 @@ static inline bool red_geom(long long rows, int c, int ve, RedGeom& g) {
     if (g.cg > 256) return false;
     g.rpi = 256 / g.cg;
     long long nb = cdiv(rows, (long long)g.rpi * 8);
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
     long long ch = cdiv(rows, nb);
     ch = cdiv(ch, g.rpi) * g.rpi;
@@ -56,17 +56,30 @@ __device__ __forceinline__ void block_fold(const float (&part)[K][VE], bool acti
     }
 }
 
-// stage 2: totals[k] for channel ch = sum over workspace rows, then Post::run(ch, totals)
+// stage 2: totals[k] for channel ch = sum over workspace rows, then Post::run(ch, totals).
+// 512 threads = 32 channels x 16 row groups; every thread keeps 4 loads in flight (the loop is latency-bound).
+#define RVIP_FOLD_GROUPS 16
 template <int K, typename Post>
-__global__ __launch_bounds__(256) void fold_finalize(const float* __restrict__ ws, int nblk, int width, Post post) {
-    __shared__ double sh[8][K][32];
+__global__ __launch_bounds__(512) void fold_finalize(const float* __restrict__ ws, int nblk, int width, Post post) {
+    __shared__ double sh[RVIP_FOLD_GROUPS][K][32];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int ch = blockIdx.x * 32 + c;
     double s[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = 0.0;
     if (ch < width) {
-        for (int b = g; b < nblk; b += 8) {
+        int b = g;
+        for (; b + 3 * RVIP_FOLD_GROUPS < nblk; b += 4 * RVIP_FOLD_GROUPS) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float v0 = ws[((size_t)b * K + k) * width + ch];
+                const float v1 = ws[((size_t)(b + RVIP_FOLD_GROUPS) * K + k) * width + ch];
+                const float v2 = ws[((size_t)(b + 2 * RVIP_FOLD_GROUPS) * K + k) * width + ch];
+                const float v3 = ws[((size_t)(b + 3 * RVIP_FOLD_GROUPS) * K + k) * width + ch];
+                s[k] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+            }
+        }
+        for (; b < nblk; b += RVIP_FOLD_GROUPS) {
 #pragma unroll
             for (int k = 0; k < K; ++k) s[k] += (double)ws[((size_t)b * K + k) * width + ch];
         }
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(256) void fold_finalize(const float* __restrict__ w
         for (int k = 0; k < K; ++k) {
             double acc = 0.0;
 #pragma unroll
-            for (int gg = 0; gg < 8; ++gg) acc += sh[gg][k][c];
+            for (int gg = 0; gg < RVIP_FOLD_GROUPS; ++gg) acc += sh[gg][k][c];
             t[k] = acc;
         }
         post.run(ch, t);
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256) void fold_finalize(const float* __restrict__ w
 
 template <int K, typename Post>
 static int launch_fold(const float* ws, int nblk, int width, Post post, hipStream_t s) {
-    hipLaunchKernelGGL((fold_finalize<K, Post>), dim3((unsigned)cdiv(width, 32)), dim3(256), 0, s, ws, nblk, width, post);
+    hipLaunchKernelGGL((fold_finalize<K, Post>), dim3((unsigned)cdiv(width, 32)), dim3(32 * RVIP_FOLD_GROUPS), 0, s, ws, nblk, width, post);
     return check_launch();
 }
 

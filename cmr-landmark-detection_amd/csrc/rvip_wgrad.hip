@@ -159,12 +159,31 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(WgArgs a) {
     }
 }
 
-__global__ void wgrad_fold_kernel(const float* __restrict__ slab, int nsplit, long long count, float* __restrict__ dw) {
-    const long long i = blockIdx.x * 256LL + threadIdx.x;
-    if (i >= count) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * count + i];
-    dw[i] = s;
+// dw[i] = sum_k slab[k][i] in split order.  256 threads = 32 elements x 8 split groups so that small kernels
+// (9*32*32 elements, hundreds of splits) still fill the chip; fixed summation order -> reproducible.
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ slab, int nsplit, long long count, float* __restrict__ dw) {
+    __shared__ float sh[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long i = blockIdx.x * 32LL + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < count) {
+        int k = g;
+        for (; k + 24 < nsplit; k += 32) {
+            s0 += slab[(size_t)k * count + i];
+            s1 += slab[(size_t)(k + 8) * count + i];
+            s2 += slab[(size_t)(k + 16) * count + i];
+            s3 += slab[(size_t)(k + 24) * count + i];
+        }
+        for (; k < nsplit; k += 8) s0 += slab[(size_t)k * count + i];
+    }
+    sh[g][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) t += sh[gg][e];
+        dw[i] = t;
+    }
 }
 
 static void wgrad_geometry(int n, int h, int w, int cin, int cout, int& tw, int& tiles_x, int& tiles_y, int& ntiles, int& nsplit) {
@@ -174,7 +193,7 @@ static void wgrad_geometry(int n, int h, int w, int cin, int cout, int& tw, int&
     tiles_y = (int)cdiv(h, th);
     ntiles = n * tiles_x * tiles_y;
     const long long pairs = cdiv(cin, 32) * cdiv(cout, 32);
-    long long s = 1024 / pairs;
+    long long s = 512 / pairs;                 // ~2 workgroups per CU in total
     if (s < 1) s = 1;
     if (s > ntiles) s = ntiles;
     nsplit = (int)s;
@@ -233,6 +252,6 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     else rc = tw == 32 ? launch_wgrad<float, 32>(a, s) : launch_wgrad<float, 16>(a, s);
     if (rc) return rc;
     const long long count = 9LL * a.cin * a.cout;
-    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(count, 256)), dim3(256), 0, s, a.slab, a.nsplit, count, d->dw);
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(count, 32)), dim3(256), 0, s, a.slab, a.nsplit, count, d->dw);
     return check_launch();
 }
