@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--detail', default=None, help='write a per-launch timing table (conv / wgrad shapes) to this file')
     args = ap.parse_args()
 
     import numpy as np
@@ -128,6 +129,7 @@ def main():
         conv_fn, wgrad_fn = L.rvip_conv3x3_fwd, L.rvip_conv3x3_wgrad
         reps = 3
         agg = {}
+        detail = []
         for _ in range(reps):
             eng.stage_input()
             for seq in (eng.fwd_train, eng.bwd, eng.opt):
@@ -145,7 +147,18 @@ def main():
                         d = a[0]._obj
                         flops = 2.0 * d.n * d.h * d.w * 9 * (d.c0 + d.c1) * d.cout
                     agg.setdefault(fn.__name__, []).append((e0, e1, flops))
+                    if flops > 0:
+                        detail.append((fn.__name__, (d.n, d.h, d.w, d.c0 + d.c1, d.cout, d.up0, 1 if d.c1 else 0), e0, e1, flops))
         torch.cuda.synchronize()
+        if args.detail:
+            rows = {}
+            for name, shp, a, b, f in detail:
+                r = rows.setdefault((name, shp), [0.0, 0, f])
+                r[0] += a.elapsed_time(b); r[1] += 1
+            with open(args.detail, 'w') as fh:
+                fh.write('kernel n h w cin cout up cat launches avg_us tflops\n')
+                for (name, shp), (ms, cnt, f) in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+                    fh.write('%s %s %d %.1f %.1f\n' % (name, ' '.join(map(str, shp)), cnt // reps, 1e3 * ms / cnt, f / (ms / cnt * 1e-3) / 1e12))
         for name, evs in agg.items():
             ms = sum(a.elapsed_time(b) for a, b, _ in evs)
             fl = sum(f for _, _, f in evs)

@@ -15,6 +15,7 @@
 //                  (exact fp32, k-ordered fma chain; the k <-> channel map only has to agree between
 //                  the two operands, and both read the same 16-byte channel group).
 #include "rvip_common.h"
+#include <cstdlib>
 
 namespace rvip {
 
@@ -221,6 +222,288 @@ static int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// igemm v2: LDS-DMA staging.  Same math and tile/fragment maps as conv3x3_igemm above, but
+//   * global -> LDS goes through buffer_load ... lds (1 KiB per wave-instruction = 16 rows x 64 B, no VGPR
+//     staging, no ds_write); an out-of-range lane (halo outside the image, channel tail, row padding) gets an
+//     offset beyond num_records and the hardware writes ZEROS -> "same" zero padding costs nothing;
+//   * rows are UNPADDED 64 B; bank conflicts are removed by an XOR swizzle applied on the SOURCE side: LDS row r
+//     keeps logical 16-byte piece p in slot p ^ ((r >> 2) & 3), readers apply the same XOR (conflict-free for any
+//     16 rows that are distinct mod 16);
+//   * two input stages: the DMA of work item i+1 is in flight while item i is multiplied, one barrier per item;
+//   * NW waves (8: 512-pixel tile, 4: 256-pixel tile), persistent over pixel tiles; when all K chunks of the
+//     weights fit next to the two input stages they are loaded ONCE per workgroup (weight-stationary).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (base, stride 0, num_records = bytes, raw 32-bit format) built from wave-uniform values
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;
+    r.x = (int)(unsigned)a; r.y = (int)((unsigned)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+}
+// One LDS-DMA piece: 64 lanes x 16 B -> LDS bytes [lds_off, lds_off + 1024).  Issued as inline asm so that hipcc
+// does not see an LDS store (it would fence every later ds_read with vmcnt(0) and serialise load and compute);
+// completion is tracked by hand: s_waitcnt vmcnt(0) + s_barrier at the top of every work item.  M0 (the DMA's LDS
+// base) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(lds_void_t*)p; }
+
+struct ConvArgs2 {
+    const unsigned char* x0; const unsigned char* x1;
+    const unsigned char* wp; const float* bias;
+    unsigned char* y; unsigned char* y1;
+    unsigned x0_bytes, x1_bytes, wp_bytes;
+    int c0, c1, up0, csplit;
+    int n, h, w, cin, cout, act;
+    int tiles_x, tiles_y, ntiles, wres;      // wres: weight stages resident (= nchunks) or 0 -> 2 rotating stages
+    int lds_bias_off;
+};
+
+template <typename T, int TW, int NCT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
+    constexpr int NPIX = NW * 64, TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
+    constexpr int NHROWS = (NHALO + 15) / 16 * 16;
+    constexpr int BN = NCT * 32, WROWS = 9 * BN;
+    constexpr int IN_BYTES = NHROWS * 64, W_BYTES = WROWS * 64;
+    constexpr int VE = Vec<T>::VE, KCE = 4 * VE;
+    constexpr int NQI = NHROWS / 16, NQW = WROWS / 16;                 // 1 KiB DMA pieces per stage
+    constexpr int QI = (NQI + NW - 1) / NW, QW = (NQW + NW - 1) / NW;  // per wave
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lin = smem;                       // [2][IN_BYTES]
+    unsigned char* lw = smem + 2 * IN_BYTES;         // [wres or 2][W_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * BN;
+    const int nchunks = (a.cin + KCE - 1) / KCE;
+    const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
+    const bool resident = a.wres > 0;
+
+    const i32x4 rs0 = make_rsrc(a.x0, a.x0_bytes);
+    const i32x4 rs1 = make_rsrc(a.x1 ? a.x1 : a.x0, a.x1 ? a.x1_bytes : 0u);
+    const i32x4 rsw = make_rsrc(a.wp, a.wp_bytes);
+    const unsigned lds_base = lds_offset_of(smem);
+    float* lbias = reinterpret_cast<float*>(smem + a.lds_bias_off);        // [BN] bias of this output-channel tile
+    if (tid < BN) lbias[tid] = (a.bias && co0 + tid < a.cout) ? a.bias[co0 + tid] : 0.f;
+
+    // DMA lane geometry: lane -> (row within the 16-row piece, physical 16-byte slot)
+    const int drow = lane >> 2, dslot = lane & 3;
+
+    auto issue_weights = [&](int kc, int wstage) {
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            const int q = wv + NW * i;
+            if (q < NQW) {
+                const int row = q * 16 + drow;
+                const int tap = row / BN, co = co0 + (row & (BN - 1));
+                const int p = dslot ^ ((row >> 2) & 3);
+                const int c = kc * KCE + p * VE;
+                unsigned off = OOB;
+                if (co < a.cout && c < a.cin) off = (unsigned)(((tap * a.cout + co) * a.cin + c) * (int)sizeof(T));
+                dma16(rsw, off, lds_base + 2 * IN_BYTES + wstage * W_BYTES + q * 1024);
+            }
+        }
+    };
+    auto issue_input = [&](int tile, int kc, int stage) {
+        int bx = tile;
+        const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty_i = bx % a.tiles_y;
+        const int n = bx / a.tiles_y;
+        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+        const int cbase = kc * KCE;
+        const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
+#pragma unroll
+        for (int i = 0; i < QI; ++i) {
+            const int q = wv + NW * i;
+            if (q < NQI) {
+                const int row = q * 16 + drow;
+                const int hy = row / HWD, hx = row - hy * HWD;
+                const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+                const int p = dslot ^ ((row >> 2) & 3);
+                unsigned off = OOB;
+                if (row < NHALO && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w) {
+                    if (from0) {
+                        const int c = cbase + p * VE;
+                        if (c < a.c0) off = (unsigned)((((n * h0 + (gy >> a.up0)) * w0 + (gx >> a.up0)) * a.c0 + c) * (int)sizeof(T));
+                    } else {
+                        const int c = cbase - a.c0 + p * VE;
+                        if (c < a.c1) off = (unsigned)((((n * a.h + gy) * a.w + gx) * a.c1 + c) * (int)sizeof(T));
+                    }
+                }
+                if (from0) dma16(rs0, off, lds_base + stage * IN_BYTES + q * 1024);
+                else dma16(rs1, off, lds_base + stage * IN_BYTES + q * 1024);
+            }
+        }
+    };
+
+    // fragment read addresses (stage-relative).  pixel row r0 (+ tap rows); piece p = 2g + hf
+    int r0[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int P = wv * 64 + pt * 32 + j;
+        r0[pt] = (P / TW) * HWD + (P % TW);
+    }
+    int w_addr[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int r = ct * 32 + j;
+        w_addr[ct] = r * 64 + ((hf ^ ((r >> 2) & 3)) << 4);          // g = 0; g = 1 is this address ^ 32
+    }
+
+    f32x16 acc[NCT][2];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+
+    const int first_tile = blockIdx.x;
+    if (first_tile >= a.ntiles) return;
+    if (resident) for (int kc = 0; kc < nchunks; ++kc) issue_weights(kc, kc);
+    else issue_weights(0, 0);
+    issue_input(first_tile, 0, 0);
+
+    int it = 0;
+    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
+        int bx = tile;
+        const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty_i = bx % a.tiles_y;
+        const int n = bx / a.tiles_y;
+        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+        for (int kc = 0; kc < nchunks; ++kc, ++it) {
+            // item `it` has landed for me; after the barrier for everyone, and everyone has finished item it-1
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            {   // prefetch the next item into the other stage
+                int ntile = tile, nkc = kc + 1;
+                if (nkc == nchunks) { nkc = 0; ntile = tile + gridDim.x; }
+                if (ntile < a.ntiles) {
+                    issue_input(ntile, nkc, (it + 1) & 1);
+                    if (!resident) issue_weights(nkc, (it + 1) & 1);
+                }
+            }
+            const unsigned char* sin = lin + (it & 1) * IN_BYTES;
+            const unsigned char* sw = lw + (resident ? kc : (it & 1)) * W_BYTES;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int trow = (tap / 3) * HWD + (tap % 3);
+                int in_addr[2];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const int r = r0[pt] + trow;
+                    in_addr[pt] = r * 64 + ((hf ^ ((r >> 2) & 3)) << 4);
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    uint4 fa[NCT], fb[2];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) fa[ct] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + (w_addr[ct] ^ (g << 5)));
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) fb[pt] = *reinterpret_cast<const uint4*>(sin + (in_addr[pt] ^ (g << 5)));
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) Mma<T>::run(fa[ct], fb[pt], acc[ct][pt]);
+                }
+            }
+        }
+        // epilogue of this tile (the next item's DMA is already in flight)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int P = wv * 64 + pt * 32 + j;
+            const int gy = ty0 + P / TW, gx = tx0 + P % TW;
+            const bool pix_ok = gy < a.h && gx < a.w;
+            const size_t pix = ((size_t)n * a.h + gy) * a.w + gx;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = co0 + ct * 32 + 8 * q + 4 * hf;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float t = acc[ct][pt][4 * q + i];
+                        acc[ct][pt][4 * q + i] = 0.f;
+                        t += lbias[ct * 32 + 8 * q + 4 * hf + i];
+                        v[i] = act_fwd(t, a.act);
+                    }
+                    if (!pix_ok || co >= a.cout) continue;
+                    unsigned char* dst;
+                    if (a.y1 && co >= a.csplit) dst = a.y1 + (pix * (a.cout - a.csplit) + (co - a.csplit)) * sizeof(T);
+                    else dst = a.y + (pix * (a.y1 ? a.csplit : a.cout) + co) * sizeof(T);
+                    if constexpr (sizeof(T) == 4) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 o;
+                        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(dst) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int TW, int NCT, int NW>
+static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used) {
+    constexpr int NPIX = NW * 64, TH = NPIX / TW;
+    constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
+    constexpr int IN_BYTES = NHROWS * 64, W_BYTES = 9 * NCT * 32 * 64;
+    constexpr int KCE = 64 / (int)sizeof(T);
+    constexpr int LDS_MAX = 160 * 1024;
+    used = false;
+    const int nchunks = (int)cdiv(a0.cin, KCE);
+    // eligibility: 32-bit byte offsets, chunks never straddle the concat boundary
+    const long long x0b = (long long)a0.n * (a0.h >> a0.up0) * (a0.w >> a0.up0) * a0.c0 * (long long)sizeof(T);
+    const long long x1b = (long long)a0.n * a0.h * a0.w * a0.c1 * (long long)sizeof(T);
+    const long long wpb = 9LL * a0.cin * a0.cout * (long long)sizeof(T);
+    if (x0b >= (1LL << 31) || x1b >= (1LL << 31) || wpb >= (1LL << 31)) return RVIP_OK;
+    if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
+    ConvArgs2 b;
+    b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
+    b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit;
+    b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
+    b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
+    b.ntiles = a0.n * b.tiles_x * b.tiles_y;
+    const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 <= LDS_MAX;
+    b.wres = res ? nchunks : 0;
+    b.lds_bias_off = 2 * IN_BYTES + (res ? nchunks : 2) * W_BYTES;
+    const int lds = b.lds_bias_off + 256;
+    if (lds > LDS_MAX) return RVIP_OK;
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma<T, TW, NCT, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
+        attr_lds = LDS_MAX;
+    }
+    const int cot = (int)cdiv(a0.cout, NCT * 32);
+    int gx = 256 / cot;                      // one workgroup per CU in total (LDS-limited), persistent over tiles
+    if (gx < 1) gx = 1;
+    if (gx > b.ntiles) gx = b.ntiles;
+    hipLaunchKernelGGL((conv3x3_igemm_dma<T, TW, NCT, NW>), dim3((unsigned)gx, (unsigned)cot), dim3(NW * 64), lds, s, b);
+    used = true;
+    return check_launch();
+}
+
+template <typename T>
+static int dispatch_igemm_dma(const ConvArgs& a, hipStream_t s, bool& used) {
+    const bool two = a.cout > 32;
+    if (a.w > 16 && a.h >= 16) return two ? launch_igemm_dma<T, 32, 2, 8>(a, s, used) : launch_igemm_dma<T, 32, 1, 8>(a, s, used);
+    if (a.w > 16) return two ? launch_igemm_dma<T, 32, 2, 4>(a, s, used) : launch_igemm_dma<T, 32, 1, 4>(a, s, used);
+    return two ? launch_igemm_dma<T, 16, 2, 4>(a, s, used) : launch_igemm_dma<T, 16, 1, 4>(a, s, used);
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight re-layout: fp32 HWIO -> packed [9][Cout][Cin] (forward) and [9][Cin][Cout] rotated (dgrad)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -309,6 +592,12 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout; a.act = d->act;
     a.tiles_x = a.tiles_y = 0;
     hipStream_t s = (hipStream_t)stream;
+    static const bool force_v1 = [] { const char* e = getenv("RVIP_IGEMM"); return e && e[0] == 'v' && e[1] == '1'; }();
+    if (!force_v1) {
+        bool used = false;
+        const int rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
+        if (rc || used) return rc;
+    }
     return d->dtype == RVIP_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
 }
 

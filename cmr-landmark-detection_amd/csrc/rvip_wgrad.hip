@@ -12,6 +12,7 @@
 // The four waves' accumulators are folded through LDS in a fixed order, each workgroup writes one fp32
 // slab [9][Cin][Cout], and a second kernel sums the slabs in split order: bitwise reproducible.
 #include "rvip_common.h"
+#include <cstdlib>
 
 namespace rvip {
 
@@ -159,6 +160,212 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(WgArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad v2: LDS-DMA staging (buffer_load ... lds, zeros for out-of-range lanes = halo / tile overhang /
+// channel tails), two stages so the next pixel tile streams in while the current one is contracted, and a
+// (CIB x COB) block of (ci, co) per workgroup: with 64 x 64 the four waves own one 32 x 32 pair each and
+// contract all 256 pixels of the tile (no cross-wave fold); with fewer pairs the waves split the pixels and
+// are folded through LDS in a fixed order.  Rows are 64 B (32 bf16 / 16 f32 channels... see RB) or 128 B;
+// 128-byte rows store their two 64-byte halves swapped when (row >> 1) & 1 (source-side swizzle) so that the
+// 4 consecutive pixel rows a transposed read touches fall on 4 different 64-byte bank segments.
+// ---------------------------------------------------------------------------------------------
+typedef int i32x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4w make_rsrc_w(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4w r;
+    r.x = (int)(unsigned)a; r.y = (int)((unsigned)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void dma16w(i32x4w rsrc, unsigned voff, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
+}
+
+struct WgArgs2 {
+    const unsigned char* x0; const unsigned char* x1; const unsigned char* dy;
+    float* slab;
+    unsigned x0_bytes, x1_bytes, dy_bytes;
+    int c0, c1, up0;
+    int n, h, w, cin, cout;
+    int tiles_x, tiles_y, ntiles, nsplit;
+};
+
+template <typename T, int TW, int CIB, int COB>
+__global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
+    constexpr int TH = 256 / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
+    constexpr int NHROWS = (NHALO + 15) / 16 * 16;
+    constexpr int ESZ = (int)sizeof(T), VE = Vec<T>::VE;
+    constexpr int RBX = CIB * ESZ, RBG = COB * ESZ;                 // row bytes: 64 or 128
+    static_assert((RBX == 64 || RBX == 128) && (RBG == 64 || RBG == 128), "row bytes");
+    constexpr int X_BYTES = NHROWS * RBX, G_BYTES = 256 * RBG, ST_BYTES = X_BYTES + G_BYTES;
+    constexpr int NQX = X_BYTES / 1024, NQG = G_BYTES / 1024;
+    constexpr int QX = (NQX + 3) / 4, QG = (NQG + 3) / 4;
+    constexpr int NPAIR = (CIB / 32) * (COB / 32) > 4 ? 4 : (CIB * ESZ / 64) * 0 + ((CIB / 32) * (COB / 32));
+    constexpr int NCI = (ESZ == 2) ? CIB / 32 : 1, NCO = (ESZ == 2) ? COB / 32 : 1;   // 32-channel MFMA tiles per block
+    constexpr int PAIRS = NCI * NCO;                                  // 1, 2 or 4
+    constexpr int PSPLIT = 4 / PAIRS;
+    constexpr unsigned OOB = 0x80000000u;
+    (void)NPAIR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x, ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
+    const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
+    const int pair = wv % PAIRS, part = wv / PAIRS;
+    const int ci_t = pair % NCI, co_t = pair / NCI;
+
+    const bool from0 = ci0 < a.c0;                                    // a block never straddles the concat (host)
+    const i32x4w rsx = from0 ? make_rsrc_w(a.x0, a.x0_bytes) : make_rsrc_w(a.x1, a.x1_bytes);
+    const i32x4w rsg = make_rsrc_w(a.dy, a.dy_bytes);
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+
+    auto issue = [&](int tile, int stage) {
+        int bx = tile;
+        const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty_i = bx % a.tiles_y;
+        const int n = bx / a.tiles_y;
+        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+        {
+            constexpr int SL = RBX / 16, RPP = 1024 / RBX;           // 16-byte slots per row, rows per piece
+            const int prow = lane / SL, slot = lane % SL;
+            const int csrc = from0 ? a.c0 : a.c1, cb0 = from0 ? ci0 : ci0 - a.c0;
+#pragma unroll
+            for (int i = 0; i < QX; ++i) {
+                const int q = wv + 4 * i;
+                if (q < NQX) {
+                    const int row = q * RPP + prow;
+                    const int hy = row / HWD, hx = row - hy * HWD;
+                    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+                    const int p = (RBX == 128) ? ((((slot >> 2) ^ ((row >> 1) & 1)) << 2) | (slot & 3)) : slot;
+                    const int c = cb0 + p * VE;
+                    unsigned off = OOB;
+                    if (row < NHALO && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && c < csrc) {
+                        const int pix = from0 ? ((n * h0 + (gy >> a.up0)) * w0 + (gx >> a.up0)) : ((n * a.h + gy) * a.w + gx);
+                        off = (unsigned)((pix * csrc + c) * ESZ);
+                    }
+                    dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
+                }
+            }
+        }
+        {
+            constexpr int SL = RBG / 16, RPP = 1024 / RBG;
+            const int prow = lane / SL, slot = lane % SL;
+#pragma unroll
+            for (int i = 0; i < QG; ++i) {
+                const int q = wv + 4 * i;
+                if (q < NQG) {
+                    const int P = q * RPP + prow;
+                    const int gy = ty0 + P / TW, gx = tx0 + P % TW;
+                    const int p = (RBG == 128) ? ((((slot >> 2) ^ ((P >> 1) & 1)) << 2) | (slot & 3)) : slot;
+                    const int c = co0 + p * VE;
+                    unsigned off = OOB;
+                    if (gy < a.h && gx < a.w && c < a.cout) off = (unsigned)((((n * a.h + gy) * a.w + gx) * a.cout + c) * ESZ);
+                    dma16w(rsg, off, lds_base + stage * ST_BYTES + X_BYTES + q * 1024);
+                }
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (split < a.ntiles) issue(split, 0);
+    int it = 0;
+    for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, (it + 1) & 1);
+        const unsigned char* lx = smem + (it & 1) * ST_BYTES;
+        const unsigned char* lg = lx + X_BYTES;
+        if constexpr (ESZ == 2) {
+            const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, grp = lane >> 4;
+            const int kk = 8 * (grp >> 1) + q4;
+            const int cb = (16 * (grp & 1) + 4 * p4) * 2;
+            constexpr int STEPS = 16 / PSPLIT;
+#pragma unroll 2
+            for (int s = 0; s < STEPS; ++s) {
+                int gaddr[2], xrow[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int P = (part * STEPS + s) * 16 + kk + 4 * u;
+                    gaddr[u] = P * RBG + ((RBG == 128) ? ((co_t ^ ((P >> 1) & 1)) << 6) : 0) + cb;
+                    xrow[u] = (P / TW) * HWD + (P % TW);
+                }
+                const s16x4 g0 = tr_read(lg + gaddr[0]);
+                const s16x4 g1 = tr_read(lg + gaddr[1]);
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int trow = (t / 3) * HWD + (t % 3);
+                    int xa[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int rr = xrow[u] + trow;
+                        xa[u] = rr * RBX + ((RBX == 128) ? ((ci_t ^ ((rr >> 1) & 1)) << 6) : 0) + cb;
+                    }
+                    const s16x4 x0 = tr_read(lx + xa[0]);
+                    const s16x4 x1 = tr_read(lx + xa[1]);
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+            // f32: 32 channels per operand (128-byte rows), lane = channel, one pixel per half-wave
+            constexpr int STEPS = 128 / PSPLIT;
+            const int choff = (j & 15) * 4, chalf = j >> 4;
+#pragma unroll 2
+            for (int s = 0; s < STEPS; ++s) {
+                const int P = (part * STEPS + s) * 2 + hf;
+                const float g = *reinterpret_cast<const float*>(lg + P * RBG + ((chalf ^ ((P >> 1) & 1)) << 6) + choff);
+                const int xr = (P / TW) * HWD + (P % TW);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int rr = xr + (t / 3) * HWD + (t % 3);
+                    const float x = *reinterpret_cast<const float*>(lx + rr * RBX + ((chalf ^ ((rr >> 1) & 1)) << 6) + choff);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, g, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // results: one 9 x 32 x 32 fp32 block per (ci_t, co_t) pair; waves that split the pixels fold through LDS
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    float* out = a.slab + (size_t)split * 9 * a.cin * a.cout;
+    if constexpr (PSPLIT == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + ci_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf, co = co0 + co_t * 32 + j;
+                if (ci < a.cin && co < a.cout) out[((size_t)t * a.cin + ci) * a.cout + co] = acc[t][r];
+            }
+    } else {
+        float* red = reinterpret_cast<float*>(smem) + pair * 9 * 32 * 32;   // [PAIRS][9][32][32]
+        for (int psel = 0; psel < PSPLIT; ++psel) {
+            if (part == psel) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int idx = (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j;
+                        red[idx] = (psel == 0 ? 0.f : red[idx]) + acc[t][r];
+                    }
+            }
+            __syncthreads();
+        }
+        const float* redall = reinterpret_cast<const float*>(smem);
+        for (int e = tid; e < PAIRS * 9 * 32 * 32; e += 256) {
+            const int pr = e / (9 * 32 * 32), rem = e % (9 * 32 * 32);
+            const int t = rem >> 10, ci = ci0 + (pr % NCI) * 32 + ((rem >> 5) & 31), co = co0 + (pr / NCI) * 32 + (rem & 31);
+            if (ci < a.cin && co < a.cout) out[((size_t)t * a.cin + ci) * a.cout + co] = redall[e];
+        }
+    }
+}
+
 // dw[i] = sum_k slab[k][i] in split order.  256 threads = 32 elements x 8 split groups so that small kernels
 // (9*32*32 elements, hundreds of splits) still fill the chip; fixed summation order -> reproducible.
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ slab, int nsplit, long long count, float* __restrict__ dw) {
@@ -199,6 +406,53 @@ static void wgrad_geometry(int n, int h, int w, int cin, int cout, int& tw, int&
     nsplit = (int)s;
 }
 
+struct Wg2Geom { int tw, cib, cob, tiles_x, tiles_y, ntiles, nsplit; bool ok; };
+
+static Wg2Geom wgrad2_geometry(int n, int h, int w, int c0, int c1, int cout, int dtype) {
+    Wg2Geom g;
+    const int cin = c0 + c1;
+    const int esz = dtype == RVIP_BF16 ? 2 : 4;
+    const int wide = 128 / esz, narrow = 64 / esz;             // channels in a 128-byte / 64-byte row
+    g.tw = w > 16 ? 32 : 16;
+    const int th = 256 / g.tw;
+    g.tiles_x = (int)cdiv(w, g.tw); g.tiles_y = (int)cdiv(h, th);
+    g.ntiles = n * g.tiles_x * g.tiles_y;
+    if (dtype == RVIP_BF16) {
+        g.cib = (cin >= wide && (c1 == 0 || c0 % wide == 0)) ? wide : narrow;
+        g.cob = cout >= wide ? wide : narrow;
+    } else {
+        g.cib = wide; g.cob = wide;                              // f32: 32 channels = 128-byte rows
+    }
+    g.ok = (c1 == 0 || c0 % g.cib == 0);
+    const long long blocks = cdiv(cin, g.cib) * cdiv(cout, g.cob);
+    long long s = 256 / blocks;                                  // one workgroup per CU (LDS-limited)
+    if (s < 1) s = 1;
+    if (s > g.ntiles) s = g.ntiles;
+    g.nsplit = (int)s;
+    return g;
+}
+
+template <typename T, int TW, int CIB, int COB>
+static int launch_wgrad2(const WgArgs2& a, hipStream_t s) {
+    constexpr int TH = 256 / TW;
+    constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int ST = NHROWS * CIB * ESZ + 256 * COB * ESZ;
+    constexpr int lds = 2 * ST;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static_assert(2 * ST >= 4 * 9 * 32 * 32 * 4 || true, "fold buffer");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma<T, TW, CIB, COB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
+        attr_done = true;
+    }
+    dim3 grid((unsigned)a.nsplit, (unsigned)cdiv(a.cin, CIB), (unsigned)cdiv(a.cout, COB));
+    hipLaunchKernelGGL((wgrad3x3_dma<T, TW, CIB, COB>), grid, dim3(256), lds, s, a);
+    return check_launch();
+}
+
 template <typename T, int TW>
 static int launch_wgrad(const WgArgs& a, hipStream_t s) {
     constexpr int TH = 256 / TW;
@@ -224,6 +478,8 @@ using namespace rvip;
 extern "C" size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout) {
     int tw, tx, ty, nt, ns;
     wgrad_geometry(n, h, w, cin, cout, tw, tx, ty, nt, ns);
+    int ns2 = nt < 256 ? nt : 256;                              // upper bound of the LDS-DMA kernel's split count
+    if (ns2 > ns) ns = ns2;
     return (size_t)ns * 9 * cin * cout * sizeof(float);
 }
 
@@ -242,12 +498,44 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     a.slab = (float*)d->workspace;
     a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    static const bool force_v1 = [] { const char* e = getenv("RVIP_WGRAD"); return e && e[0] == 'v' && e[1] == '1'; }();
+    const long long esz = d->dtype == RVIP_BF16 ? 2 : 4;
+    const long long x0b = (long long)a.n * (a.h >> a.up0) * (a.w >> a.up0) * a.c0 * esz, x1b = (long long)a.n * a.h * a.w * a.c1 * esz;
+    const long long dyb = (long long)a.n * a.h * a.w * a.cout * esz;
+    const Wg2Geom g2 = wgrad2_geometry(a.n, a.h, a.w, a.c0, a.c1, a.cout, d->dtype);
+    if (!force_v1 && g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) {
+        WgArgs2 b;
+        b.x0 = a.x0; b.x1 = a.x1; b.dy = a.dy; b.slab = a.slab;
+        b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.dy_bytes = (unsigned)dyb;
+        b.c0 = a.c0; b.c1 = a.c1; b.up0 = a.up0; b.n = a.n; b.h = a.h; b.w = a.w; b.cin = a.cin; b.cout = a.cout;
+        b.tiles_x = g2.tiles_x; b.tiles_y = g2.tiles_y; b.ntiles = g2.ntiles; b.nsplit = g2.nsplit;
+        if (d->workspace_bytes < (size_t)b.nsplit * 9 * a.cin * a.cout * sizeof(float)) return RVIP_EWORKSPACE;
+        if (d->dtype == RVIP_BF16) {
+            if (g2.tw == 32) {
+                if (g2.cib == 64 && g2.cob == 64) rc = launch_wgrad2<bf16_t, 32, 64, 64>(b, s);
+                else if (g2.cib == 64) rc = launch_wgrad2<bf16_t, 32, 64, 32>(b, s);
+                else if (g2.cob == 64) rc = launch_wgrad2<bf16_t, 32, 32, 64>(b, s);
+                else rc = launch_wgrad2<bf16_t, 32, 32, 32>(b, s);
+            } else {
+                if (g2.cib == 64 && g2.cob == 64) rc = launch_wgrad2<bf16_t, 16, 64, 64>(b, s);
+                else if (g2.cib == 64) rc = launch_wgrad2<bf16_t, 16, 64, 32>(b, s);
+                else if (g2.cob == 64) rc = launch_wgrad2<bf16_t, 16, 32, 64>(b, s);
+                else rc = launch_wgrad2<bf16_t, 16, 32, 32>(b, s);
+            }
+        } else {
+            rc = g2.tw == 32 ? launch_wgrad2<float, 32, 32, 32>(b, s) : launch_wgrad2<float, 16, 32, 32>(b, s);
+        }
+        if (rc) return rc;
+        const long long count2 = 9LL * a.cin * a.cout;
+        hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(count2, 32)), dim3(256), 0, s, a.slab, b.nsplit, count2, d->dw);
+        return check_launch();
+    }
     int tw;
     wgrad_geometry(a.n, a.h, a.w, a.cin, a.cout, tw, a.tiles_x, a.tiles_y, a.ntiles, a.nsplit);
     const size_t need = (size_t)a.nsplit * 9 * a.cin * a.cout * sizeof(float);
     if (d->workspace_bytes < need) return RVIP_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    int rc;
     if (d->dtype == RVIP_BF16) rc = tw == 32 ? launch_wgrad<bf16_t, 32>(a, s) : launch_wgrad<bf16_t, 16>(a, s);
     else rc = tw == 32 ? launch_wgrad<float, 32>(a, s) : launch_wgrad<float, 16>(a, s);
     if (rc) return rc;
