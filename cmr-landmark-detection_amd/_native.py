@@ -35,6 +35,10 @@ class Conv3x3Desc(C.Structure):
                 ('act', C.c_int32), ('dtype', C.c_int32)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [('w_off', C.c_longlong), ('f_off', C.c_longlong), ('d_off', C.c_longlong), ('cin', C.c_int32), ('cout', C.c_int32)]
+
+
 class Wgrad3x3Desc(C.Structure):
     _fields_ = [('x0', vp), ('c0', C.c_int32), ('up0', C.c_int32),
                 ('x1', vp), ('c1', C.c_int32),
@@ -73,6 +77,7 @@ SIGNATURES = {
     'rvip_last_hip_error': (C.c_int, []),
     'rvip_conv3x3_fwd': (C.c_int, [C.POINTER(Conv3x3Desc), vp]),
     'rvip_pack_conv3x3_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    'rvip_pack_all_conv3x3_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_conv3x3_wgrad_workspace': (C.c_size_t, [C.c_int] * 5),
     'rvip_conv3x3_wgrad': (C.c_int, [C.POINTER(Wgrad3x3Desc), vp]),
     'rvip_conv3x3_c1_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -564,6 +564,81 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const T* __restrict__ x
     Vec<T>::store(y + ((size_t)p * cout + cv * VE) * sizeof(T), v);
 }
 
+// first layer, tiled form: the 8x32-pixel tile's 10x34 halo of the single input channel sits in LDS, a thread owns
+// one channel vector for good (its 9 x VE weights stay in registers) and walks pixels/tiles; a wave stores 1 KiB
+// of contiguous NHWC output per instruction.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_c1_tiled(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, unsigned char* y,
+                                                        int n, int h, int wd, int cout, int act, int tiles_x, int tiles_y) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float xs[10 * 34];
+    const int tid = threadIdx.x, cg = cout / VE, cv = tid % cg, ps = tid / cg, pps = 256 / cg;
+    float wr[9][VE], br[VE];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) wr[t][e] = w[t * cout + cv * VE + e];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) br[e] = bias ? bias[cv * VE + e] : 0.f;
+    const int ntiles = n * tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int bx = tile;
+        const int tx0 = (bx % tiles_x) * 32; bx /= tiles_x;
+        const int ty0 = (bx % tiles_y) * 8;
+        const long long img = bx / tiles_y;
+        __syncthreads();
+        for (int i = tid; i < 340; i += 256) {
+            const int gy = ty0 - 1 + i / 34, gx = tx0 - 1 + i % 34;
+            xs[i] = ((unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)wd) ? ld1<T>(x + (img * h + gy) * wd + gx) : 0.f;
+        }
+        __syncthreads();
+        for (int p = ps; p < 256; p += pps) {
+            const int py = p >> 5, px = p & 31;
+            const int gy = ty0 + py, gx = tx0 + px;
+            if (gy >= h || gx >= wd) continue;
+            float xin[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) xin[t] = xs[(py + t / 3) * 34 + px + t % 3];
+            float v[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                float acc = br[e];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = fmaf(xin[t], wr[t][e], acc);
+                v[e] = act_fwd(acc, act);
+            }
+            Vec<T>::store(y + ((((size_t)img * h + gy) * wd + gx) * cout + cv * VE) * sizeof(T), v);
+        }
+    }
+}
+
+// all 3x3 kernels of the model in ONE launch: table-driven re-layout (see pack_w_kernel)
+struct PackEntry { long long w_off; long long f_off; long long d_off; int cin, cout; };
+template <typename T>
+__global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__ theta, const PackEntry* __restrict__ tab,
+                                                       T* __restrict__ wf_base, T* __restrict__ wd_base) {
+    const PackEntry en = tab[blockIdx.y];
+    const float* w = theta + en.w_off;
+    T* wf = wf_base + en.f_off;
+    T* wd = wd_base + en.d_off;
+    const long long total = 9LL * en.cin * en.cout;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int o = (int)(i % en.cout);
+        const int ci = (int)((i / en.cout) % en.cin);
+        const int t = (int)(i / ((long long)en.cout * en.cin));
+        const float v = w[i];
+        if constexpr (sizeof(T) == 4) {
+            wf[((size_t)t * en.cout + o) * en.cin + ci] = v;
+            wd[((size_t)(8 - t) * en.cin + ci) * en.cout + o] = v;
+        } else {
+            const uint16_t b = f32_to_bf16(v);
+            wf[((size_t)t * en.cout + o) * en.cin + ci].bits = b;
+            wd[((size_t)(8 - t) * en.cin + ci) * en.cout + o].bits = b;
+        }
+    }
+}
+
 }  // namespace rvip
 
 using namespace rvip;
@@ -621,9 +696,33 @@ extern "C" int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* b
     if (cout <= 0 || cout % ve) return RVIP_EINVAL;
     const long long total = (long long)n * h * w_ * (cout / ve);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype != RVIP_BF16 && dtype != RVIP_F32) return RVIP_EINVAL;
+    if (256 % (cout / ve) == 0) {
+        const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
+        long long nt = (long long)n * tx * ty;
+        dim3 g2((unsigned)(nt < 2048 ? nt : 2048));
+        if (dtype == RVIP_BF16) hipLaunchKernelGGL(conv3x3_c1_tiled<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty);
+        else hipLaunchKernelGGL(conv3x3_c1_tiled<float>, g2, dim3(256), 0, s, (const float*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty);
+        return check_launch();
+    }
     dim3 grid((unsigned)cdiv(total, 256));
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(conv3x3_c1_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act);
     else if (dtype == RVIP_F32) hipLaunchKernelGGL(conv3x3_c1_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act);
+    else return RVIP_EINVAL;
+    return check_launch();
+}
+
+extern "C" int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
+                                             void* wf_base, void* wd_base, void* stream) {
+    (void)hipGetLastError();
+    if (!theta || !table || entries <= 0 || max_elems <= 0 || !wf_base || !wd_base) return RVIP_EINVAL;
+    long long nb = cdiv(max_elems, 256 * 4);
+    if (nb > 64) nb = 64;
+    if (nb < 1) nb = 1;
+    dim3 grid((unsigned)nb, (unsigned)entries);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(pack_all_kernel<bf16_t>, grid, dim3(256), 0, s, theta, (const PackEntry*)table, (bf16_t*)wf_base, (bf16_t*)wd_base);
+    else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_all_kernel<float>, grid, dim3(256), 0, s, theta, (const PackEntry*)table, (float*)wf_base, (float*)wd_base);
     else return RVIP_EINVAL;
     return check_launch();
 }

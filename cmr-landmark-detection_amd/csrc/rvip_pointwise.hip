@@ -27,7 +27,7 @@ static inline bool red_geom(long long rows, int c, int ve, RedGeom& g) {
     if (g.cg > 256) return false;
     g.rpi = 256 / g.cg;
     long long nb = cdiv(rows, (long long)g.rpi * 8);
-    if (nb > 512) nb = 512;
+    if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     long long ch = cdiv(rows, nb);
     ch = cdiv(ch, g.rpi) * g.rpi;
@@ -126,11 +126,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned char* __re
 #pragma unroll
     for (int e = 0; e < VE; ++e) part[0][e] = part[1][e] = 0.f;
     if (active) {
-        for (long long r = r0 + prow; r < r1; r += g.rpi) {
-            float v[VE];
-            Vec<T>::load(z + ((size_t)r * c + cgi * VE) * sizeof(T), v);
+        for (long long r = r0 + prow; r < r1; r += 4 * g.rpi) {
+            float v[4][VE];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) { part[0][e] += v[e]; part[1][e] = fmaf(v[e], v[e], part[1][e]); }
+            for (int u = 0; u < 4; ++u) {
+                const long long rr = r + u * g.rpi;
+                if (rr < r1) Vec<T>::load(z + ((size_t)rr * c + cgi * VE) * sizeof(T), v[u]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) v[u][e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VE; ++e) { part[0][e] += v[u][e]; part[1][e] = fmaf(v[u][e], v[u][e], part[1][e]); }
         }
     }
     block_fold<2, VE>(part, active, prow * g.cg + cgi, c, g.rpi, lds, ws + (size_t)blockIdx.x * 2 * c);
@@ -179,9 +189,8 @@ struct ApplyArgs {
 };
 
 template <typename T, int VE>
-__device__ __forceinline__ void apply_vec(const ApplyArgs& a, size_t e0, const float (&sc)[VE], const float (&sh)[VE],
-                                          uint32_t key, float (&v)[VE]) {
-    Vec<T>::load(a.z + e0 * sizeof(T), v);
+__device__ __forceinline__ void apply_xform(const ApplyArgs& a, size_t e0, const float (&sc)[VE], const float (&sh)[VE],
+                                            uint32_t key, float (&v)[VE]) {
 #pragma unroll
     for (int e = 0; e < VE; ++e) v[e] = act_fwd(fmaf(v[e], sc[e], sh[e]), a.act);
     if (a.drop) {
@@ -197,45 +206,72 @@ __device__ __forceinline__ void apply_vec(const ApplyArgs& a, size_t e0, const f
     }
 }
 
+// thread = (row slot, channel vector): the channel vector is fixed per thread, so scale/shift live in registers;
+// every thread keeps UNR independent 16-byte loads in flight (the kernel is a pure HBM stream).
 template <typename T, bool POOL>
-__global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int rpi, long long ngroups) {
     constexpr int VE = Vec<T>::VE;
-    const int cg = a.c / VE;
-    const long long idx = blockIdx.x * 256LL + threadIdx.x;
-    const int cv = (int)(idx % cg);
+    constexpr int UNR = POOL ? 2 : 4;
+    const int tid = threadIdx.x, cv = tid % cg, prow = tid / cg;
+    if (prow >= rpi) return;
     float sc[VE], sh[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) { sc[e] = a.scale ? a.scale[cv * VE + e] : 1.f; sh[e] = a.shift ? a.shift[cv * VE + e] : 0.f; }
     const uint32_t key = (a.drop && !a.mask) ? dropout_key(a.state[RVIP_STATE_SEED], a.state[RVIP_STATE_STEP], (uint32_t)a.layer_id) : 0u;
+    const long long G = gridDim.x;
     if constexpr (!POOL) {
         const long long rows = (long long)a.n * a.h * a.w;
-        const long long r = idx / cg;
-        if (r >= rows) return;
-        const size_t e0 = (size_t)r * a.c + cv * VE;
-        float v[VE];
-        apply_vec<T, VE>(a, e0, sc, sh, key, v);
-        Vec<T>::store(a.y + e0 * sizeof(T), v);
-    } else {
-        const int oh = a.h >> 1, ow = a.w >> 1;
-        const long long q = idx / cg;
-        if (q >= (long long)a.n * oh * ow) return;
-        const int ox = (int)(q % ow), oy = (int)((q / ow) % oh);
-        const long long img = q / ((long long)ow * oh);
-        float best[VE];
+        for (long long g = blockIdx.x; g < ngroups; g += UNR * G) {
+            float v[UNR][VE]; size_t e0[UNR]; bool ok[UNR];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const size_t r = ((size_t)img * a.h + 2 * oy + (k >> 1)) * a.w + 2 * ox + (k & 1);
-            const size_t e0 = r * a.c + cv * VE;
-            float v[VE];
-            apply_vec<T, VE>(a, e0, sc, sh, key, v);
-            Vec<T>::store(a.y + e0 * sizeof(T), v);
+            for (int u = 0; u < UNR; ++u) {
+                const long long r = (g + u * G) * rpi + prow;
+                ok[u] = (g + u * G) < ngroups && r < rows;
+                e0[u] = (size_t)r * a.c + cv * VE;
+                if (ok[u]) Vec<T>::load(a.z + e0[u] * sizeof(T), v[u]);
+            }
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const float vr = Vec<T>::round(v[e]);                 // pool what was stored
-                best[e] = (k == 0 || vr > best[e]) ? vr : best[e];
+            for (int u = 0; u < UNR; ++u) {
+                if (!ok[u]) continue;
+                apply_xform<T, VE>(a, e0[u], sc, sh, key, v[u]);
+                Vec<T>::store(a.y + e0[u] * sizeof(T), v[u]);
             }
         }
-        Vec<T>::store(a.pooled + ((size_t)q * a.c + cv * VE) * sizeof(T), best);
+    } else {
+        const int oh = a.h >> 1, ow = a.w >> 1;
+        const long long quads = (long long)a.n * oh * ow;
+        for (long long g = blockIdx.x; g < ngroups; g += UNR * G) {
+            float v[UNR][4][VE]; size_t e0[UNR][4]; bool ok[UNR]; long long qi[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const long long q = (g + u * G) * rpi + prow;
+                qi[u] = q;
+                ok[u] = (g + u * G) < ngroups && q < quads;
+                const int ox = (int)(q % ow), oy = (int)((q / ow) % oh);
+                const long long img = q / ((long long)ow * oh);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    e0[u][k] = (((size_t)img * a.h + 2 * oy + (k >> 1)) * a.w + 2 * ox + (k & 1)) * a.c + cv * VE;
+                    if (ok[u]) Vec<T>::load(a.z + e0[u][k] * sizeof(T), v[u][k]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (!ok[u]) continue;
+                float best[VE];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    apply_xform<T, VE>(a, e0[u][k], sc, sh, key, v[u][k]);
+                    Vec<T>::store(a.y + e0[u][k] * sizeof(T), v[u][k]);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        const float vr = Vec<T>::round(v[u][k][e]);                 // pool what was stored
+                        best[e] = (k == 0 || vr > best[e]) ? vr : best[e];
+                    }
+                }
+                Vec<T>::store(a.pooled + ((size_t)qi[u] * a.c + cv * VE) * sizeof(T), best);
+            }
+        }
     }
 }
 
@@ -252,8 +288,7 @@ struct BnBwdArgs {
 
 // g = dL/d(BN-side output before dropout) [times act'(y) when the activation follows BN]
 template <typename T, int VE>
-__device__ __forceinline__ void load_g(const BnBwdArgs& a, size_t e0, int cbase, uint32_t key, const float (&z)[VE], float (&g)[VE]) {
-    Vec<T>::load(a.dy + e0 * sizeof(T), g);
+__device__ __forceinline__ void xform_g(const BnBwdArgs& a, size_t e0, int cbase, uint32_t key, const float (&z)[VE], float (&g)[VE]) {
     if (a.drop) {
         if (a.mask) {
 #pragma unroll
@@ -290,13 +325,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom
         is[e] = active ? a.invstd[cgi * VE + e] : 0.f;
     }
     if (active) {
-        for (long long r = r0 + prow; r < r1; r += gm.rpi) {
-            const size_t e0 = (size_t)r * a.c + cgi * VE;
-            float z[VE], g[VE];
-            Vec<T>::load(a.z + e0 * sizeof(T), z);
-            load_g<T, VE>(a, e0, cgi * VE, key, z, g);
+        for (long long r = r0 + prow; r < r1; r += 2 * gm.rpi) {
+            float z[2][VE], g[2][VE]; size_t e0[2]; bool ok[2];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) { part[0][e] += g[e]; part[1][e] = fmaf(g[e], (z[e] - mu[e]) * is[e], part[1][e]); }
+            for (int u = 0; u < 2; ++u) {
+                const long long rr = r + u * gm.rpi;
+                ok[u] = rr < r1;
+                e0[u] = (size_t)rr * a.c + cgi * VE;
+                if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); Vec<T>::load(a.dy + e0[u] * sizeof(T), g[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!ok[u]) continue;
+                xform_g<T, VE>(a, e0[u], cgi * VE, key, z[u], g[u]);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) { part[0][e] += g[u][e]; part[1][e] = fmaf(g[u][e], (z[u][e] - mu[e]) * is[e], part[1][e]); }
+            }
         }
     }
     block_fold<2, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws + (size_t)blockIdx.x * 2 * a.c);
@@ -335,19 +379,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
         c3[e] = (a.has_bn && active) ? a.coef[2 * a.c + ch] : 0.f;
     }
     if (active) {
-        for (long long r = r0 + prow; r < r1; r += gm.rpi) {
-            const size_t e0 = (size_t)r * a.c + cgi * VE;
-            float z[VE], g[VE], d[VE];
-            Vec<T>::load(a.z + e0 * sizeof(T), z);
-            load_g<T, VE>(a, e0, cgi * VE, key, z, g);
+        for (long long r = r0 + prow; r < r1; r += 2 * gm.rpi) {
+            float z[2][VE], g[2][VE]; size_t e0[2]; bool ok[2];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                float t = fmaf(c1[e], g[e], fmaf(c2[e], z[e], c3[e]));
-                if (!a.act_after_bn) t *= act_bwd(z[e], a.act);       // z is the activation output here
-                d[e] = t;
-                part[0][e] += Vec<T>::round(t);                        // bias grad of what the wgrad kernels read
+            for (int u = 0; u < 2; ++u) {
+                const long long rr = r + u * gm.rpi;
+                ok[u] = rr < r1;
+                e0[u] = (size_t)rr * a.c + cgi * VE;
+                if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); Vec<T>::load(a.dy + e0[u] * sizeof(T), g[u]); }
             }
-            Vec<T>::store(a.dz + e0 * sizeof(T), d);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!ok[u]) continue;
+                xform_g<T, VE>(a, e0[u], cgi * VE, key, z[u], g[u]);
+                float d[VE];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    float t = fmaf(c1[e], g[u][e], fmaf(c2[e], z[u][e], c3[e]));
+                    if (!a.act_after_bn) t *= act_bwd(z[u][e], a.act);   // z is the activation output here
+                    d[e] = t;
+                    part[0][e] += Vec<T>::round(t);                    // bias grad of what the wgrad kernels read
+                }
+                Vec<T>::store(a.dz + e0[u] * sizeof(T), d);
+            }
         }
     }
     block_fold<1, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws + (size_t)blockIdx.x * a.c);
@@ -594,6 +648,53 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const T* __restrict__ x, 
     block_fold<9, VE>(part, active, prow * gm.cg + cgi, cout, gm.rpi, lds, ws + (size_t)blockIdx.x * 9 * cout);
 }
 
+// tiled form of the same reduction: halo of the single input channel in LDS, thread = (pixel slot, channel vector)
+template <typename T>
+__global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, const unsigned char* __restrict__ dy,
+                                                      int n, int h, int w, int cout, int tiles_x, int tiles_y, float* __restrict__ ws) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float xs[10 * 34];
+    __shared__ float lds[256 * VE];
+    const int tid = threadIdx.x, cg = cout / VE, cv = tid % cg, ps = tid / cg, pps = 256 / cg;
+    float part[9][VE];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) part[t][e] = 0.f;
+    const int ntiles = n * tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int bx = tile;
+        const int tx0 = (bx % tiles_x) * 32; bx /= tiles_x;
+        const int ty0 = (bx % tiles_y) * 8;
+        const long long img = bx / tiles_y;
+        __syncthreads();
+        for (int i = tid; i < 340; i += 256) {
+            const int gy = ty0 - 1 + i / 34, gx = tx0 - 1 + i % 34;
+            float xv = 0.f;
+            if ((unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) {
+                if constexpr (sizeof(T) == 4) xv = x[(img * h + gy) * w + gx];
+                else xv = bf16_to_f32(x[(img * h + gy) * w + gx].bits);
+            }
+            xs[i] = xv;
+        }
+        __syncthreads();
+        for (int p = ps; p < 256; p += pps) {
+            const int py = p >> 5, px = p & 31;
+            const int gy = ty0 + py, gx = tx0 + px;
+            if (gy >= h || gx >= w) continue;
+            float g[VE];
+            Vec<T>::load(dy + ((((size_t)img * h + gy) * w + gx) * cout + cv * VE) * sizeof(T), g);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float xv = xs[(py + t / 3) * 34 + px + t % 3];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) part[t][e] = fmaf(xv, g[e], part[t][e]);
+            }
+        }
+    }
+    block_fold<9, VE>(part, true, ps * cg + cv, cout, pps, lds, ws + (size_t)blockIdx.x * 9 * cout);
+}
+
 struct PostC1Wgrad {
     float* dw; int cout;
     __device__ void run(int ch, const double (&t)[9]) const {
@@ -708,18 +809,22 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     a.inv_keep = drop ? 1.f / (1.f - d->drop_rate) : 1.f; a.thr = dropout_thr(d->drop_rate);
     a.mask = d->mask; a.state = d->state; a.layer_id = d->layer_id; a.drop = drop;
     a.n = d->n; a.h = d->h; a.w = d->w; a.c = d->c;
-    const long long cg = d->c / ve;
+    const int cg = d->c / ve;
+    if (cg > 256) return RVIP_EINVAL;
+    const int rpi = 256 / cg;
     hipStream_t s = (hipStream_t)stream;
+    const long long units = d->pooled ? (long long)d->n * (d->h / 2) * (d->w / 2) : (long long)d->n * d->h * d->w;
+    const long long ngroups = cdiv(units, rpi);
+    const int unr = d->pooled ? 2 : 4;
+    long long nb = cdiv(ngroups, unr);
+    if (nb > 4096) nb = 4096;
+    dim3 grid((unsigned)nb);
     if (d->pooled) {
-        const long long total = (long long)d->n * (d->h / 2) * (d->w / 2) * cg;
-        dim3 grid((unsigned)cdiv(total, 256));
-        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((bn_apply_kernel<float, true>), grid, dim3(256), 0, s, a);
+        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+        else hipLaunchKernelGGL((bn_apply_kernel<float, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
     } else {
-        const long long total = (long long)d->n * d->h * d->w * cg;
-        dim3 grid((unsigned)cdiv(total, 256));
-        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((bn_apply_kernel<float, false>), grid, dim3(256), 0, s, a);
+        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+        else hipLaunchKernelGGL((bn_apply_kernel<float, false>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
     }
     return check_launch();
 }
@@ -869,6 +974,18 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
     if (workspace_bytes < (size_t)g.nblk * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
+    if (256 % g.cg == 0) {
+        const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
+        long long nt = (long long)n * tx * ty;
+        const int nb = (int)(nt < 1024 ? nt : 1024);
+        if (workspace_bytes < (size_t)nb * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
+        if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws);
+        else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws);
+        int rc2 = check_launch();
+        if (rc2) return rc2;
+        PostC1Wgrad p2{dw, cout};
+        return launch_fold<9, PostC1Wgrad>(ws, nb, cout, p2, s);
+    }
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     else hipLaunchKernelGGL(c1_wgrad_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     int rc = check_launch();

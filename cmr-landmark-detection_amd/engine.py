@@ -73,15 +73,28 @@ class ParamStore:
         self.state = torch.zeros(N.STATE_WORDS, dtype=torch.int32, device=device)
         self.set_lr(lr)
         self.set_seed(seed)
+        # packed MFMA operands of every 3x3 conv in two flat blocks + a device table for the one-launch re-layout
         self.packed = {}
+        entries, off = [], 0
         for st in plan.stages:
             if st.transpose:
                 raise NotImplementedError('USE_UPSAMPLE=False (Conv2DTranspose decoder, KerasLayers.py:761-765) is not built '
                                           'yet; the default UpSampling+Conv path is')
             if st.src0 != 'input_1':
                 k = 9 * st.cin * st.cout
-                self.packed[st.conv] = (torch.empty(k, dtype=self.tdtype, device=device),
-                                        torch.empty(k, dtype=self.tdtype, device=device))
+                entries.append((st.conv, self.off[(st.conv, 'kernel')][0], off, st.cin, st.cout))
+                off += -(-k // ALIGN) * ALIGN
+        self.wf_all = torch.empty(max(off, ALIGN), dtype=self.tdtype, device=device)
+        self.wd_all = torch.empty(max(off, ALIGN), dtype=self.tdtype, device=device)
+        tab = (N.PackEntry * max(len(entries), 1))()
+        self.pack_max = 1
+        for i, (name, w_off, p_off, cin, cout) in enumerate(entries):
+            tab[i].w_off, tab[i].f_off, tab[i].d_off, tab[i].cin, tab[i].cout = w_off, p_off, p_off, cin, cout
+            k = 9 * cin * cout
+            self.packed[name] = (self.wf_all[p_off:p_off + k], self.wd_all[p_off:p_off + k])
+            self.pack_max = max(self.pack_max, k)
+        self.pack_entries = len(entries)
+        self.pack_table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(device)
         self.upload(host_weights)
 
     # -- host <-> device ------------------------------------------------------------------------------
@@ -138,13 +151,16 @@ class ParamStore:
     def step_count(self):
         return int(self.state[N.STATE_STEP].item())
 
-    def repack(self, stream):
+    def pack_call(self):
+        """(fn, args) of the one-launch re-layout of every 3x3 kernel (fp32 HWIO master -> packed MFMA operands)."""
         L = N.lib()
-        for st in self.plan.stages:
-            if st.conv in self.packed:
-                wf, wd = self.packed[st.conv]
-                N.check(L.rvip_pack_conv3x3_weights(self.p(st.conv, 'kernel'), st.cin, st.cout, self.dt, _ptr(wf), _ptr(wd),
-                                                    C.c_void_p(stream)), 'rvip_pack_conv3x3_weights')
+        return (L.rvip_pack_all_conv3x3_weights, (_ptr(self.theta), _ptr(self.pack_table), self.pack_entries, self.pack_max,
+                                                  self.dt, _ptr(self.wf_all), _ptr(self.wd_all)))
+
+    def repack(self, stream):
+        if self.pack_entries:
+            fn, args = self.pack_call()
+            N.check(fn(*args, C.c_void_p(stream)), 'rvip_pack_all_conv3x3_weights')
 
 
 class Engine:
@@ -382,10 +398,8 @@ class Engine:
         self.fwd_train, self.fwd_infer, self.bwd = fwd_t, fwd_i, bwd
         self.opt = [(L.rvip_adam_step, (_ptr(P.theta), _ptr(P.grad), _ptr(P.adam_m), _ptr(P.adam_v), C.c_longlong(P.count),
                                         C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0), _ptr(P.state)))]
-        for st in plan.stages:
-            if st.conv in P.packed:
-                wf, wd = P.packed[st.conv]
-                self.opt.append((L.rvip_pack_conv3x3_weights, (P.p(st.conv, 'kernel'), st.cin, st.cout, dt, _ptr(wf), _ptr(wd))))
+        if P.pack_entries:
+            self.opt.append(P.pack_call())
         self.opt.append((L.rvip_state_tick, (_ptr(P.state),)))
 
     # -- execution ------------------------------------------------------------------------------------

@@ -90,6 +90,13 @@ int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
 int rvip_pack_conv3x3_weights(const float* w_hwio, int cin, int cout, int dtype,
                               void* w_fwd, void* w_dgrad, void* stream);
 
+/* The same re-layout for ALL 3x3 kernels of a model in one launch.  `theta` is the flat fp32 parameter block;
+ * `table` is a DEVICE array of `entries` records {int64 w_off (floats into theta), int64 f_off, int64 d_off
+ * (elements into wf_base / wd_base), int32 cin, int32 cout}; max_elems = max over entries of 9*cin*cout. */
+typedef struct rvip_pack_entry { long long w_off, f_off, d_off; int32_t cin, cout; } rvip_pack_entry;
+int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
+                                  void* wf_base, void* wd_base, void* stream);
+
 /* Weight gradient of the same conv (autodiff of KerasLayers.py:683,689,758):
  *   dw[t][i][o] = sum_{n,h,w} X[n,h+t/3-1,w+t%3-1,i] * dy[n,h,w,o],   X = virtual [up(x0), x1]
  * fp32 HWIO output.  Deterministic two-stage split-K: workspace holds nsplit partial slabs.

@@ -63,6 +63,7 @@ def test_fp32_training_steps_match_oracle(variant):
     B = 4
     model = rvip.get_model(cfg, metrics=[M.dice_coef_labels, M.dice_coef_lower, M.dice_coef_upper])
     ref, layers = _oracle_from(model, cfg)
+    ref32, _ = _oracle_from(model, cfg, dtype=np.float32)     # conditioning probe: the same graph evaluated in float32
     x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=3)
     x64, y64 = x.astype(np.float64), y.astype(np.float64)
     eng = model._engine(B)
@@ -72,6 +73,7 @@ def test_fp32_training_steps_match_oracle(variant):
         # Adam turns fp32 noise on near-zero gradients into O(lr) weight differences, so the oracle restarts every
         # step from the DEVICE weights; the optimiser arithmetic is checked separately on the device's gradients.
         ref.set_weights(model.get_weights())
+        ref32.set_weights(model.get_weights())
         masks = _masks(layers, B, model.seed, step)
         eng.load_input(x, y)
         eng.forward(training=True)
@@ -84,6 +86,14 @@ def test_fp32_training_steps_match_oracle(variant):
             rpred, cache = ref.forward(x64, True, masks)
             lv, dlog = O.bce_dice_loss(y64, rpred, w_bce=kind[1], w_dice=kind[2], logits=cache['logits'])
             rgrads = ref.backward(cache, dlog, d_is_logit_grad=True)
+        # float32 evaluation of the oracle: BN backward cancels the common-mode part of the incoming gradient (large
+        # with BCE-Dice), so fp32 results scatter around the float64 truth by far more than 1e-7 on some inputs
+        p32, c32 = ref32.forward(x, True, masks)
+        if loss_name == 'mse':
+            g32 = ref32.backward(c32, O.mse_loss(y, p32)[1])
+        else:
+            g32 = ref32.backward(c32, O.bce_dice_loss(y, p32, w_bce=kind[1], w_dice=kind[2], logits=c32['logits'])[1].astype(np.float32),
+                                 d_is_logit_grad=True)
         assert abs(float(eng.loss.item()) - lv) <= 2e-5 * max(1.0, abs(lv)), (step, float(eng.loss.item()), lv)
         np.testing.assert_allclose(eng.pred.cpu().numpy(), rpred, atol=1e-4)
         got = model._params.grads_host()
@@ -91,8 +101,9 @@ def test_fp32_training_steps_match_oracle(variant):
         for (lname, i), g in _flat_grads(rgrads).items():
             wn = wname[i] if lname.startswith('conv') or lname == 'unet' else ('gamma', 'beta')[i]
             gg = got[(lname, wn)]
+            # within 3e-4 of the float64 gradient, or at least as close to it as the float32 CPU evaluation is;
             # absolute floor: a conv bias directly in front of BN has an exactly-zero gradient (fp32 noise ~1e-8)
-            tol = max(3e-4 * float(np.abs(g).max()), 5e-8)
+            tol = max(3e-4 * float(np.abs(g).max()), 5e-8, float(np.abs(g32[lname][i] - g).max()))
             assert np.abs(gg - g).max() <= tol, (step, lname, wn, float(np.abs(gg - g).max()), tol)
             dev_grads.setdefault(lname, [None, None])[i] = gg.astype(np.float64)
         eng.optimizer_step()
