@@ -235,6 +235,7 @@ static int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 // raw buffer descriptor (base, stride 0, num_records = bytes, raw 32-bit format) built from wave-uniform values
 __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
@@ -258,7 +259,7 @@ struct ConvArgs2 {
     const unsigned char* x0; const unsigned char* x1;
     const unsigned char* wp; const float* bias;
     unsigned char* y; unsigned char* y1;
-    unsigned x0_bytes, x1_bytes, wp_bytes;
+    unsigned x0_bytes, x1_bytes, wp_bytes, y_bytes, y1_bytes;
     int c0, c1, up0, csplit;
     int n, h, w, cin, cout, act;
     int tiles_x, tiles_y, ntiles, wres;      // wres: weight stages resident (= nchunks) or 0 -> 2 rotating stages
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
     constexpr int NQI = NHROWS / 16, NQW = WROWS / 16;                 // 1 KiB DMA pieces per stage
     constexpr int QI = (NQI + NW - 1) / NW, QW = (NQW + NW - 1) / NW;  // per wave
     constexpr unsigned OOB = 0x80000000u;
+    constexpr int NST = (sizeof(T) == 2) ? NCT * 2 * 2 : NCT * 2 * 4;   // buffer stores per wave per tile epilogue
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lin = smem;                       // [2][IN_BYTES]
     unsigned char* lw = smem + 2 * IN_BYTES;         // [wres or 2][W_BYTES]
@@ -289,6 +291,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
     const i32x4 rs0 = make_rsrc(a.x0, a.x0_bytes);
     const i32x4 rs1 = make_rsrc(a.x1 ? a.x1 : a.x0, a.x1 ? a.x1_bytes : 0u);
     const i32x4 rsw = make_rsrc(a.wp, a.wp_bytes);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y1 ? a.y1 : a.y), 0, a.y1 ? a.y1_bytes : 0, 0x00020000);
     const unsigned lds_base = lds_offset_of(smem);
     float* lbias = reinterpret_cast<float*>(smem + a.lds_bias_off);        // [BN] bias of this output-channel tile
     if (tid < BN) lbias[tid] = (a.bias && co0 + tid < a.cout) ? a.bias[co0 + tid] : 0.f;
@@ -311,34 +315,37 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
             }
         }
     };
+    // per-lane halo coordinates of each DMA piece this wave issues (tile independent): (hy << 16) | hx, -1 = pad row
+    int hyx[QI], pslot[QI];
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+        const int row = (wv + NW * i) * 16 + drow;
+        const int hy = row / HWD, hx = row - hy * HWD;
+        hyx[i] = (row < NHALO) ? ((hy << 16) | hx) : -1;
+        pslot[i] = (dslot ^ ((row >> 2) & 3)) * VE;              // first channel (within the chunk) of my 16-byte piece
+    }
     auto issue_input = [&](int tile, int kc, int stage) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
         const int n = bx / a.tiles_y;
-        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+        const int ty0 = ty_i * TH - 1, tx0 = tx_i * TW - 1;
         const int cbase = kc * KCE;
         const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
+        const int csrc = from0 ? a.c0 : a.c1;
+        const int cb = from0 ? cbase : cbase - a.c0;
+        const int hs = from0 ? h0 : a.h, wsrc = from0 ? w0 : a.w, sh = from0 ? a.up0 : 0;
+        const i32x4 rs = from0 ? rs0 : rs1;
 #pragma unroll
         for (int i = 0; i < QI; ++i) {
             const int q = wv + NW * i;
             if (q < NQI) {
-                const int row = q * 16 + drow;
-                const int hy = row / HWD, hx = row - hy * HWD;
-                const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-                const int p = dslot ^ ((row >> 2) & 3);
+                const int gy = ty0 + (hyx[i] >> 16), gx = tx0 + (hyx[i] & 0xffff);
+                const int c = cb + pslot[i];
                 unsigned off = OOB;
-                if (row < NHALO && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w) {
-                    if (from0) {
-                        const int c = cbase + p * VE;
-                        if (c < a.c0) off = (unsigned)((((n * h0 + (gy >> a.up0)) * w0 + (gx >> a.up0)) * a.c0 + c) * (int)sizeof(T));
-                    } else {
-                        const int c = cbase - a.c0 + p * VE;
-                        if (c < a.c1) off = (unsigned)((((n * a.h + gy) * a.w + gx) * a.c1 + c) * (int)sizeof(T));
-                    }
-                }
-                if (from0) dma16(rs0, off, lds_base + stage * IN_BYTES + q * 1024);
-                else dma16(rs1, off, lds_base + stage * IN_BYTES + q * 1024);
+                if (hyx[i] >= 0 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && c < csrc)
+                    off = (unsigned)((((n * hs + (gy >> sh)) * wsrc + (gx >> sh)) * csrc + c) * (int)sizeof(T));
+                dma16(rs, off, lds_base + stage * IN_BYTES + q * 1024);
             }
         }
     };
@@ -379,8 +386,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
         const int n = bx / a.tiles_y;
         const int ty0 = ty_i * TH, tx0 = tx_i * TW;
         for (int kc = 0; kc < nchunks; ++kc, ++it) {
-            // item `it` has landed for me; after the barrier for everyone, and everyone has finished item it-1
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            // item `it` has landed for me; after the barrier for everyone, and everyone has finished item it-1.
+            // The epilogue's NST buffer stores are YOUNGER than this item's DMA: leave them in flight.
+            if (kc == 0 && it > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             {   // prefetch the next item into the other stage
                 int ntile = tile, nkc = kc + 1;
                 if (nkc == nchunks) { nkc = 0; ntile = tile + gridDim.x; }
@@ -414,41 +423,65 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
                 }
             }
         }
-        // epilogue of this tile (the next item's DMA is already in flight)
+        // epilogue of this tile (the next item's DMA is already in flight).  Stores are buffer stores whose masked lanes
+        // (pixel outside the image, channel tail) carry an out-of-range offset: the instruction count per wave is fixed
+        // (= NST), which is what lets the next item-top wait be vmcnt(NST).  bf16: two accumulator quads are merged with
+        // v_permlane32_swap so that every lane stores 16 contiguous bytes (8 channels of one pixel).
+        auto epilogue = [&](auto actf) {
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             const int P = wv * 64 + pt * 32 + j;
             const int gy = ty0 + P / TW, gx = tx0 + P % TW;
             const bool pix_ok = gy < a.h && gx < a.w;
-            const size_t pix = ((size_t)n * a.h + gy) * a.w + gx;
+            const unsigned pix = (unsigned)((n * a.h + gy) * a.w + gx);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
+                const int cbase = co0 + ct * 32;                                   // wave-uniform
+                const bool second = a.y1 && cbase >= a.csplit;                     // csplit % 32 == 0 (host)
+                const int cstride = a.y1 ? (second ? a.cout - a.csplit : a.csplit) : a.cout;
+                const int cshift = second ? a.csplit : 0;
+                float v[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int co = co0 + ct * 32 + 8 * q + 4 * hf;
-                    float v[4];
+                for (int r = 0; r < 16; ++r) {
+                    const float t = acc[ct][pt][r] + lbias[ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
+                    acc[ct][pt][r] = 0.f;
+                    v[r] = actf(t);
+                }
+                if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float t = acc[ct][pt][4 * q + i];
-                        acc[ct][pt][4 * q + i] = 0.f;
-                        t += lbias[ct * 32 + 8 * q + 4 * hf + i];
-                        v[i] = act_fwd(t, a.act);
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = cbase + 8 * q + 4 * hf;
+                        const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 4u : OOB;
+                        const u32x4v dta = {__builtin_bit_cast(unsigned, v[4 * q]), __builtin_bit_cast(unsigned, v[4 * q + 1]),
+                                            __builtin_bit_cast(unsigned, v[4 * q + 2]), __builtin_bit_cast(unsigned, v[4 * q + 3])};
+                        if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
                     }
-                    if (!pix_ok || co >= a.cout) continue;
-                    unsigned char* dst;
-                    if (a.y1 && co >= a.csplit) dst = a.y1 + (pix * (a.cout - a.csplit) + (co - a.csplit)) * sizeof(T);
-                    else dst = a.y + (pix * (a.y1 ? a.csplit : a.cout) + co) * sizeof(T);
-                    if constexpr (sizeof(T) == 4) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        uint2 o;
-                        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        unsigned ax = (uint32_t)f32_to_bf16(v[8 * qq + 0]) | ((uint32_t)f32_to_bf16(v[8 * qq + 1]) << 16);
+                        unsigned ay = (uint32_t)f32_to_bf16(v[8 * qq + 2]) | ((uint32_t)f32_to_bf16(v[8 * qq + 3]) << 16);
+                        unsigned bxx = (uint32_t)f32_to_bf16(v[8 * qq + 4]) | ((uint32_t)f32_to_bf16(v[8 * qq + 5]) << 16);
+                        unsigned byy = (uint32_t)f32_to_bf16(v[8 * qq + 6]) | ((uint32_t)f32_to_bf16(v[8 * qq + 7]) << 16);
+                        // lanes 0-31 keep quad 2qq and receive the upper half's quad 2qq (channels +4..7);
+                        // lanes 32-63 receive the lower half's quad 2qq+1 and keep their own (channels +8..15)
+                        auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
+                        auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
+                        const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
+                        const int co = cbase + 16 * qq + 8 * hf;
+                        const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
+                        if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
                     }
                 }
             }
         }
+        };
+        // the activation is launch-uniform: specialise the hot cases so the epilogue stays a few hundred instructions
+        if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
+        else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
+        else epilogue([&](float t) { return act_fwd(t, a.act); });
     }
 }
 
@@ -467,9 +500,14 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used) {
     const long long wpb = 9LL * a0.cin * a0.cout * (long long)sizeof(T);
     if (x0b >= (1LL << 31) || x1b >= (1LL << 31) || wpb >= (1LL << 31)) return RVIP_OK;
     if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
+    if (a0.y1 && a0.csplit % 32) return RVIP_OK;
+    const long long npx = (long long)a0.n * a0.h * a0.w;
+    const long long yb = npx * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
+    if (yb >= (1LL << 31) || y1b >= (1LL << 31)) return RVIP_OK;
+    if (sizeof(T) == 2 && a0.cout % 8) return RVIP_OK;
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
-    b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb;
+    b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
     b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
