@@ -53,11 +53,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('--gpus %d needs the torch.distributed.run launcher (one rank per GPU)' % args.gpus)
-    torch.cuda.set_device(local)
+    backend = os.environ.get('RVIP_BENCH_BACKEND', 'nccl')       # 'gloo' only to rehearse the N>1 code path on one GPU
+    ndev = max(torch.cuda.device_count(), 1)
+    os.environ['LOCAL_RANK'] = str(local % ndev)                 # the engine picks its device from LOCAL_RANK
+    torch.cuda.set_device(local % ndev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local % ndev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = dict(DIM=[args.dim, args.dim], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
                MASK_CLASSES=2, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-4, RVIP_PRECISION=args.precision,
@@ -71,31 +77,49 @@ def main():
     eng.load_input(x, y)                       # synthetic batch resident in HBM before the timed region
     torch.cuda.synchronize()
 
-    def step():
+    def fwd_bwd():
         eng.stage_input()                      # fp32 slice -> network input dtype (on device)
-        eng.train_step()
+        eng.forward(training=True)
+        eng.backward()
 
-    use_graph = (not args.no_graph) and world == 1
-    graph = None
+    def step():                                # eager: fwd + bwd + [RCCL all-reduce] + Adam
+        fwd_bwd()
+        eng.allreduce_grads()
+        eng.optimizer_step()
+
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        torch.cuda.synchronize()
+        return g
+
     for _ in range(min(2, max(args.warmup, 1))):
         step()
     torch.cuda.synchronize()
-    if use_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-            torch.cuda.synchronize()
-        except Exception as e:                 # capture is an optimisation of the launch path, never required
+    run, launch = step, 'eager'
+    if not args.no_graph:
+        try:                                   # hipGraph replay removes ~190 host launches per step; never required
+            if world == 1:
+                g_all = capture(lambda: (fwd_bwd(), eng.optimizer_step()))
+                run, launch = g_all.replay, 'hipGraph'
+            else:                              # the collective stays outside the graphs: A (fwd+bwd) -> all-reduce -> B (Adam)
+                g_a, g_b = capture(fwd_bwd), capture(eng.optimizer_step)
+
+                def run():
+                    g_a.replay()
+                    eng.allreduce_grads()
+                    g_b.replay()
+                launch = 'hipGraph x2 + eager all-reduce'
+        except Exception as e:
             sys.stderr.write('hipGraph capture failed (%s); running eagerly\n' % (e,))
-            graph = None
+            run, launch = step, 'eager'
             torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
 
     def barrier():
         if world > 1:
@@ -133,7 +157,9 @@ def main():
         for _ in range(reps):
             eng.stage_input()
             for seq in (eng.fwd_train, eng.bwd, eng.opt):
-                for fn, a in seq:
+                for th in seq:
+                    fn, a = th[0], th[1]
+                    lab = th[2] if len(th) > 2 else ''
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(s)
                     rc = fn(*a, C.c_void_p(s.cuda_stream))
@@ -149,6 +175,8 @@ def main():
                     agg.setdefault(fn.__name__, []).append((e0, e1, flops))
                     if flops > 0:
                         detail.append((fn.__name__, (d.n, d.h, d.w, d.c0 + d.c1, d.cout, d.up0, 1 if d.c1 else 0), e0, e1, flops))
+                    else:
+                        detail.append((fn.__name__, (lab,), e0, e1, 0.0))
         torch.cuda.synchronize()
         if args.detail:
             rows = {}
@@ -158,7 +186,7 @@ def main():
             with open(args.detail, 'w') as fh:
                 fh.write('kernel n h w cin cout up cat launches avg_us tflops\n')
                 for (name, shp), (ms, cnt, f) in sorted(rows.items(), key=lambda kv: -kv[1][0]):
-                    fh.write('%s %s %d %.1f %.1f\n' % (name, ' '.join(map(str, shp)), cnt // reps, 1e3 * ms / cnt, f / (ms / cnt * 1e-3) / 1e12))
+                    fh.write('%s %s %d %.1f %.1f\n' % (name, ' '.join(map(str, shp)), max(cnt // reps, 1), 1e3 * ms / cnt, f / (ms / cnt * 1e-3) / 1e12))
         for name, evs in agg.items():
             ms = sum(a.elapsed_time(b) for a, b, _ in evs)
             fl = sum(f for _, _, f in evs)
@@ -186,7 +214,7 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': '4-level 2D U-Net F=32, %dx%d, batch %d per GPU, fwd+loss(MSE)+bwd+Adam%s' % (
                 args.dim, args.dim, B, ' + RCCL grad all-reduce' if world > 1 else ''),
-                'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': 'hipGraph' if graph is not None else 'eager',
+                'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch, 'collective': ('%s all-reduce of %d fp32 gradients' % (backend, model._params.count)) if world > 1 else None,
                 'gflop_per_slice_fwd_bwd': round(step_flops / 1e9, 3)},
             'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),
             'loss': loss,

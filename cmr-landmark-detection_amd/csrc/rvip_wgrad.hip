@@ -221,49 +221,51 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
     const i32x4w rsg = make_rsrc_w(a.dy, a.dy_bytes);
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
 
+    // tile-independent lane geometry of the DMA pieces this wave issues
+    constexpr int SLX = RBX / 16, RPPX = 1024 / RBX, SLG = RBG / 16, RPPG = 1024 / RBG;
+    const int csrc = from0 ? a.c0 : a.c1, cb0 = from0 ? ci0 : ci0 - a.c0;
+    const int hs = from0 ? h0 : a.h, wsrc = from0 ? w0 : a.w, shf = from0 ? a.up0 : 0;
+    int xhyx[QX], xch[QX], gyx[QG], gch[QG];
+#pragma unroll
+    for (int i = 0; i < QX; ++i) {
+        const int row = (wv + 4 * i) * RPPX + lane / SLX, slot = lane % SLX;
+        const int hy = row / HWD, hx = row - hy * HWD;
+        const int p = (RBX == 128) ? ((((slot >> 2) ^ ((row >> 1) & 1)) << 2) | (slot & 3)) : slot;
+        xhyx[i] = (row < NHALO) ? ((hy << 16) | hx) : -1;
+        xch[i] = cb0 + p * VE;
+    }
+#pragma unroll
+    for (int i = 0; i < QG; ++i) {
+        const int P = (wv + 4 * i) * RPPG + lane / SLG, slot = lane % SLG;
+        const int p = (RBG == 128) ? ((((slot >> 2) ^ ((P >> 1) & 1)) << 2) | (slot & 3)) : slot;
+        gyx[i] = ((P / TW) << 16) | (P % TW);
+        gch[i] = co0 + p * VE;
+    }
     auto issue = [&](int tile, int stage) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
         const int n = bx / a.tiles_y;
         const int ty0 = ty_i * TH, tx0 = tx_i * TW;
-        {
-            constexpr int SL = RBX / 16, RPP = 1024 / RBX;           // 16-byte slots per row, rows per piece
-            const int prow = lane / SL, slot = lane % SL;
-            const int csrc = from0 ? a.c0 : a.c1, cb0 = from0 ? ci0 : ci0 - a.c0;
 #pragma unroll
-            for (int i = 0; i < QX; ++i) {
-                const int q = wv + 4 * i;
-                if (q < NQX) {
-                    const int row = q * RPP + prow;
-                    const int hy = row / HWD, hx = row - hy * HWD;
-                    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-                    const int p = (RBX == 128) ? ((((slot >> 2) ^ ((row >> 1) & 1)) << 2) | (slot & 3)) : slot;
-                    const int c = cb0 + p * VE;
-                    unsigned off = OOB;
-                    if (row < NHALO && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && c < csrc) {
-                        const int pix = from0 ? ((n * h0 + (gy >> a.up0)) * w0 + (gx >> a.up0)) : ((n * a.h + gy) * a.w + gx);
-                        off = (unsigned)((pix * csrc + c) * ESZ);
-                    }
-                    dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
-                }
+        for (int i = 0; i < QX; ++i) {
+            const int q = wv + 4 * i;
+            if (q < NQX) {
+                const int gy = ty0 - 1 + (xhyx[i] >> 16), gx = tx0 - 1 + (xhyx[i] & 0xffff);
+                unsigned off = OOB;
+                if (xhyx[i] >= 0 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && xch[i] < csrc)
+                    off = (unsigned)((((n * hs + (gy >> shf)) * wsrc + (gx >> shf)) * csrc + xch[i]) * ESZ);
+                dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
             }
         }
-        {
-            constexpr int SL = RBG / 16, RPP = 1024 / RBG;
-            const int prow = lane / SL, slot = lane % SL;
 #pragma unroll
-            for (int i = 0; i < QG; ++i) {
-                const int q = wv + 4 * i;
-                if (q < NQG) {
-                    const int P = q * RPP + prow;
-                    const int gy = ty0 + P / TW, gx = tx0 + P % TW;
-                    const int p = (RBG == 128) ? ((((slot >> 2) ^ ((P >> 1) & 1)) << 2) | (slot & 3)) : slot;
-                    const int c = co0 + p * VE;
-                    unsigned off = OOB;
-                    if (gy < a.h && gx < a.w && c < a.cout) off = (unsigned)((((n * a.h + gy) * a.w + gx) * a.cout + c) * ESZ);
-                    dma16w(rsg, off, lds_base + stage * ST_BYTES + X_BYTES + q * 1024);
-                }
+        for (int i = 0; i < QG; ++i) {
+            const int q = wv + 4 * i;
+            if (q < NQG) {
+                const int gy = ty0 + (gyx[i] >> 16), gx = tx0 + (gyx[i] & 0xffff);
+                unsigned off = OOB;
+                if (gy < a.h && gx < a.w && gch[i] < a.cout) off = (unsigned)((((n * a.h + gy) * a.w + gx) * a.cout + gch[i]) * ESZ);
+                dma16w(rsg, off, lds_base + stage * ST_BYTES + X_BYTES + q * 1024);
             }
         }
     };

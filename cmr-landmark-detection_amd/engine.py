@@ -264,12 +264,21 @@ class Engine:
         ws, wsb = _ptr(self.ws), C.c_size_t(self.ws_bytes)
         state = _ptr(P.state)
         self._keep = []                 # keep ctypes structs alive
-        fwd_t, fwd_i, bwd = [], [], []
+
+        class _Labelled(list):
+            """launch list whose entries carry a (stage, bytes moved) label for bench.py --detail"""
+            label = ''
+
+            def append(self, item):
+                list.append(self, (item[0], item[1], self.label))
+        fwd_t, fwd_i, bwd = _Labelled(), _Labelled(), _Labelled()
+        esz = 2 if dt == N.BF16 else 4
 
         for st in plan.stages:
             rows = n * st.h * st.w
             z, y = self.act[st.z], self.act[st.y]
             first = st.src0 == 'input_1'
+            fwd_t.label = fwd_i.label = '%s %dx%dx%d->%d tensor=%.1fMB' % (st.conv, st.h, st.w, st.cin, st.cout, rows * st.cout * esz / 1e6)
             bias = P.p(st.conv, 'bias')
             act_conv = A[st.act_conv]
             # ---- conv ----
@@ -318,6 +327,7 @@ class Engine:
                     (fwd_t if training else fwd_i).append((L.rvip_bn_apply, (C.byref(a),)))
 
         hd = plan.head
+        fwd_t.label = fwd_i.label = bwd.label = 'head'
         hrows = C.c_longlong(n * hd['h'] * hd['w'])
         hx = self.act[hd['src']]
         hw_, hb_ = P.p(hd['conv'], 'kernel'), P.p(hd['conv'], 'bias')
@@ -325,7 +335,7 @@ class Engine:
                                         hd['cin'], hd['k'], dt, ws, wsb)))
         fwd_i.append((L.rvip_head_fwd, (_ptr(hx), hw_, hb_, _ptr(self.pred), None, None, hrows, hd['cin'], hd['k'], dt,
                                         None, C.c_size_t(0))))
-        self.fwd_eval = fwd_i[:-1] + [fwd_t[-1]]          # inference-mode network + loss sums (validation)
+        self.fwd_eval = list(fwd_i[:-1]) + [fwd_t[-1]]          # inference-mode network + loss sums (validation)
 
         # ---------------- backward ----------------
         per_rank = float(n * hd['h'] * hd['w'] * hd['k'])
@@ -338,6 +348,7 @@ class Engine:
         for st in reversed(plan.stages):
             rows = n * st.h * st.w
             first = st.src0 == 'input_1'
+            bwd.label = '%s %dx%dx%d->%d tensor=%.1fMB' % (st.conv, st.h, st.w, st.cin, st.cout, rows * st.cout * esz / 1e6)
             gy, dz, z = self.grd[st.y], self.dz[st.z], self.act[st.z]
             if st.pool:
                 add = self.gskip.get(st.y)
@@ -406,7 +417,8 @@ class Engine:
     @staticmethod
     def _run(seq, stream):
         s = C.c_void_p(stream)
-        for fn, args in seq:
+        for th in seq:
+            fn, args = th[0], th[1]
             rc = fn(*args, s)
             if rc:
                 N.check(rc, fn.__name__)
