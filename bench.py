@@ -196,10 +196,18 @@ def main():
         ms = sum(a.elapsed_time(b) for a, b, _ in cv)
         fl = sum(f for _, _, f in cv)
         achieved = fl / (ms * 1e-3) / 1e12
+        traffic = None
+        try:                                   # HBM bytes per launch of this kernel family from the committed PMC pass
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))['kernels']['conv3x3_igemm_dma']
+            traffic = pm['hbm_bytes_per_launch']
+        except Exception:
+            pass
         roof = dict(bound='mfma', kernel='conv3x3_igemm (fwd + dgrad launches)', achieved=round(achieved, 2),
                     peak=PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3, unit='TFLOP/s',
                     frac=round(achieved / (PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3), 4),
-                    traffic=None, launches_per_step=len(cv) // reps, avg_launch_ms=round(ms / len(cv), 4),
+                    traffic=traffic, traffic_source='profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)' if traffic else None,
+                    algorithmic_bytes_per_launch=round(plan.ideal_bytes_per_slice(2 if args.precision == 'bf16' else 4) * 2.0 / 3.0 * B / max(len(cv) // reps, 1)),
+                    launches_per_step=len(cv) // reps, avg_launch_ms=round(ms / len(cv), 4),
                     flops_per_launch=fl / len(cv))
 
     fwd_flops, step_flops = plan.flops_per_slice()

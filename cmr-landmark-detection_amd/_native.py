@@ -76,6 +76,9 @@ SIGNATURES = {
     'rvip_build_info': (C.c_char_p, []),
     'rvip_last_hip_error': (C.c_int, []),
     'rvip_conv3x3_fwd': (C.c_int, [C.POINTER(Conv3x3Desc), vp]),
+    'rvip_conv3x3_fwd_stats_rows': (C.c_int, [C.POINTER(Conv3x3Desc)]),
+    'rvip_conv3x3_fwd_stats': (C.c_int, [C.POINTER(Conv3x3Desc), vp, C.c_size_t, vp]),
+    'rvip_bn_stats_finalize': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp, vp]),
     'rvip_pack_conv3x3_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_pack_all_conv3x3_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_conv3x3_wgrad_workspace': (C.c_size_t, [C.c_int] * 5),

@@ -264,9 +264,10 @@ struct ConvArgs2 {
     int n, h, w, cin, cout, act;
     int tiles_x, tiles_y, ntiles, wres;      // wres: weight stages resident (= nchunks) or 0 -> 2 rotating stages
     int lds_bias_off;
+    float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
 };
 
-template <typename T, int TW, int NCT, int NW>
+template <typename T, int TW, int NCT, int NW, bool STATS>
 __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
     constexpr int NPIX = NW * 64, TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
     constexpr int NHROWS = (NHALO + 15) / 16 * 16;
@@ -372,6 +373,15 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
 
+    // fused BatchNormalization statistics (optional): per-lane partial sums of the values actually stored, over every
+    // tile this workgroup produces; reduced once at the end (fixed order -> reproducible)
+    constexpr int SN = STATS ? NCT : 1, SR = STATS ? 16 : 1;
+    float ssum[SN][SR], ssq[SN][SR];
+#pragma unroll
+    for (int ct = 0; ct < SN; ++ct)
+#pragma unroll
+        for (int r = 0; r < SR; ++r) ssum[ct][r] = ssq[ct][r] = 0.f;
+
     const int first_tile = blockIdx.x;
     if (first_tile >= a.ntiles) return;
     if (resident) for (int kc = 0; kc < nchunks; ++kc) issue_weights(kc, kc);
@@ -446,6 +456,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
                     const float t = acc[ct][pt][r] + lbias[ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
                     acc[ct][pt][r] = 0.f;
                     v[r] = actf(t);
+                    if constexpr (STATS) {
+                        if (pix_ok) {
+                            const float q = Vec<T>::round(v[r]);
+                            ssum[ct][r] += q;
+                            ssq[ct][r] = fmaf(q, q, ssq[ct][r]);
+                        }
+                    }
                 }
                 if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -483,10 +500,37 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
         else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
         else epilogue([&](float t) { return act_fwd(t, a.act); });
     }
+    if constexpr (STATS) {
+        // lanes of one half-wave hold the same 16*NCT channels for 32 different pixels: butterfly over the pixels,
+        // then the NW waves are folded in wave order through LDS (stage memory is free: everything has been consumed)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        float* lst = reinterpret_cast<float*>(smem);                       // [NW][2][BN]
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = ssum[ct][r], s2 = ssq[ct][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                if (j == 0) {
+                    const int c = ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                    lst[(wv * 2 + 0) * BN + c] = s1;
+                    lst[(wv * 2 + 1) * BN + c] = s2;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int k = tid / BN, c = tid % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < NW; ++w8) t += lst[(w8 * 2 + k) * BN + c];
+            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * 2 + k) * a.cout + co0 + c] = t;
+        }
+    }
 }
 
 template <typename T, int TW, int NCT, int NW>
-static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used) {
+static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry) {
     constexpr int NPIX = NW * 64, TH = NPIX / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int IN_BYTES = NHROWS * 64, W_BYTES = 9 * NCT * 32 * 64;
@@ -518,9 +562,11 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used) {
     const int lds = b.lds_bias_off + 256;
     if (lds > LDS_MAX) return RVIP_OK;
     static int attr_lds = 0;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma<T, TW, NCT, NW>),
+    if (!dry && lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma<T, TW, NCT, NW, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma<T, TW, NCT, NW, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
         attr_lds = LDS_MAX;
     }
@@ -528,17 +574,21 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used) {
     int gx = 256 / cot;                      // one workgroup per CU in total (LDS-limited), persistent over tiles
     if (gx < 1) gx = 1;
     if (gx > b.ntiles) gx = b.ntiles;
-    hipLaunchKernelGGL((conv3x3_igemm_dma<T, TW, NCT, NW>), dim3((unsigned)gx, (unsigned)cot), dim3(NW * 64), lds, s, b);
+    b.stats = stats;
+    if (rows_out) *rows_out = gx;
+    if (dry) { used = true; return RVIP_OK; }
+    if (stats) hipLaunchKernelGGL((conv3x3_igemm_dma<T, TW, NCT, NW, true>), dim3((unsigned)gx, (unsigned)cot), dim3(NW * 64), lds, s, b);
+    else hipLaunchKernelGGL((conv3x3_igemm_dma<T, TW, NCT, NW, false>), dim3((unsigned)gx, (unsigned)cot), dim3(NW * 64), lds, s, b);
     used = true;
     return check_launch();
 }
 
 template <typename T>
-static int dispatch_igemm_dma(const ConvArgs& a, hipStream_t s, bool& used) {
+static int dispatch_igemm_dma(const ConvArgs& a, hipStream_t s, bool& used, float* stats = nullptr, int* rows_out = nullptr, bool dry = false) {
     const bool two = a.cout > 32;
-    if (a.w > 16 && a.h >= 16) return two ? launch_igemm_dma<T, 32, 2, 8>(a, s, used) : launch_igemm_dma<T, 32, 1, 8>(a, s, used);
-    if (a.w > 16) return two ? launch_igemm_dma<T, 32, 2, 4>(a, s, used) : launch_igemm_dma<T, 32, 1, 4>(a, s, used);
-    return two ? launch_igemm_dma<T, 16, 2, 4>(a, s, used) : launch_igemm_dma<T, 16, 1, 4>(a, s, used);
+    if (a.w > 16 && a.h >= 16) return two ? launch_igemm_dma<T, 32, 2, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_dma<T, 32, 1, 8>(a, s, used, stats, rows_out, dry);
+    if (a.w > 16) return two ? launch_igemm_dma<T, 32, 2, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_dma<T, 32, 1, 4>(a, s, used, stats, rows_out, dry);
+    return two ? launch_igemm_dma<T, 16, 2, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_dma<T, 16, 1, 4>(a, s, used, stats, rows_out, dry);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -712,6 +762,56 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
         if (rc || used) return rc;
     }
     return d->dtype == RVIP_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
+}
+
+static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
+    if (!d || !d->x0 || !d->w_packed || !d->y) return RVIP_EINVAL;
+    const int ve = d->dtype == RVIP_BF16 ? 8 : 4;
+    if (d->dtype != RVIP_BF16 && d->dtype != RVIP_F32) return RVIP_EINVAL;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->c0 <= 0) return RVIP_EINVAL;
+    if (d->c0 % ve || d->c1 % ve || d->cout % 4) return RVIP_EINVAL;
+    if ((d->c1 > 0) != (d->x1 != nullptr)) return RVIP_EINVAL;
+    if (d->up0 && ((d->h | d->w) & 1)) return RVIP_EINVAL;
+    if (d->up0 != 0 && d->up0 != 1) return RVIP_EINVAL;
+    if (d->y1 && (d->csplit <= 0 || d->csplit >= d->cout || d->csplit % 4)) return RVIP_EINVAL;
+    if ((long long)d->n * d->h * d->w >= (1LL << 31)) return RVIP_EINVAL;
+    a.x0 = (const unsigned char*)d->x0; a.x1 = (const unsigned char*)d->x1;
+    a.wp = (const unsigned char*)d->w_packed; a.bias = d->bias;
+    a.y = (unsigned char*)d->y; a.y1 = (unsigned char*)d->y1;
+    a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0; a.csplit = d->csplit;
+    a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout; a.act = d->act;
+    a.tiles_x = a.tiles_y = 0;
+    return RVIP_OK;
+}
+
+// Number of partial-statistics rows rvip_conv3x3_fwd_stats will write for this shape (0 = this shape is served by the
+// register-staged fallback kernel, which does not fuse statistics: run rvip_bn_train_stats instead).
+extern "C" int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d) {
+    ConvArgs a;
+    if (conv_args_from_desc(d, a) != RVIP_OK || d->y1) return 0;
+    if (d->cout > 32) return 0;      // the 64-channel tile variant would exceed 256 VGPRs with the per-lane accumulators
+    static const bool force_v1 = [] { const char* e = getenv("RVIP_IGEMM"); return e && e[0] == 'v' && e[1] == '1'; }();
+    if (force_v1) return 0;
+    bool used = false; int rows = 0;
+    const int rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, nullptr, used, nullptr, &rows, true)
+                                         : dispatch_igemm_dma<float>(a, nullptr, used, nullptr, &rows, true);
+    return (rc == RVIP_OK && used) ? rows : 0;
+}
+
+// conv + per-channel partial sums (sum, sum of squares) of the stored output: stats_ws[rows][2][cout]
+extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_ws, size_t stats_ws_bytes, void* stream) {
+    (void)hipGetLastError();
+    ConvArgs a;
+    int rc = conv_args_from_desc(d, a);
+    if (rc) return rc;
+    const int rows = rvip_conv3x3_fwd_stats_rows(d);
+    if (!stats_ws || rows <= 0) return RVIP_EUNSUPPORTED;
+    if (stats_ws_bytes < (size_t)rows * 2 * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
+    bool used = false;
+    hipStream_t s = (hipStream_t)stream;
+    rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used, stats_ws) : dispatch_igemm_dma<float>(a, s, used, stats_ws);
+    if (rc) return rc;
+    return used ? RVIP_OK : RVIP_EUNSUPPORTED;
 }
 
 extern "C" int rvip_pack_conv3x3_weights(const float* w, int cin, int cout, int dtype, void* wf, void* wd, void* stream) {

@@ -786,6 +786,17 @@ extern "C" int rvip_bn_train_stats(const void* z, long long rows, int c, int dty
     return launch_fold<2, PostBnStats>(ws, g.nblk, c, p, s);
 }
 
+// Stage 2 alone: fold `rows` partial rows [rows][2][c] (sum, sum of squares; e.g. written by rvip_conv3x3_fwd_stats)
+// into mean / invstd / scale / shift and the moving statistics.  `count` = N*H*W elements per channel.
+extern "C" int rvip_bn_stats_finalize(const float* partial, int rows, long long count, int c, const float* gamma, const float* beta,
+                                      float* moving_mean, float* moving_var, float momentum, float eps, int unbiased_moving,
+                                      float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    (void)hipGetLastError();
+    if (!partial || rows <= 0 || count <= 0 || c <= 0 || !mean || !invstd || !scale || !shift) return RVIP_EINVAL;
+    PostBnStats p{gamma, beta, moving_mean, moving_var, mean, invstd, scale, shift, (double)count, momentum, eps, unbiased_moving};
+    return launch_fold<2, PostBnStats>(partial, rows, c, p, (hipStream_t)stream);
+}
+
 extern "C" int rvip_bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int c,
                                     float* scale, float* shift, void* stream) {
     (void)hipGetLastError();

@@ -18,6 +18,7 @@ Data layout in HBM (per rank)
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -295,14 +296,25 @@ class Engine:
                 d.n, d.h, d.w, d.cout, d.act, d.dtype = n, st.h, st.w, st.cout, act_conv, dt
                 self._keep.append(d)
                 call = (L.rvip_conv3x3_fwd, (C.byref(d),))
-            fwd_t.append(call)
-            fwd_i.append(call)
             # ---- BN statistics / coefficients ----
-            if st.bn:
-                fwd_t.append((L.rvip_bn_train_stats, (
-                    _ptr(z), C.c_longlong(rows), st.cout, dt, P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'),
+            fused_rows = 0
+            if st.bn and not first and os.environ.get('RVIP_FUSE_STATS', '1') != '0':
+                fused_rows = L.rvip_conv3x3_fwd_stats_rows(C.byref(d))     # > 0: the LDS-DMA igemm folds them in its epilogue
+            if fused_rows > 0:
+                fwd_t.append((L.rvip_conv3x3_fwd_stats, (C.byref(d), ws, wsb)))
+                fwd_t.append((L.rvip_bn_stats_finalize, (
+                    ws, fused_rows, C.c_longlong(rows), st.cout, P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'),
                     P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), 1,
-                    self._bn(st, 'mean'), self._bn(st, 'invstd'), self._bn(st, 'scale'), self._bn(st, 'shift'), ws, wsb)))
+                    self._bn(st, 'mean'), self._bn(st, 'invstd'), self._bn(st, 'scale'), self._bn(st, 'shift'))))
+            else:
+                fwd_t.append(call)
+            fwd_i.append(call)
+            if st.bn:
+                if fused_rows <= 0:
+                    fwd_t.append((L.rvip_bn_train_stats, (
+                        _ptr(z), C.c_longlong(rows), st.cout, dt, P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'),
+                        P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), 1,
+                        self._bn(st, 'mean'), self._bn(st, 'invstd'), self._bn(st, 'scale'), self._bn(st, 'shift'), ws, wsb)))
                 fwd_i.append((L.rvip_bn_infer_coeffs, (
                     P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'), P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'),
                     C.c_float(BN_EPS), st.cout, self._bn(st, 'scale'), self._bn(st, 'shift'))))

@@ -83,6 +83,13 @@ typedef struct rvip_conv3x3_desc {
 
 int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
 
+/* The same convolution with the BatchNormalization statistics of its (stored) output fused into the epilogue:
+ * writes rvip_conv3x3_fwd_stats_rows(d) partial rows [rows][2][cout] (per-channel sum, sum of squares) to stats_ws;
+ * finish with rvip_bn_stats_finalize.  rows == 0 means this shape runs on the register-staged fallback kernel,
+ * which does not fuse statistics (use rvip_conv3x3_fwd + rvip_bn_train_stats). */
+int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d);
+int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_ws, size_t stats_ws_bytes, void* stream);
+
 /* Re-layout the fp32 HWIO master kernel [3][3][Cin][Cout] into the two packed operands:
  *   w_fwd [9][Cout][Cin]  (w_fwd[t][o][i] = W[t][i][o])        -- forward
  *   w_dgrad [9][Cin][Cout] (w_dgrad[t][i][o] = W[8-t][i][o])   -- data gradient (taps rotated 180)
@@ -139,6 +146,12 @@ int rvip_bn_train_stats(const void* z, long long rows, int c, int dtype,
                         float* moving_mean, float* moving_var, float momentum, float eps, int unbiased_moving,
                         float* mean, float* invstd, float* scale, float* shift,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Stage 2 of the statistics alone: fold `rows` partial rows [rows][2][c] into mean/invstd/scale/shift and update the
+ * moving statistics; count = N*H*W. */
+int rvip_bn_stats_finalize(const float* partial, int rows, long long count, int c, const float* gamma, const float* beta,
+                           float* moving_mean, float* moving_var, float momentum, float eps, int unbiased_moving,
+                           float* mean, float* invstd, float* scale, float* shift, void* stream);
 
 /* Inference coefficients from the moving statistics (Model.predict: BN in inference mode). */
 int rvip_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean,

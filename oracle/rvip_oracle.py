@@ -442,6 +442,36 @@ def bf16_round(a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy().astype(a.dtype)
 
 
+def knife_edges(layers, cache, rel=3e-6):
+    """Elements at which a float32 evaluation may legitimately take the other branch of a non-smooth op: ReLU
+    pre-activations within `rel` of zero (relative to the tensor scale) and 2x2 max-pool windows whose two largest
+    entries differ by less than `rel` (exact ties excluded: first-max is deterministic).  Returns a list of
+    (layer name, count).  Used by the parity tests to tell an ill-posed comparison from a wrong kernel."""
+    out = []
+    t = cache['tensors']
+    for l in layers:
+        if l['type'] == 'Conv2D' and l.get('activation') == 'relu' and l['name'] in cache.get('pre', {}):
+            a = np.abs(cache['pre'][l['name']])
+            n = int((a < rel * max(a.max(), 1e-30)).sum())
+            if n:
+                out.append((l['name'], n))
+        elif l['type'] == 'Activation' and l.get('activation') == 'relu':
+            a = np.abs(t[l['inputs'][0]])
+            n = int((a < rel * max(a.max(), 1e-30)).sum())
+            if n:
+                out.append((l['name'], n))
+        elif l['type'] == 'MaxPooling2D':
+            x = t[l['inputs'][0]]
+            n_, h, w, c = x.shape
+            win = x[:, :h // 2 * 2, :w // 2 * 2, :].reshape(n_, h // 2, 2, w // 2, 2, c).transpose(0, 1, 3, 5, 2, 4).reshape(-1, 4)
+            srt = np.sort(win, -1)
+            gap = srt[:, 3] - srt[:, 2]
+            n = int(((gap > 0) & (gap < rel * max(np.abs(x).max(), 1e-30))).sum())
+            if n:
+                out.append((l['name'], n))
+    return out
+
+
 def landmark_argmax(heat):
     """Flat argmax per (slice, channel), row-major over (H, W), first max wins."""
     n, h, w, c = heat.shape
@@ -548,6 +578,7 @@ class OracleUNet:
                     w = self.quant(w)
                 pre = conv2d_same_fwd(ins[0], w, b)
                 out = act_fwd(pre, l['activation'])
+                cache.setdefault('pre', {})[name] = pre
                 if name == 'unet':
                     cache['logits'] = pre
             elif ty == 'Conv2DTranspose':

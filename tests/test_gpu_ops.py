@@ -134,6 +134,43 @@ def test_conv3x3_fwd_dgrad_wgrad(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 40, 72, 32, 32), (3, 16, 16, 32, 24), (2, 24, 40, 8, 8)])
+def test_conv3x3_fused_batchnorm_statistics(shape, dtype):
+    """conv + bias + ReLU with the BatchNormalization statistics of the STORED output folded into the epilogue, then
+    rvip_bn_stats_finalize: same mean / invstd / moving statistics as the two-pass kernels and the oracle."""
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(11)
+    x = rnd(rng.standard_normal((n, h, w, ci)), dtype)
+    wt = rnd(rng.standard_normal((3, 3, ci, co)) * 0.2, dtype)
+    b = rng.standard_normal(co).astype(np.float32)
+    xd, bd = up(x, dtype), f32(b)
+    wf, _ = pack(wt, dtype)
+    y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    d = conv_desc(xd, ci, 0, None, 0, wf, bd, y, None, 0, n, h, w, co, N.ACT['relu'], dtype)
+    L = N.lib()
+    rows = L.rvip_conv3x3_fwd_stats_rows(C.byref(d))
+    assert rows > 0
+    wsb = rows * 2 * co * 4
+    ws = torch.full((rows * 2 * co + 16,), 123.0, dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_fwd_stats', C.byref(d), P(ws), C.c_size_t(wsb), stream())
+    gamma = (1 + 0.3 * rng.standard_normal(co)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(co)).astype(np.float32)
+    gd, btd, mm, mv = f32(gamma), f32(beta), f32(np.zeros(co)), f32(np.ones(co))
+    mean, invstd, scale, shift = (torch.empty(co, dtype=torch.float32, device=dev()) for _ in range(4))
+    N.call('rvip_bn_stats_finalize', P(ws), rows, C.c_longlong(n * h * w), co, P(gd), P(btd), P(mm), P(mv), 0.99, 1e-3, 1,
+           P(mean), P(invstd), P(scale), P(shift), stream())
+    yq = down(y).astype(np.float64)                                   # statistics are those of the stored tensor
+    ref = O.act_fwd(O.conv2d_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), 'relu')
+    close(yq, ref, dtype, 'fwd (stats variant)')
+    _, cache = O.bn_train_fwd(yq, gamma.astype(np.float64), beta.astype(np.float64))
+    np.testing.assert_allclose(down(mean), cache[2], atol=3e-6 * max(1.0, np.abs(cache[2]).max()))
+    np.testing.assert_allclose(down(invstd), cache[1], rtol=1e-5)
+    rm, rv = O.bn_moving_update(np.zeros(co), np.ones(co), cache[2], cache[3], n * h * w)
+    np.testing.assert_allclose(down(mv), rv, rtol=1e-5)
+    np.testing.assert_allclose(down(scale), gamma * cache[1], rtol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_conv3x3_virtual_upsample_concat_and_split(dtype):
     """UpSampling2D + Conv2D and Concatenate + Conv2D as addressing modes; dgrad of the concat conv writes the
     two halves of the gradient to separate tensors."""
