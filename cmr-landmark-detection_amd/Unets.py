@@ -174,7 +174,7 @@ class UnetPlan:
                 uc = self._add('ConvTranspose', 'Conv%dDTranspose' % nd, [lower.name], up_shape + (f,),
                                int(np.prod(self.f_size)) * cin * f + f, kernel=tuple(self.f_size), strides=self.m_pool,
                                activation=self.activation, cin=cin, cout=f)
-                su = ConvStage(src0=lower.name, c0=cin, h=up_shape[0], w=up_shape[1] if nd == 2 else 0, transpose=True,
+                su = ConvStage(src0=lower.name, c0=cin, up0=2, h=up_shape[0], w=up_shape[1] if nd == 2 else 0, transpose=True,
                                conv=uc.name, act_conv=self.activation, cout=f, z=uc.name, y=uc.name)
                 self.stages.append(su)
             cat = self._add('Concatenate', 'Concatenate', [uc.name, skip.name], up_shape + (f + skip.shape[-1],))

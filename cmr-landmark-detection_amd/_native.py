@@ -93,6 +93,7 @@ SIGNATURES = {
     'rvip_bn_bwd_reduce': (C.c_int, [C.POINTER(BnBwdDesc), vp]),
     'rvip_bn_bwd_apply': (C.c_int, [C.POINTER(BnBwdDesc), vp]),
     'rvip_maxpool2x2_bwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rvip_subsample_odd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_upsample2x_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_upsample2x_bwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_head_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),

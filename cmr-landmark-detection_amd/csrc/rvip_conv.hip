@@ -43,6 +43,7 @@ struct ConvArgs {
     int c0, c1, up0, csplit;
     int n, h, w, cin, cout, act;
     int tiles_x, tiles_y;
+    int zs;                                   // zero-stuffed x2 read of source 0 (Conv2DTranspose): only odd (y, x) carry data
 };
 
 template <typename T, int TW, int NCT>
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(ConvArgs a) {
         const int hp = id >> 2;
         const int hy = hp / HWD, hx = hp - hy * HWD;
         const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-        const bool ok = (id < NHALO * 4) && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+        const bool ok = (id < NHALO * 4) && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && (!a.zs || ((gy & gx) & 1));
         pix0[i] = ok ? ((n * h0 + (gy >> a.up0)) * w0 + (gx >> a.up0)) : -1;
         pix1[i] = ok ? ((n * a.h + gy) * a.w + gx) : -1;
     }
@@ -264,6 +265,7 @@ struct ConvArgs2 {
     int n, h, w, cin, cout, act;
     int tiles_x, tiles_y, ntiles, wres;      // wres: weight stages resident (= nchunks) or 0 -> 2 rotating stages
     int lds_bias_off;
+    int zs;
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
 };
 
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
                 const int gy = ty0 + (hyx[i] >> 16), gx = tx0 + (hyx[i] & 0xffff);
                 const int c = cb + pslot[i];
                 unsigned off = OOB;
-                if (hyx[i] >= 0 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && c < csrc)
+                if (hyx[i] >= 0 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && c < csrc && (!(from0 && a.zs) || ((gy & gx) & 1)))
                     off = (unsigned)((((n * hs + (gy >> sh)) * wsrc + (gx >> sh)) * csrc + c) * (int)sizeof(T));
                 dma16(rs, off, lds_base + stage * IN_BYTES + q * 1024);
             }
@@ -552,7 +554,7 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -744,14 +746,14 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
     if (d->c0 % ve || d->c1 % ve || d->cout % 4) return RVIP_EINVAL;
     if ((d->c1 > 0) != (d->x1 != nullptr)) return RVIP_EINVAL;
     if (d->up0 && ((d->h | d->w) & 1)) return RVIP_EINVAL;
-    if (d->up0 != 0 && d->up0 != 1) return RVIP_EINVAL;
+    if (d->up0 < 0 || d->up0 > 2 || (d->up0 == 2 && d->c1 > 0)) return RVIP_EINVAL;
     if (d->y1 && (d->csplit <= 0 || d->csplit >= d->cout || d->csplit % 4)) return RVIP_EINVAL;
     if ((long long)d->n * d->h * d->w >= (1LL << 31)) return RVIP_EINVAL;
     ConvArgs a;
     a.x0 = (const unsigned char*)d->x0; a.x1 = (const unsigned char*)d->x1;
     a.wp = (const unsigned char*)d->w_packed; a.bias = d->bias;
     a.y = (unsigned char*)d->y; a.y1 = (unsigned char*)d->y1;
-    a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0; a.csplit = d->csplit;
+    a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0 ? 1 : 0; a.zs = d->up0 == 2; a.csplit = d->csplit;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout; a.act = d->act;
     a.tiles_x = a.tiles_y = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -772,13 +774,13 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     if (d->c0 % ve || d->c1 % ve || d->cout % 4) return RVIP_EINVAL;
     if ((d->c1 > 0) != (d->x1 != nullptr)) return RVIP_EINVAL;
     if (d->up0 && ((d->h | d->w) & 1)) return RVIP_EINVAL;
-    if (d->up0 != 0 && d->up0 != 1) return RVIP_EINVAL;
+    if (d->up0 < 0 || d->up0 > 2 || (d->up0 == 2 && d->c1 > 0)) return RVIP_EINVAL;
     if (d->y1 && (d->csplit <= 0 || d->csplit >= d->cout || d->csplit % 4)) return RVIP_EINVAL;
     if ((long long)d->n * d->h * d->w >= (1LL << 31)) return RVIP_EINVAL;
     a.x0 = (const unsigned char*)d->x0; a.x1 = (const unsigned char*)d->x1;
     a.wp = (const unsigned char*)d->w_packed; a.bias = d->bias;
     a.y = (unsigned char*)d->y; a.y1 = (unsigned char*)d->y1;
-    a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0; a.csplit = d->csplit;
+    a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0 ? 1 : 0; a.zs = d->up0 == 2; a.csplit = d->csplit;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout; a.act = d->act;
     a.tiles_x = a.tiles_y = 0;
     return RVIP_OK;

@@ -480,6 +480,23 @@ __global__ __launch_bounds__(256) void upsample_kernel(const unsigned char* __re
     }
 }
 
+// dst[n][i][j] = src[n][2i+1][2j+1]: data gradient of the zero-stuffed read (Conv2DTranspose backward)
+template <typename T>
+__global__ __launch_bounds__(256) void subsample_odd_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                            int n, int h, int w, int c) {   // h, w = LOW resolution
+    constexpr int VE = Vec<T>::VE;
+    const int cg = c / VE;
+    const long long idx = blockIdx.x * 256LL + threadIdx.x;
+    const int cv = (int)(idx % cg);
+    const long long q = idx / cg;
+    if (q >= (long long)n * h * w) return;
+    const int x = (int)(q % w), yy = (int)((q / w) % h);
+    const long long img = q / ((long long)w * h);
+    float v[VE];
+    Vec<T>::load(src + ((((size_t)img * 2 * h + 2 * yy + 1) * 2 * w + 2 * x + 1) * c + cv * VE) * sizeof(T), v);
+    Vec<T>::store(dst + ((size_t)q * c + cv * VE) * sizeof(T), v);
+}
+
 // ------------------------------------------------------------------------------------------------
 // head: 1x1 conv + sigmoid, loss sums, loss gradient, backward
 // ------------------------------------------------------------------------------------------------
@@ -921,6 +938,17 @@ extern "C" int rvip_upsample2x_fwd(const void* x, void* y, int n, int h, int w, 
 extern "C" int rvip_upsample2x_bwd(const void* dy, void* dx, int n, int h, int w, int c, int dtype, void* stream) {
     (void)hipGetLastError();
     return launch_upsample<true>(dy, dx, n, h, w, c, dtype, stream);
+}
+
+extern "C" int rvip_subsample_odd(const void* src, void* dst, int n, int h, int w, int c, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!src || !dst || !RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % RVIP_VE(dtype)) return RVIP_EINVAL;
+    const long long total = (long long)n * h * w * (c / RVIP_VE(dtype));
+    dim3 grid((unsigned)cdiv(total, 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(subsample_odd_kernel<bf16_t>, grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
+    else hipLaunchKernelGGL(subsample_odd_kernel<float>, grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
+    return check_launch();
 }
 
 struct PostHeadSums {

@@ -22,6 +22,7 @@ struct WgArgs {
     int c0, c1, up0;
     int n, h, w, cin, cout;
     int tiles_x, tiles_y, ntiles, nsplit;
+    int zs;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(WgArgs a) {
                 if ((unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w) {
                     if (c < a.c0) {
                         const size_t pix = ((size_t)n * h0 + (gy >> a.up0)) * w0 + (gx >> a.up0);
-                        r = *reinterpret_cast<const uint4*>(a.x0 + (pix * a.c0 + c) * sizeof(T));
+                        if (!a.zs || ((gy & gx) & 1)) r = *reinterpret_cast<const uint4*>(a.x0 + (pix * a.c0 + c) * sizeof(T));
                     } else if (c < a.cin) {
                         const size_t pix = ((size_t)n * a.h + gy) * a.w + gx;
                         r = *reinterpret_cast<const uint4*>(a.x1 + (pix * a.c1 + (c - a.c0)) * sizeof(T));
@@ -189,6 +190,7 @@ struct WgArgs2 {
     int c0, c1, up0;
     int n, h, w, cin, cout;
     int tiles_x, tiles_y, ntiles, nsplit;
+    int zs;
 };
 
 template <typename T, int TW, int CIB, int COB>
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
             if (q < NQX) {
                 const int gy = ty0 - 1 + (xhyx[i] >> 16), gx = tx0 - 1 + (xhyx[i] & 0xffff);
                 unsigned off = OOB;
-                if (xhyx[i] >= 0 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && xch[i] < csrc)
+                if (xhyx[i] >= 0 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && xch[i] < csrc && (!(from0 && a.zs) || ((gy & gx) & 1)))
                     off = (unsigned)((((n * hs + (gy >> shf)) * wsrc + (gx >> shf)) * csrc + xch[i]) * ESZ);
                 dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
             }
@@ -493,12 +495,12 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->c0 <= 0) return RVIP_EINVAL;
     if (d->c0 % ve || d->c1 % ve || d->cout % ve) return RVIP_EINVAL;
     if ((d->c1 > 0) != (d->x1 != nullptr)) return RVIP_EINVAL;
-    if (d->up0 != 0 && d->up0 != 1) return RVIP_EINVAL;
+    if (d->up0 < 0 || d->up0 > 2 || (d->up0 == 2 && d->c1 > 0)) return RVIP_EINVAL;
     if (d->up0 && ((d->h | d->w) & 1)) return RVIP_EINVAL;
     WgArgs a;
     a.x0 = (const unsigned char*)d->x0; a.x1 = (const unsigned char*)d->x1; a.dy = (const unsigned char*)d->dy;
     a.slab = (float*)d->workspace;
-    a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0;
+    a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0 ? 1 : 0; a.zs = d->up0 == 2;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout;
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -511,7 +513,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
         WgArgs2 b;
         b.x0 = a.x0; b.x1 = a.x1; b.dy = a.dy; b.slab = a.slab;
         b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.dy_bytes = (unsigned)dyb;
-        b.c0 = a.c0; b.c1 = a.c1; b.up0 = a.up0; b.n = a.n; b.h = a.h; b.w = a.w; b.cin = a.cin; b.cout = a.cout;
+        b.c0 = a.c0; b.c1 = a.c1; b.up0 = a.up0; b.zs = a.zs; b.n = a.n; b.h = a.h; b.w = a.w; b.cin = a.cin; b.cout = a.cout;
         b.tiles_x = g2.tiles_x; b.tiles_y = g2.tiles_y; b.ntiles = g2.ntiles; b.nsplit = g2.nsplit;
         if (d->workspace_bytes < (size_t)b.nsplit * 9 * a.cin * a.cout * sizeof(float)) return RVIP_EWORKSPACE;
         if (d->dtype == RVIP_BF16) {

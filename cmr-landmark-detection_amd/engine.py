@@ -77,10 +77,10 @@ class ParamStore:
         # packed MFMA operands of every 3x3 conv in two flat blocks + a device table for the one-launch re-layout
         self.packed = {}
         entries, off = [], 0
+        # Conv2DTranspose(3, strides=2, 'same') layers (USE_UPSAMPLE=False) are kept on the device as the EQUIVALENT forward
+        # conv over the zero-stuffed input: Weq[t][ci][co] = W_hwoi[2-t][co][ci] (taps reversed, last two axes swapped)
+        self.transposed = {st.conv for st in plan.stages if st.transpose}
         for st in plan.stages:
-            if st.transpose:
-                raise NotImplementedError('USE_UPSAMPLE=False (Conv2DTranspose decoder, KerasLayers.py:761-765) is not built '
-                                          'yet; the default UpSampling+Conv path is')
             if st.src0 != 'input_1':
                 k = 9 * st.cin * st.cout
                 entries.append((st.conv, self.off[(st.conv, 'kernel')][0], off, st.cin, st.cout))
@@ -104,9 +104,12 @@ class ParamStore:
         th = np.zeros(self.count, np.float32)
         mv = np.zeros(self.moving.numel(), np.float32)
         for (lname, wname, shape, trainable, _), arr in zip(self.plan.weight_specs(), host_weights):
-            a = np.asarray(arr, np.float32).reshape(-1)
+            a = np.asarray(arr, np.float32)
             if a.size != int(np.prod(shape)):
                 raise ValueError('weight %s/%s: expected shape %s' % (lname, wname, (shape,)))
+            if wname == 'kernel' and lname in self.transposed:
+                a = self._to_equivalent(a.reshape(shape))
+            a = np.ascontiguousarray(a).reshape(-1)
             if trainable:
                 o = self.off[(lname, wname)][0]
                 th[o:o + a.size] = a
@@ -124,12 +127,22 @@ class ParamStore:
         for (lname, wname, shape, trainable, _) in self.plan.weight_specs():
             size = int(np.prod(shape))
             src, o = (th, self.off[(lname, wname)][0]) if trainable else (mv, self.moff[(lname, wname)][0])
-            out.append(src[o:o + size].reshape(shape).copy())
+            out.append(self._from_device(lname, wname, src[o:o + size], shape))
         return out
+
+    @staticmethod
+    def _to_equivalent(w_hwoi):
+        return np.ascontiguousarray(w_hwoi[::-1, ::-1].transpose(0, 1, 3, 2))
+
+    def _from_device(self, lname, wname, flat, shape):
+        if wname == 'kernel' and lname in self.transposed:
+            kh, kw, co, ci = shape
+            return np.ascontiguousarray(flat.reshape(kh, kw, ci, co).transpose(0, 1, 3, 2)[::-1, ::-1])
+        return flat.reshape(shape).copy()
 
     def grads_host(self):
         g = self.grad.detach().cpu().numpy()
-        return OrderedDict((k, g[o:o + int(np.prod(s))].reshape(s).copy()) for k, (o, s) in self.off.items())
+        return OrderedDict(((ln, wn), self._from_device(ln, wn, g[o:o + int(np.prod(s))], s)) for (ln, wn), (o, s) in self.off.items())
 
     def p(self, lname, wname):
         return _ptr(self.theta, self.off[(lname, wname)][0])
@@ -415,9 +428,9 @@ class Engine:
                 dg.y = self.grd[st.src0].data_ptr()
             self._keep.append(dg)
             bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
-            if st.up0:
-                bwd.append((L.rvip_upsample2x_bwd, (_ptr(self.up_tmp[st.conv]), _ptr(self.grd[st.src0]), n, st.h // 2, st.w // 2,
-                                                    st.c0, dt)))
+            if st.up0:                      # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions
+                back = L.rvip_upsample2x_bwd if st.up0 == 1 else L.rvip_subsample_odd
+                bwd.append((back, (_ptr(self.up_tmp[st.conv]), _ptr(self.grd[st.src0]), n, st.h // 2, st.w // 2, st.c0, dt)))
         self.fwd_train, self.fwd_infer, self.bwd = fwd_t, fwd_i, bwd
         self.opt = [(L.rvip_adam_step, (_ptr(P.theta), _ptr(P.grad), _ptr(P.adam_m), _ptr(P.adam_v), C.c_longlong(P.count),
                                         C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0), _ptr(P.state)))]

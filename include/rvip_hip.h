@@ -62,7 +62,11 @@ int         rvip_last_hip_error(void);      /* last hipError_t seen by a launche
  * 3x3 "same" convolution as implicit GEMM on MFMA.  Replaces Conv2D(filters, 3, padding='same',
  * activation=act) -- KerasLayers.py:683,689 (conv_layer_fn) and :758 (up-conv) -- including the
  * UpSampling2D (:756-757) and Concatenate (:767) in front of it, which are addressing modes here:
- *   source 0: x0 [N, H>>up0, W>>up0, C0]   (up0 = 1: nearest-neighbour x2 read, y[h,w] = x[h/2,w/2])
+ *   source 0: x0 [N, H>>(up0!=0), W>>(up0!=0), C0]
+ *             up0 = 1: nearest-neighbour x2 read, v[h,w] = x[h/2,w/2]          (UpSampling2D)
+ *             up0 = 2: zero-stuffed x2 read, v[2i+1,2j+1] = x[i,j], 0 elsewhere (Conv2DTranspose(3, strides=2,
+ *                      'same'), KerasLayers.py:761-765: out[j] = sum_{2i+k=j} in[i] W[k] is this conv with taps
+ *                      reversed; the host keeps the layer's master kernel in that equivalent HWIO form)
  *   source 1: x1 [N, H, W, C1] or NULL     (channels C0.. of the virtual concat [x0, x1])
  * Output y [N,H,W,Cout] = act(conv + bias).  With y1 != NULL the output channels are split:
  * [0,csplit) -> y (row stride csplit), [csplit,Cout) -> y1 (row stride Cout-csplit); used by the
@@ -200,6 +204,9 @@ int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);
  * NULL; it carries the skip-connection gradient that reaches the same tensor). */
 int rvip_maxpool2x2_bwd(const void* y, const void* dpooled, const void* add, void* dx,
                         int n, int h, int w, int c, int dtype, void* stream);
+
+/* Data gradient of the zero-stuffed read: dst[n,i,j] = src[n,2i+1,2j+1]  (h, w = low-resolution extents). */
+int rvip_subsample_odd(const void* src, void* dst, int n, int h, int w, int c, int dtype, void* stream);
 
 /* UpSampling2D(2) forward (materialised; the conv reads it virtually) and backward (2x2 sum). */
 int rvip_upsample2x_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream);

@@ -52,6 +52,7 @@ VARIANTS = [
     dict(BATCH_NORMALISATION=False, ACTIVATION='elu'),
     dict(DEPTH=3, DIM=[48, 40], LOSS_FUNCTION=M.bce_dice_loss),
     dict(LOSS_FUNCTION=M.BceDiceLoss(), FILTERS=12),
+    dict(USE_UPSAMPLE=False),                       # Conv2DTranspose decoder (KerasLayers.py:761-765)
 ]
 
 

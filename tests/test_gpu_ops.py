@@ -217,6 +217,49 @@ def test_conv3x3_virtual_upsample_concat_and_split(dtype):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 12, 20, 16, 8), (1, 8, 8, 8, 24)])
+def test_conv2d_transpose_as_zero_stuffed_conv(shape, dtype):
+    """Conv2DTranspose(3, strides=2, 'same') = the 3x3 igemm over the zero-stuffed read (up0 = 2) with the kernel in its
+    equivalent forward form Weq[t][ci][co] = W_hwoi[2-t][co][ci]; forward, input gradient (odd-position gather of the
+    data gradient) and weight gradient against the oracle's transpose-conv."""
+    n, hl, wl, ci, co = shape                       # low-resolution input
+    h, w = 2 * hl, 2 * wl
+    rng = np.random.default_rng(21)
+    x = rnd(rng.standard_normal((n, hl, wl, ci)), dtype)
+    wt = rnd(rng.standard_normal((3, 3, co, ci)) * 0.2, dtype)          # Keras HWOI
+    b = rng.standard_normal(co).astype(np.float32)
+    weq = np.ascontiguousarray(wt[::-1, ::-1].transpose(0, 1, 3, 2))    # [3][3][ci][co]
+    wf, wd = pack(weq, dtype)
+    xd, bd = up(x, dtype), f32(b)
+    y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    d = conv_desc(xd, ci, 2, None, 0, wf, bd, y, None, 0, n, h, w, co, 0, dtype)
+    N.call('rvip_conv3x3_fwd', C.byref(d), stream())
+    ref = O.conv2d_transpose_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    close(down(y), ref, dtype, 'transpose fwd')
+    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
+    rdx, rdw, _ = O.conv2d_transpose_same_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64))
+    dyd = up(dy, dtype)
+    gfull = torch.empty((n, h, w, ci), dtype=tdt(dtype), device=dev())
+    d2 = conv_desc(dyd, co, 0, None, 0, wd, None, gfull, None, 0, n, h, w, ci, 0, dtype)
+    N.call('rvip_conv3x3_fwd', C.byref(d2), stream())
+    dx = torch.empty((n, hl, wl, ci), dtype=tdt(dtype), device=dev())
+    N.call('rvip_subsample_odd', P(gfull), P(dx), n, hl, wl, ci, ndt(dtype), stream())
+    close(down(dx), rdx, dtype, 'transpose dgrad')
+    L = N.lib()
+    wsb = L.rvip_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.empty((3, 3, ci, co), dtype=torch.float32, device=dev())
+    g = N.Wgrad3x3Desc()
+    g.x0, g.c0, g.up0, g.x1, g.c1 = xd.data_ptr(), ci, 2, None, 0
+    g.dy, g.dw = dyd.data_ptr(), dw.data_ptr()
+    g.n, g.h, g.w, g.cout, g.dtype = n, h, w, co, ndt(dtype)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
+    N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+    dw_hwoi = down(dw).transpose(0, 1, 3, 2)[::-1, ::-1]                  # back to Keras' layout
+    assert np.abs(dw_hwoi - rdw).max() <= (2e-3 if dtype == 'bf16' else 2e-5) * np.abs(rdw).max()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_first_layer_c1(dtype):
     n, h, w, co = 2, 20, 36, 16
     rng = np.random.default_rng(4)
