@@ -303,51 +303,63 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
     // DMA lane geometry: lane -> (row within the 16-row piece, physical 16-byte slot)
     const int drow = lane >> 2, dslot = lane & 3;
 
-    auto issue_weights = [&](int kc, int wstage) {
+    int wrel[QW], wch[QW];
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int row = (wv + NW * i) * 16 + drow;
+        const int tap = row / BN, co = co0 + (row & (BN - 1));
+        wch[i] = (co < a.cout && row < WROWS) ? (dslot ^ ((row >> 2) & 3)) * VE : 1 << 28;   // dead rows fail the channel test
+        wrel[i] = (((tap * a.cout + co) * a.cin) + (dslot ^ ((row >> 2) & 3)) * VE) * (int)sizeof(T);
+    }
+    auto issue_weights = [&](int kc, int wstage) __attribute__((always_inline)) {
+        const int cbase = kc * KCE;
 #pragma unroll
         for (int i = 0; i < QW; ++i) {
             const int q = wv + NW * i;
             if (q < NQW) {
-                const int row = q * 16 + drow;
-                const int tap = row / BN, co = co0 + (row & (BN - 1));
-                const int p = dslot ^ ((row >> 2) & 3);
-                const int c = kc * KCE + p * VE;
-                unsigned off = OOB;
-                if (co < a.cout && c < a.cin) off = (unsigned)(((tap * a.cout + co) * a.cin + c) * (int)sizeof(T));
+                const unsigned off = (wch[i] < a.cin - cbase) ? (unsigned)(wrel[i] + cbase * (int)sizeof(T)) : OOB;
                 dma16(rsw, off, lds_base + 2 * IN_BYTES + wstage * W_BYTES + q * 1024);
             }
         }
     };
-    // per-lane halo coordinates of each DMA piece this wave issues (tile independent): (hy << 16) | hx, -1 = pad row
-    int hyx[QI], pslot[QI];
+    // Per-lane geometry of each DMA piece this wave issues (tile independent).  Byte offset of a piece =
+    // tile/chunk base (wave-uniform) + rel (per lane); tiles start on even coordinates so the x2 reads stay linear:
+    // ((ty0 - 1 + hy) >> 1) = ty0/2 + ((hy - 1) >> 1).  Validity = a few compares folded into one select.
+    int ihy[QI], ihx[QI], irel0[QI], ich[QI];
 #pragma unroll
     for (int i = 0; i < QI; ++i) {
         const int row = (wv + NW * i) * 16 + drow;
         const int hy = row / HWD, hx = row - hy * HWD;
-        hyx[i] = (row < NHALO) ? ((hy << 16) | hx) : -1;
-        pslot[i] = (dslot ^ ((row >> 2) & 3)) * VE;              // first channel (within the chunk) of my 16-byte piece
+        ich[i] = (dslot ^ ((row >> 2) & 3)) * VE;                 // first channel (within the chunk) of my 16-byte piece
+        ihy[i] = (row < NHALO) ? hy - 1 : -100000;
+        ihx[i] = hx - 1;
+        irel0[i] = ((((hy - 1) >> a.up0) * w0 + ((hx - 1) >> a.up0)) * a.c0 + ich[i]) * (int)sizeof(T);
     }
-    auto issue_input = [&](int tile, int kc, int stage) {
+    auto issue_input = [&](int tile, int kc, int stage) __attribute__((always_inline)) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
         const int n = bx / a.tiles_y;
-        const int ty0 = ty_i * TH - 1, tx0 = tx_i * TW - 1;
+        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
         const int cbase = kc * KCE;
         const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
-        const int csrc = from0 ? a.c0 : a.c1;
         const int cb = from0 ? cbase : cbase - a.c0;
-        const int hs = from0 ? h0 : a.h, wsrc = from0 ? w0 : a.w, sh = from0 ? a.up0 : 0;
+        const int crem = (from0 ? a.c0 : a.c1) - cb;     // channels of this source left from the chunk start
+        const int base = from0 ? (((n * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 + cb) * (int)sizeof(T)
+                               : (((n * a.h + ty0) * a.w + tx0) * a.c1 + cb) * (int)sizeof(T);
+        const bool zs = from0 && a.zs;
         const i32x4 rs = from0 ? rs0 : rs1;
 #pragma unroll
         for (int i = 0; i < QI; ++i) {
             const int q = wv + NW * i;
             if (q < NQI) {
-                const int gy = ty0 + (hyx[i] >> 16), gx = tx0 + (hyx[i] & 0xffff);
-                const int c = cb + pslot[i];
-                unsigned off = OOB;
-                if (hyx[i] >= 0 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && c < csrc && (!(from0 && a.zs) || ((gy & gx) & 1)))
-                    off = (unsigned)((((n * hs + (gy >> sh)) * wsrc + (gx >> sh)) * csrc + c) * (int)sizeof(T));
+                const int gy = ty0 + ihy[i], gx = tx0 + ihx[i];
+                bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && ich[i] < crem;
+                if (zs) ok = ok && ((gy & gx) & 1);
+                // (no `from0 ? irel0[i] : irel1[i]`: hipcc turns a select between two register arrays into scratch indexing)
+                int rel = irel0[i];
+                if (!from0) rel = ((ihy[i] * a.w + ihx[i]) * a.c1 + ich[i]) * (int)sizeof(T);
+                const unsigned off = ok ? (unsigned)(base + rel) : OOB;
                 dma16(rs, off, lds_base + stage * IN_BYTES + q * 1024);
             }
         }

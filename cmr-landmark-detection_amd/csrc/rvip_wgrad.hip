@@ -223,40 +223,51 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
     const i32x4w rsg = make_rsrc_w(a.dy, a.dy_bytes);
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
 
-    // tile-independent lane geometry of the DMA pieces this wave issues
+    // Tile-independent lane geometry of the DMA pieces this wave issues.  A piece's byte offset is
+    //   tile_base (wave-uniform) + rel (per lane, precomputed)      -- also for the x2 reads: tiles start on even
+    // coordinates, so ((ty0 - 1 + hy) >> 1) = ty0/2 + ((hy - 1) >> 1) -- and validity is a handful of compares
+    // folded into one select (no branches in the per-tile issue code).
     constexpr int SLX = RBX / 16, RPPX = 1024 / RBX, SLG = RBG / 16, RPPG = 1024 / RBG;
     const int csrc = from0 ? a.c0 : a.c1, cb0 = from0 ? ci0 : ci0 - a.c0;
     const int hs = from0 ? h0 : a.h, wsrc = from0 ? w0 : a.w, shf = from0 ? a.up0 : 0;
-    int xhyx[QX], xch[QX], gyx[QG], gch[QG];
+    const bool zsx = from0 && a.zs;
+    int xhy[QX], xhx[QX], xrel[QX], grel[QG], gpy[QG], gpx[QG];
 #pragma unroll
     for (int i = 0; i < QX; ++i) {
         const int row = (wv + 4 * i) * RPPX + lane / SLX, slot = lane % SLX;
         const int hy = row / HWD, hx = row - hy * HWD;
-        const int p = (RBX == 128) ? ((((slot >> 2) ^ ((row >> 1) & 1)) << 2) | (slot & 3)) : slot;
-        xhyx[i] = (row < NHALO) ? ((hy << 16) | hx) : -1;
-        xch[i] = cb0 + p * VE;
+        const int p = (RBX == 128) ? ((((slot >> 2) ^ ((hx >> 1) & 1)) << 2) | (slot & 3)) : slot;   // swizzle by the halo x coordinate
+        const int c = cb0 + p * VE;
+        const bool ok = row < NHALO && c < csrc;
+        xhy[i] = ok ? hy - 1 : -100000;                           // a statically dead piece fails the range test below
+        xhx[i] = hx - 1;
+        xrel[i] = ((((hy - 1) >> shf) * wsrc + ((hx - 1) >> shf)) * csrc + c) * ESZ;
     }
 #pragma unroll
     for (int i = 0; i < QG; ++i) {
         const int P = (wv + 4 * i) * RPPG + lane / SLG, slot = lane % SLG;
         const int p = (RBG == 128) ? ((((slot >> 2) ^ ((P >> 1) & 1)) << 2) | (slot & 3)) : slot;
-        gyx[i] = ((P / TW) << 16) | (P % TW);
-        gch[i] = co0 + p * VE;
+        const int c = co0 + p * VE;
+        gpy[i] = (c < a.cout) ? P / TW : -100000;
+        gpx[i] = P % TW;
+        grel[i] = (((P / TW) * a.w + (P % TW)) * a.cout + c) * ESZ;
     }
-    auto issue = [&](int tile, int stage) {
+    auto issue = [&](int tile, int stage) __attribute__((always_inline)) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
         const int n = bx / a.tiles_y;
         const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+        const int xbase = ((n * hs + (ty0 >> shf)) * wsrc + (tx0 >> shf)) * csrc * ESZ;
+        const int gbase = ((n * a.h + ty0) * a.w + tx0) * a.cout * ESZ;
 #pragma unroll
         for (int i = 0; i < QX; ++i) {
             const int q = wv + 4 * i;
             if (q < NQX) {
-                const int gy = ty0 - 1 + (xhyx[i] >> 16), gx = tx0 - 1 + (xhyx[i] & 0xffff);
-                unsigned off = OOB;
-                if (xhyx[i] >= 0 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && xch[i] < csrc && (!(from0 && a.zs) || ((gy & gx) & 1)))
-                    off = (unsigned)((((n * hs + (gy >> shf)) * wsrc + (gx >> shf)) * csrc + xch[i]) * ESZ);
+                const int gy = ty0 + xhy[i], gx = tx0 + xhx[i];
+                bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+                if (zsx) ok = ok && ((gy & gx) & 1);
+                const unsigned off = ok ? (unsigned)(xbase + xrel[i]) : OOB;
                 dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
             }
         }
@@ -264,9 +275,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
         for (int i = 0; i < QG; ++i) {
             const int q = wv + 4 * i;
             if (q < NQG) {
-                const int gy = ty0 + (gyx[i] >> 16), gx = tx0 + (gyx[i] & 0xffff);
-                unsigned off = OOB;
-                if (gy < a.h && gx < a.w && gch[i] < a.cout) off = (unsigned)((((n * a.h + gy) * a.w + gx) * a.cout + gch[i]) * ESZ);
+                const int gy = ty0 + gpy[i], gx = tx0 + gpx[i];
+                const bool ok = (unsigned)gy < (unsigned)a.h && gx < a.w;
+                const unsigned off = ok ? (unsigned)(gbase + grel[i]) : OOB;
                 dma16w(rsg, off, lds_base + stage * ST_BYTES + X_BYTES + q * 1024);
             }
         }
@@ -286,33 +297,39 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
         const unsigned char* lx = smem + (it & 1) * ST_BYTES;
         const unsigned char* lg = lx + X_BYTES;
         if constexpr (ESZ == 2) {
+            // Every transposed read of the tile = one of 6 (X) / 2 (G) per-lane base addresses + a compile-time offset:
+            // the 64-byte-half swizzle of a 128-byte row depends only on bit 1 of the halo x coordinate, which is the
+            // same for every k-step (k-steps start on multiples of 16 pixels) and every tap ROW; only the tap COLUMN
+            // (tx = 0..2) changes it.  No address arithmetic is left between the MFMAs.
+            constexpr int STEPS = 16 / PSPLIT;
             const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, grp = lane >> 4;
             const int kk = 8 * (grp >> 1) + q4;
             const int cb = (16 * (grp & 1) + 4 * p4) * 2;
-            constexpr int STEPS = 16 / PSPLIT;
-#pragma unroll 2
-            for (int s = 0; s < STEPS; ++s) {
-                int gaddr[2], xrow[2];
+            const int wave_px = part * STEPS * 16;                       // first pixel of this wave's share (multiple of 64)
+            const unsigned char* xp[3][2];
+            const unsigned char* gp[2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int P = (part * STEPS + s) * 16 + kk + 4 * u;
-                    gaddr[u] = P * RBG + ((RBG == 128) ? ((co_t ^ ((P >> 1) & 1)) << 6) : 0) + cb;
-                    xrow[u] = (P / TW) * HWD + (P % TW);
+            for (int u = 0; u < 2; ++u) {
+                const int pxl = kk + 4 * u;                              // x within the k-step (0..15)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const int hx = pxl + tx;
+                    xp[tx][u] = lx + ((wave_px / TW) * HWD + hx) * RBX + ((RBX == 128) ? ((ci_t ^ ((hx >> 1) & 1)) << 6) : 0) + cb;
                 }
-                const s16x4 g0 = tr_read(lg + gaddr[0]);
-                const s16x4 g1 = tr_read(lg + gaddr[1]);
+                gp[u] = lg + (wave_px + pxl) * RBG + ((RBG == 128) ? ((co_t ^ ((pxl >> 1) & 1)) << 6) : 0) + cb;
+            }
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                constexpr int dummy = 0; (void)dummy;
+                const int srow = (s * 16) / TW, scol = (s * 16) % TW;     // compile-time after unrolling
+                const s16x4 g0 = tr_read(gp[0] + s * 16 * RBG);
+                const s16x4 g1 = tr_read(gp[1] + s * 16 * RBG);
                 const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int trow = (t / 3) * HWD + (t % 3);
-                    int xa[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int rr = xrow[u] + trow;
-                        xa[u] = rr * RBX + ((RBX == 128) ? ((ci_t ^ ((rr >> 1) & 1)) << 6) : 0) + cb;
-                    }
-                    const s16x4 x0 = tr_read(lx + xa[0]);
-                    const s16x4 x1 = tr_read(lx + xa[1]);
+                    const int off = ((srow + t / 3) * HWD + scol) * RBX;
+                    const s16x4 x0 = tr_read(xp[t % 3][0] + off);
+                    const s16x4 x1 = tr_read(xp[t % 3][1] + off);
                     const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
                 }
@@ -324,12 +341,13 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
 #pragma unroll 2
             for (int s = 0; s < STEPS; ++s) {
                 const int P = (part * STEPS + s) * 2 + hf;
-                const float g = *reinterpret_cast<const float*>(lg + P * RBG + ((chalf ^ ((P >> 1) & 1)) << 6) + choff);
-                const int xr = (P / TW) * HWD + (P % TW);
+                const int py = P / TW, px = P % TW;
+                const float g = *reinterpret_cast<const float*>(lg + P * RBG + ((chalf ^ ((px >> 1) & 1)) << 6) + choff);
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int rr = xr + (t / 3) * HWD + (t % 3);
-                    const float x = *reinterpret_cast<const float*>(lx + rr * RBX + ((chalf ^ ((rr >> 1) & 1)) << 6) + choff);
+                    const int hx = px + t % 3;
+                    const int rr = (py + t / 3) * HWD + hx;
+                    const float x = *reinterpret_cast<const float*>(lx + rr * RBX + ((chalf ^ ((hx >> 1) & 1)) << 6) + choff);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, g, acc[t], 0, 0, 0);
                 }
             }
