@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librvip_hip.so')
+LIB_PATH = os.environ.get('RVIP_LIB') or os.path.join(_HERE, 'librvip_hip.so')     # RVIP_LIB: A/B another build of the same ABI
 
 F32, BF16 = 0, 1
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'elu': 2, 'sigmoid': 3}

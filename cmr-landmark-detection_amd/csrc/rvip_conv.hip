@@ -330,7 +330,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
     for (int i = 0; i < QI; ++i) {
         const int row = (wv + NW * i) * 16 + drow;
         const int hy = row / HWD, hx = row - hy * HWD;
-        ich[i] = (dslot ^ ((row >> 2) & 3)) * VE;                 // first channel (within the chunk) of my 16-byte piece
+        ich[i] = (dslot ^ ((hx >> 2) & 3)) * VE;                  // first channel (within the chunk) of my 16-byte piece;
+                                                                  // slot swizzle by the halo x coordinate (tap-row invariant)
         ihy[i] = (row < NHALO) ? hy - 1 : -100000;
         ihx[i] = hx - 1;
         irel0[i] = ((((hy - 1) >> a.up0) * w0 + ((hx - 1) >> a.up0)) * a.c0 + ich[i]) * (int)sizeof(T);
@@ -365,12 +366,20 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
         }
     };
 
-    // fragment read addresses (stage-relative).  pixel row r0 (+ tap rows); piece p = 2g + hf
-    int r0[2];
+    // Fragment read addresses (stage-relative): one per-lane base per (pixel tile, tap COLUMN, k-half g) + compile-time
+    // offsets for the tap row.  The slot swizzle of a halo row depends only on its x coordinate, so it does not change
+    // with the tap row; piece p = 2g + hf sits in slot p ^ ((hx >> 2) & 3).
+    int in_base[2][3][2];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const int P = wv * 64 + pt * 32 + j;
-        r0[pt] = (P / TW) * HWD + (P % TW);
+        const int py = P / TW, px = P % TW;
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int hx = px + tx;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) in_base[pt][tx][g] = (py * HWD + hx) * 64 + (((2 * g + hf) ^ ((hx >> 2) & 3)) << 4);
+        }
     }
     int w_addr[NCT];
 #pragma unroll
@@ -426,20 +435,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
             const unsigned char* sw = lw + (resident ? kc : (it & 1)) * W_BYTES;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int trow = (tap / 3) * HWD + (tap % 3);
-                int in_addr[2];
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    const int r = r0[pt] + trow;
-                    in_addr[pt] = r * 64 + ((hf ^ ((r >> 2) & 3)) << 4);
-                }
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     uint4 fa[NCT], fb[2];
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) fa[ct] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + (w_addr[ct] ^ (g << 5)));
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) fb[pt] = *reinterpret_cast<const uint4*>(sin + (in_addr[pt] ^ (g << 5)));
+                    for (int pt = 0; pt < 2; ++pt) fb[pt] = *reinterpret_cast<const uint4*>(sin + in_base[pt][tap % 3][g] + (tap / 3) * HWD * 64);
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
