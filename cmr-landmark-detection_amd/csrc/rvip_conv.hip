@@ -433,20 +433,28 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
             }
             const unsigned char* sin = lin + (it & 1) * IN_BYTES;
             const unsigned char* sw = lw + (resident ? kc : (it & 1)) * W_BYTES;
+            // 18 (tap, k-half) steps as a two-deep software pipeline: the NCT + 2 fragment reads of step i+1 are issued before
+            // the NCT * 2 MFMAs of step i, so an LDS round trip is always covered by ~128 cycles of matrix work (hipcc on its
+            // own emits read -> lgkmcnt(0) -> mfma with 16 recycled registers).  sched_barrier(0) pins that order.
+            uint4 fa[2][NCT], fb[2][2];
+            auto load_step = [&](int st, int buf) __attribute__((always_inline)) {
+                const int tap = st >> 1, g = st & 1;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+                for (int ct = 0; ct < NCT; ++ct) fa[buf][ct] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + (w_addr[ct] ^ (g << 5)));
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    uint4 fa[NCT], fb[2];
+                for (int pt = 0; pt < 2; ++pt) fb[buf][pt] = *reinterpret_cast<const uint4*>(sin + in_base[pt][tap % 3][g] + (tap / 3) * HWD * 64);
+            };
+            load_step(0, 0);
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) fa[ct] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + (w_addr[ct] ^ (g << 5)));
+            for (int st = 0; st < 18; ++st) {
+                const int cur = st & 1;
+                if (st + 1 < 18) load_step(st + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);             // reads of step st+1 stay ABOVE the MFMAs of step st
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) fb[pt] = *reinterpret_cast<const uint4*>(sin + in_base[pt][tap % 3][g] + (tap / 3) * HWD * 64);
+                for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                        for (int pt = 0; pt < 2; ++pt) Mma<T>::run(fa[ct], fb[pt], acc[ct][pt]);
-                }
+                    for (int pt = 0; pt < 2; ++pt) Mma<T>::run(fa[cur][ct], fb[cur][pt], acc[ct][pt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // epilogue of this tile (the next item's DMA is already in flight).  Stores are buffer stores whose masked lanes
