@@ -266,6 +266,7 @@ struct ConvArgs2 {
     int tiles_x, tiles_y, ntiles, wres;      // wres: weight stages resident (= nchunks) or 0 -> 2 rotating stages
     int lds_bias_off;
     int zs;
+    int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
 };
 
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
     // DMA lane geometry: lane -> (row within the 16-row piece, physical 16-byte slot)
     const int drow = lane >> 2, dslot = lane & 3;
 
+    bool nofetch = false;                    // ablation (RVIP_DBG & 4)
     int wrel[QW], wch[QW];
 #pragma unroll
     for (int i = 0; i < QW; ++i) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
         for (int i = 0; i < QW; ++i) {
             const int q = wv + NW * i;
             if (q < NQW) {
-                const unsigned off = (wch[i] < a.cin - cbase) ? (unsigned)(wrel[i] + cbase * (int)sizeof(T)) : OOB;
+                const unsigned off = (wch[i] < a.cin - cbase && !nofetch) ? (unsigned)(wrel[i] + cbase * (int)sizeof(T)) : OOB;
                 dma16(rsw, off, lds_base + 2 * IN_BYTES + wstage * W_BYTES + q * 1024);
             }
         }
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
                 // (no `from0 ? irel0[i] : irel1[i]`: hipcc turns a select between two register arrays into scratch indexing)
                 int rel = irel0[i];
                 if (!from0) rel = ((ihy[i] * a.w + ihx[i]) * a.c1 + ich[i]) * (int)sizeof(T);
-                const unsigned off = ok ? (unsigned)(base + rel) : OOB;
+                const unsigned off = (ok && !nofetch) ? (unsigned)(base + rel) : OOB;
                 dma16(rs, off, lds_base + stage * IN_BYTES + q * 1024);
             }
         }
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
             {   // prefetch the next item into the other stage
                 int ntile = tile, nkc = kc + 1;
                 if (nkc == nchunks) { nkc = 0; ntile = tile + gridDim.x; }
-                if (ntile < a.ntiles) {
+                if (ntile < a.ntiles && !(a.dbg & 1)) {
                     issue_input(ntile, nkc, (it + 1) & 1);
                     if (!resident) issue_weights(nkc, (it + 1) & 1);
                 }
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
             // 18 (tap, k-half) steps as a two-deep software pipeline: the NCT + 2 fragment reads of step i+1 are issued before
             // the NCT * 2 MFMAs of step i, so an LDS round trip is always covered by ~128 cycles of matrix work (hipcc on its
             // own emits read -> lgkmcnt(0) -> mfma with 16 recycled registers).  sched_barrier(0) pins that order.
+            if (a.dbg & 2) continue;
             uint4 fa[2][NCT], fb[2][2];
             auto load_step = [&](int st, int buf) __attribute__((always_inline)) {
                 const int tap = st >> 1, g = st & 1;
@@ -599,6 +602,7 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float
     if (gx < 1) gx = 1;
     if (gx > b.ntiles) gx = b.ntiles;
     b.stats = stats;
+    { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
     if (rows_out) *rows_out = gx;
     if (dry) { used = true; return RVIP_OK; }
     if (stats) hipLaunchKernelGGL((conv3x3_igemm_dma<T, TW, NCT, NW, true>), dim3((unsigned)gx, (unsigned)cot), dim3(NW * 64), lds, s, b);

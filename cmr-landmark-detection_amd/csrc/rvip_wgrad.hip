@@ -191,6 +191,7 @@ struct WgArgs2 {
     int n, h, w, cin, cout;
     int tiles_x, tiles_y, ntiles, nsplit;
     int zs;
+    int dbg;                                  // ablation only (RVIP_DBG): 1 = no DMA after the first tile, 2 = no MFMA, 4 = DMAs fetch nothing
 };
 
 template <typename T, int TW, int CIB, int COB>
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
                 const int gy = ty0 + xhy[i], gx = tx0 + xhx[i];
                 bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
                 if (zsx) ok = ok && ((gy & gx) & 1);
-                const unsigned off = ok ? (unsigned)(xbase + xrel[i]) : OOB;
+                const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(xbase + xrel[i]) : OOB;
                 dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
             }
         }
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
             if (q < NQG) {
                 const int gy = ty0 + gpy[i], gx = tx0 + gpx[i];
                 const bool ok = (unsigned)gy < (unsigned)a.h && gx < a.w;
-                const unsigned off = ok ? (unsigned)(gbase + grel[i]) : OOB;
+                const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(gbase + grel[i]) : OOB;
                 dma16w(rsg, off, lds_base + stage * ST_BYTES + X_BYTES + q * 1024);
             }
         }
@@ -293,7 +294,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
     int it = 0;
     for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (tile + a.nsplit < a.ntiles) issue(tile + a.nsplit, (it + 1) & 1);
+        if (tile + a.nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + a.nsplit, (it + 1) & 1);
+        if (a.dbg & 2) continue;
         const unsigned char* lx = smem + (it & 1) * ST_BYTES;
         const unsigned char* lg = lx + X_BYTES;
         if constexpr (ESZ == 2) {
@@ -533,6 +535,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
         b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.dy_bytes = (unsigned)dyb;
         b.c0 = a.c0; b.c1 = a.c1; b.up0 = a.up0; b.zs = a.zs; b.n = a.n; b.h = a.h; b.w = a.w; b.cin = a.cin; b.cout = a.cout;
         b.tiles_x = g2.tiles_x; b.tiles_y = g2.tiles_y; b.ntiles = g2.ntiles; b.nsplit = g2.nsplit;
+        { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
         if (d->workspace_bytes < (size_t)b.nsplit * 9 * a.cin * a.cout * sizeof(float)) return RVIP_EWORKSPACE;
         if (d->dtype == RVIP_BF16) {
             if (g2.tw == 32) {
