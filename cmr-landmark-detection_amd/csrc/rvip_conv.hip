@@ -556,6 +556,349 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// igemm v3: producer / consumer wave specialisation of v2.  Measured on v2 (RVIP_DBG ablation): the un-overlapped cost
+// of staging is the LDS-DMA INSTRUCTIONS (~100-200 issue cycles each, the same with out-of-range = zero-traffic
+// offsets), which sit in front of every wave's MFMAs.  Here a workgroup is 8 waves = one loader + one compute wave per
+// SIMD: waves 4..7 only issue the DMA pieces of the next work item, waves 0..3 only read fragments and issue MFMAs
+// (each owns NPIX/4 pixels x BN channels, so a weight fragment is reused by up to 4 pixel fragments: 0.75 KiB of LDS
+// reads per MFMA instead of 1 KiB).  One s_barrier per work item joins the two roles.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int TW, int NCT, int NPIX, bool STATS>
+__global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
+    constexpr int TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
+    constexpr int NHROWS = (NHALO + 15) / 16 * 16;
+    constexpr int BN = NCT * 32, WROWS = 9 * BN;
+    constexpr int IN_BYTES = NHROWS * 64, W_BYTES = WROWS * 64;
+    constexpr int VE = Vec<T>::VE, KCE = 4 * VE;
+    constexpr int NQI = NHROWS / 16, NQW = WROWS / 16;                 // 1 KiB DMA pieces per stage
+    constexpr int QI = (NQI + 3) / 4, QW = (NQW + 3) / 4;              // per loader wave
+    constexpr int NPT = NPIX / 128;                                    // 32-pixel tiles per compute wave
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lin = smem;                       // [2][IN_BYTES]
+    unsigned char* lw = smem + 2 * IN_BYTES;         // [wres or 2][W_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * BN;
+    const int nchunks = (a.cin + KCE - 1) / KCE;
+    const bool resident = a.wres > 0;
+    const int first_tile = blockIdx.x;
+    if (first_tile >= a.ntiles) return;
+    float* lbias = reinterpret_cast<float*>(smem + a.lds_bias_off);        // [BN] bias of this output-channel tile
+    if (tid < BN) lbias[tid] = (a.bias && co0 + tid < a.cout) ? a.bias[co0 + tid] : 0.f;
+
+    if (wv >= 4) {
+        // ------------------------------------------------ loader waves ------------------------------------------------
+        const int lwv = wv - 4;
+        const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
+        const i32x4 rs0 = make_rsrc(a.x0, a.x0_bytes);
+        const i32x4 rs1 = make_rsrc(a.x1 ? a.x1 : a.x0, a.x1 ? a.x1_bytes : 0u);
+        const i32x4 rsw = make_rsrc(a.wp, a.wp_bytes);
+        const unsigned lds_base = lds_offset_of(smem);
+        const int drow = lane >> 2, dslot = lane & 3;
+        int wrel[QW], wch[QW];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            const int row = (lwv + 4 * i) * 16 + drow;
+            const int tap = row / BN, co = co0 + (row & (BN - 1));
+            wch[i] = (co < a.cout && row < WROWS) ? (dslot ^ ((row >> 2) & 3)) * VE : 1 << 28;
+            wrel[i] = (((tap * a.cout + co) * a.cin) + (dslot ^ ((row >> 2) & 3)) * VE) * (int)sizeof(T);
+        }
+        int ihy[QI], ihx[QI], irel0[QI], ich[QI];
+#pragma unroll
+        for (int i = 0; i < QI; ++i) {
+            const int row = (lwv + 4 * i) * 16 + drow;
+            const int hy = row / HWD, hx = row - hy * HWD;
+            ich[i] = (dslot ^ ((hx >> 2) & 3)) * VE;
+            ihy[i] = (row < NHALO) ? hy - 1 : -100000;
+            ihx[i] = hx - 1;
+            irel0[i] = ((((hy - 1) >> a.up0) * w0 + ((hx - 1) >> a.up0)) * a.c0 + ich[i]) * (int)sizeof(T);
+        }
+        auto issue_weights = [&](int kc, int wstage) __attribute__((always_inline)) {
+            const int cbase = kc * KCE;
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                const int q = lwv + 4 * i;
+                if (q < NQW) {
+                    const unsigned off = (wch[i] < a.cin - cbase) ? (unsigned)(wrel[i] + cbase * (int)sizeof(T)) : OOB;
+                    dma16(rsw, off, lds_base + 2 * IN_BYTES + wstage * W_BYTES + q * 1024);
+                }
+            }
+        };
+        auto issue_input = [&](int tile, int kc, int stage) __attribute__((always_inline)) {
+            int bx = tile;
+            const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
+            const int ty_i = bx % a.tiles_y;
+            const int n = bx / a.tiles_y;
+            const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+            const int cbase = kc * KCE;
+            const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
+            const int cb = from0 ? cbase : cbase - a.c0;
+            const int crem = (from0 ? a.c0 : a.c1) - cb;
+            const int base = from0 ? (((n * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 + cb) * (int)sizeof(T)
+                                   : (((n * a.h + ty0) * a.w + tx0) * a.c1 + cb) * (int)sizeof(T);
+            const bool zs = from0 && a.zs;
+            const i32x4 rs = from0 ? rs0 : rs1;
+#pragma unroll
+            for (int i = 0; i < QI; ++i) {
+                const int q = lwv + 4 * i;
+                if (q < NQI) {
+                    const int gy = ty0 + ihy[i], gx = tx0 + ihx[i];
+                    bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && ich[i] < crem;
+                    if (zs) ok = ok && ((gy & gx) & 1);
+                    int rel = irel0[i];
+                    if (!from0) rel = ((ihy[i] * a.w + ihx[i]) * a.c1 + ich[i]) * (int)sizeof(T);
+                    const unsigned off = ok ? (unsigned)(base + rel) : OOB;
+                    dma16(rs, off, lds_base + stage * IN_BYTES + q * 1024);
+                }
+            }
+        };
+        if (resident) for (int kc = 0; kc < nchunks; ++kc) issue_weights(kc, kc);
+        else issue_weights(0, 0);
+        issue_input(first_tile, 0, 0);
+        int it = 0;
+        for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
+            for (int kc = 0; kc < nchunks; ++kc, ++it) {
+                // my pieces of item `it` have landed; after the barrier: everybody's have, and the compute waves are done
+                // with item it-1, whose stage the next item may now overwrite
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                int ntile = tile, nkc = kc + 1;
+                if (nkc == nchunks) { nkc = 0; ntile = tile + gridDim.x; }
+                if (ntile < a.ntiles && !(a.dbg & 1)) {
+                    issue_input(ntile, nkc, (it + 1) & 1);
+                    if (!resident) issue_weights(nkc, (it + 1) & 1);
+                }
+            }
+        }
+        if constexpr (STATS) {                           // the compute waves' reduction uses two more workgroup barriers
+            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+        return;
+    }
+
+    // -------------------------------------------------- compute waves --------------------------------------------------
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y1 ? a.y1 : a.y), 0, a.y1 ? a.y1_bytes : 0, 0x00020000);
+    // pixel tile pt of this wave sits 32/TW halo rows below tile pt-1: one base per (tx, g), the rest is an immediate
+    constexpr int PT_STRIDE = (32 / TW) * HWD * 64;
+    int in_base[3][2];
+    {
+        const int P = wv * (NPT * 32) + j;
+        const int py = P / TW, px = P % TW;
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int hx = px + tx;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) in_base[tx][g] = (py * HWD + hx) * 64 + (((2 * g + hf) ^ ((hx >> 2) & 3)) << 4);
+        }
+    }
+    int w_addr[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int r = ct * 32 + j;
+        w_addr[ct] = r * 64 + ((hf ^ ((r >> 2) & 3)) << 4);          // g = 0; g = 1 is this address ^ 32
+    }
+    f32x16 acc[NCT][NPT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+    constexpr int SN = STATS ? NCT : 1, SR = STATS ? 16 : 1;
+    float ssum[SN][SR], ssq[SN][SR];
+#pragma unroll
+    for (int ct = 0; ct < SN; ++ct)
+#pragma unroll
+        for (int r = 0; r < SR; ++r) ssum[ct][r] = ssq[ct][r] = 0.f;
+
+    int it = 0;
+    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
+        int bx = tile;
+        const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty_i = bx % a.tiles_y;
+        const int n = bx / a.tiles_y;
+        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+        for (int kc = 0; kc < nchunks; ++kc, ++it) {
+            asm volatile("s_barrier" ::: "memory");              // item `it` is in LDS (the loaders waited for their DMAs)
+            if (a.dbg & 2) continue;
+            const unsigned char* sin = lin + (it & 1) * IN_BYTES;
+            const unsigned char* sw = lw + (resident ? kc : (it & 1)) * W_BYTES;
+            // 18 (tap, k-half) steps, two-deep software pipeline (see v2): reads of step i+1 above the MFMAs of step i
+            uint4 fa[2][NCT], fb[2][NPT];
+            auto load_step = [&](int st, int buf) __attribute__((always_inline)) {
+                const int tap = st >> 1, g = st & 1;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) fa[buf][ct] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + (w_addr[ct] ^ (g << 5)));
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) fb[buf][pt] = *reinterpret_cast<const uint4*>(sin + in_base[tap % 3][g] + (tap / 3) * HWD * 64 + pt * PT_STRIDE);
+            };
+            load_step(0, 0);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                const int cur = st & 1;
+                if (st + 1 < 18) load_step(st + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) Mma<T>::run(fa[cur][ct], fb[cur][pt], acc[ct][pt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // epilogue of this tile; compute waves never wait on their stores (they issue no DMA)
+        auto epilogue = [&](auto actf) {
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int P = wv * (NPT * 32) + pt * 32 + j;
+            const int gy = ty0 + P / TW, gx = tx0 + P % TW;
+            const bool pix_ok = gy < a.h && gx < a.w;
+            const unsigned pix = (unsigned)((n * a.h + gy) * a.w + gx);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int cbase = co0 + ct * 32;                                   // wave-uniform
+                const bool second = a.y1 && cbase >= a.csplit;                     // csplit % 32 == 0 (host)
+                const int cstride = a.y1 ? (second ? a.cout - a.csplit : a.csplit) : a.cout;
+                const int cshift = second ? a.csplit : 0;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t = acc[ct][pt][r] + lbias[ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
+                    acc[ct][pt][r] = 0.f;
+                    v[r] = actf(t);
+                    if constexpr (STATS) {
+                        if (pix_ok) {
+                            const float q = Vec<T>::round(v[r]);
+                            ssum[ct][r] += q;
+                            ssq[ct][r] = fmaf(q, q, ssq[ct][r]);
+                        }
+                    }
+                }
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = cbase + 8 * q + 4 * hf;
+                        const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 4u : OOB;
+                        const u32x4v dta = {__builtin_bit_cast(unsigned, v[4 * q]), __builtin_bit_cast(unsigned, v[4 * q + 1]),
+                                            __builtin_bit_cast(unsigned, v[4 * q + 2]), __builtin_bit_cast(unsigned, v[4 * q + 3])};
+                        if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        unsigned ax = (uint32_t)f32_to_bf16(v[8 * qq + 0]) | ((uint32_t)f32_to_bf16(v[8 * qq + 1]) << 16);
+                        unsigned ay = (uint32_t)f32_to_bf16(v[8 * qq + 2]) | ((uint32_t)f32_to_bf16(v[8 * qq + 3]) << 16);
+                        unsigned bxx = (uint32_t)f32_to_bf16(v[8 * qq + 4]) | ((uint32_t)f32_to_bf16(v[8 * qq + 5]) << 16);
+                        unsigned byy = (uint32_t)f32_to_bf16(v[8 * qq + 6]) | ((uint32_t)f32_to_bf16(v[8 * qq + 7]) << 16);
+                        auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
+                        auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
+                        const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
+                        const int co = cbase + 16 * qq + 8 * hf;
+                        const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
+                        if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
+                    }
+                }
+            }
+        }
+        };
+        if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
+        else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
+        else epilogue([&](float t) { return act_fwd(t, a.act); });
+    }
+    if constexpr (STATS) {
+        asm volatile("s_barrier" ::: "memory");                            // every stage has been consumed
+        float* lst = reinterpret_cast<float*>(smem);                       // [4 compute waves][2][BN]
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = ssum[ct][r], s2 = ssq[ct][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                if (j == 0) {
+                    const int c = ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                    lst[(wv * 2 + 0) * BN + c] = s1;
+                    lst[(wv * 2 + 1) * BN + c] = s2;
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < 2 * BN) {
+            const int k = tid / BN, c = tid % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) t += lst[(w4 * 2 + k) * BN + c];
+            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * 2 + k) * a.cout + co0 + c] = t;
+        }
+    }
+}
+
+template <typename T, int TW, int NCT, int NPIX>
+static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry) {
+    constexpr int TH = NPIX / TW;
+    constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
+    constexpr int IN_BYTES = NHROWS * 64, W_BYTES = 9 * NCT * 32 * 64;
+    constexpr int KCE = 64 / (int)sizeof(T);
+    constexpr int LDS_MAX = 160 * 1024;
+    used = false;
+    const int nchunks = (int)cdiv(a0.cin, KCE);
+    const long long x0b = (long long)a0.n * (a0.h >> a0.up0) * (a0.w >> a0.up0) * a0.c0 * (long long)sizeof(T);
+    const long long x1b = (long long)a0.n * a0.h * a0.w * a0.c1 * (long long)sizeof(T);
+    const long long wpb = 9LL * a0.cin * a0.cout * (long long)sizeof(T);
+    if (x0b >= (1LL << 31) || x1b >= (1LL << 31) || wpb >= (1LL << 31)) return RVIP_OK;
+    if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
+    if (a0.y1 && a0.csplit % 32) return RVIP_OK;
+    const long long npx = (long long)a0.n * a0.h * a0.w;
+    const long long yb = npx * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
+    if (yb >= (1LL << 31) || y1b >= (1LL << 31)) return RVIP_OK;
+    if (sizeof(T) == 2 && a0.cout % 8) return RVIP_OK;
+    ConvArgs2 b;
+    b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
+    b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs;
+    b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
+    b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
+    b.ntiles = a0.n * b.tiles_x * b.tiles_y;
+    const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 <= LDS_MAX;
+    b.wres = res ? nchunks : 0;
+    b.lds_bias_off = 2 * IN_BYTES + (res ? nchunks : 2) * W_BYTES;
+    const int lds = b.lds_bias_off + 256;
+    if (lds > LDS_MAX) return RVIP_OK;
+    static int attr_lds = 0;
+    if (!dry && lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
+        attr_lds = LDS_MAX;
+    }
+    const int cot = (int)cdiv(a0.cout, NCT * 32);
+    int gx = 256 / cot;
+    if (gx < 1) gx = 1;
+    if (gx > b.ntiles) gx = b.ntiles;
+    b.stats = stats;
+    { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
+    if (rows_out) *rows_out = gx;
+    if (dry) { used = true; return RVIP_OK; }
+    if (stats) hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, true>), dim3((unsigned)gx, (unsigned)cot), dim3(512), lds, s, b);
+    else hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, false>), dim3((unsigned)gx, (unsigned)cot), dim3(512), lds, s, b);
+    used = true;
+    return check_launch();
+}
+
+template <typename T>
+static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float* stats = nullptr, int* rows_out = nullptr, bool dry = false) {
+    const bool two = a.cout > 32;
+    if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, 32, 2, 512>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512>(a, s, used, stats, rows_out, dry);
+    if (a.w > 16) return two ? launch_igemm_ws<T, 32, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 256>(a, s, used, stats, rows_out, dry);
+    return two ? launch_igemm_ws<T, 16, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 16, 1, 256>(a, s, used, stats, rows_out, dry);
+}
+
 template <typename T, int TW, int NCT, int NW>
 static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry) {
     constexpr int NPIX = NW * 64, TH = NPIX / TW;
@@ -755,6 +1098,18 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     }
 }
 
+// Kernel generation per launch.  RVIP_IGEMM=v1|v2|v3 forces one (A/B measurements).  Default: measured per layer on
+// MI355X (profiles/r01_igemm_v2_v3.txt) - the wave-specialised v3 wins wherever a tile carries many K chunks (-6..-16 %
+// at Cin >= 256, and on the up-sampling reads), v2 (all 8 waves share the epilogue stores) wins on the store-bound
+// layers with few chunks per tile (+8..+15 % for v3 at Cin <= 64 and at Cin = 128 on 128x128 maps).
+static int igemm_generation(const ConvArgs& a, bool stats = false) {
+    static const int forced = [] { const char* e = getenv("RVIP_IGEMM"); return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '3') ? e[1] - '0' : 0; }();
+    if (forced) return forced;
+    if (a.cin >= 256) return 3;
+    if (stats) return 2;
+    return (a.up0 == 1 || (a.cin >= 128 && a.h <= 64)) ? 3 : 2;
+}
+
 }  // namespace rvip
 
 using namespace rvip;
@@ -783,10 +1138,12 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout; a.act = d->act;
     a.tiles_x = a.tiles_y = 0;
     hipStream_t s = (hipStream_t)stream;
-    static const bool force_v1 = [] { const char* e = getenv("RVIP_IGEMM"); return e && e[0] == 'v' && e[1] == '1'; }();
-    if (!force_v1) {
+    const int gen = igemm_generation(a);
+    if (gen >= 2) {
         bool used = false;
-        const int rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
+        int rc;
+        if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used) : dispatch_igemm_ws<float>(a, s, used);
+        else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
         if (rc || used) return rc;
     }
     return d->dtype == RVIP_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
@@ -818,11 +1175,14 @@ extern "C" int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d) {
     ConvArgs a;
     if (conv_args_from_desc(d, a) != RVIP_OK || d->y1) return 0;
     if (d->cout > 32) return 0;      // the 64-channel tile variant would exceed 256 VGPRs with the per-lane accumulators
-    static const bool force_v1 = [] { const char* e = getenv("RVIP_IGEMM"); return e && e[0] == 'v' && e[1] == '1'; }();
-    if (force_v1) return 0;
+    const int gen = igemm_generation(a, true);
+    if (gen < 2) return 0;
     bool used = false; int rows = 0;
-    const int rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, nullptr, used, nullptr, &rows, true)
-                                         : dispatch_igemm_dma<float>(a, nullptr, used, nullptr, &rows, true);
+    int rc;
+    if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, nullptr, used, nullptr, &rows, true)
+                                             : dispatch_igemm_ws<float>(a, nullptr, used, nullptr, &rows, true);
+    else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, nullptr, used, nullptr, &rows, true)
+                                    : dispatch_igemm_dma<float>(a, nullptr, used, nullptr, &rows, true);
     return (rc == RVIP_OK && used) ? rows : 0;
 }
 
@@ -837,7 +1197,8 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
     if (stats_ws_bytes < (size_t)rows * 2 * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
     bool used = false;
     hipStream_t s = (hipStream_t)stream;
-    rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used, stats_ws) : dispatch_igemm_dma<float>(a, s, used, stats_ws);
+    if (igemm_generation(a, true) >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used, stats_ws) : dispatch_igemm_ws<float>(a, s, used, stats_ws);
+    else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used, stats_ws) : dispatch_igemm_dma<float>(a, s, used, stats_ws);
     if (rc) return rc;
     return used ? RVIP_OK : RVIP_EUNSUPPORTED;
 }
