@@ -35,6 +35,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='slices per GPU (BASELINE.json: 32)')
     ap.add_argument('--dim', type=int, default=256)
+    ap.add_argument('--filters', type=int, default=32, help='base filters (BASELINE.json headline: 32; cfg 4: 64)')
+    ap.add_argument('--depth', type=int, default=4, help='U-Net levels (headline: 4; cfg 4: 5)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
@@ -65,7 +67,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    cfg = dict(DIM=[args.dim, args.dim], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
+    cfg = dict(DIM=[args.dim, args.dim], FILTERS=args.filters, DEPTH=args.depth, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
                MASK_CLASSES=2, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-4, RVIP_PRECISION=args.precision,
                LOSS_FUNCTION=M.mse, SEED=42)
     model = rvip.get_model(cfg, metrics=[])
@@ -220,8 +222,8 @@ def main():
             'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
-            'config': {'workload': '4-level 2D U-Net F=32, %dx%d, batch %d per GPU, fwd+loss(MSE)+bwd+Adam%s' % (
-                args.dim, args.dim, B, ' + RCCL grad all-reduce' if world > 1 else ''),
+            'config': {'workload': '%d-level 2D U-Net F=%d, %dx%d, batch %d per GPU, fwd+loss(MSE)+bwd+Adam%s' % (
+                args.depth, args.filters, args.dim, args.dim, B, ' + RCCL grad all-reduce' if world > 1 else ''),
                 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch, 'collective': ('%s all-reduce of %d fp32 gradients' % (backend, model._params.count)) if world > 1 else None,
                 'gflop_per_slice_fwd_bwd': round(step_flops / 1e9, 3)},
             'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),

@@ -106,6 +106,45 @@ static int launch_fold(const float* ws, int nblk, int width, Post post, hipStrea
     return check_launch();
 }
 
+#define RVIP_FOLDK_GROUPS 32
+#define RVIP_FOLDK_DEPTH 8
+// the same fold for outputs that are independent per k (weight gradients with 8-9 rows per channel): blockIdx.y = k,
+// so the K chains of load latencies run side by side instead of one after the other.  Post::run_k(ch, k, total).
+template <typename Post>
+__global__ __launch_bounds__(1024) void fold_finalize_k(const float* __restrict__ ws, int nblk, int width, int K, Post post) {
+    __shared__ double sh[RVIP_FOLDK_GROUPS / 2][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5, k = blockIdx.y;
+    const int ch = blockIdx.x * 32 + c;
+    double s = 0.0;
+    if (ch < width) {
+        for (int b0 = g; b0 < nblk; b0 += RVIP_FOLDK_GROUPS * RVIP_FOLDK_DEPTH) {
+            float v[RVIP_FOLDK_DEPTH];
+#pragma unroll
+            for (int u = 0; u < RVIP_FOLDK_DEPTH; ++u) {
+                const int b = b0 + u * RVIP_FOLDK_GROUPS;
+                v[u] = b < nblk ? ws[((size_t)b * K + k) * width + ch] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < RVIP_FOLDK_DEPTH; u += 4) s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
+        }
+    }
+    const double o = __shfl_xor(s, 32);
+    if (!(g & 1)) sh[g >> 1][c] = s + o;
+    __syncthreads();
+    if (g == 0 && ch < width) {
+        double acc = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < RVIP_FOLDK_GROUPS / 2; ++gg) acc += sh[gg][c];
+        post.run_k(ch, k, acc);
+    }
+}
+
+template <typename Post>
+static int launch_fold_k(const float* ws, int nblk, int width, int K, Post post, hipStream_t s) {
+    hipLaunchKernelGGL((fold_finalize_k<Post>), dim3((unsigned)cdiv(width, 32), (unsigned)K), dim3(32 * RVIP_FOLDK_GROUPS), 0, s, ws, nblk, width, K, post);
+    return check_launch();
+}
+
 struct PostSum {                      // out[ch] = total (plain sum), K = 1
     float* out;
     __device__ void run(int ch, const double (&t)[1]) const { out[ch] = (float)t[0]; }
@@ -529,13 +568,18 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned char* __re
         for (int kk = 0; kk < RVIP_MAXK; ++kk) {
             if (kk >= k) continue;
             const float zl = lg[kk];
-            const float p = 1.f / (1.f + expf(-zl));
+            // one exponential serves the sigmoid and the softplus term: e = exp(-|z|), sigmoid = (z >= 0 ? 1 : e) / (1 + e),
+            // log1p(e) = log(1 + e) with absolute error < 1e-7 (e <= 1).  Hardware exp2 / log2 / rcp: the libm forms made
+            // this kernel VALU-bound (84 us for 134 MB).
+            const float e = __expf(-fabsf(zl));
+            const float inv = __frcp_rn(1.f + e);
+            const float p = (zl >= 0.f ? 1.f : e) * inv;
             pred[(size_t)r * k + kk] = p;
             if (yt) {
                 const float t = yt[(size_t)r * k + kk];
                 const float d = p - t;
                 s[0] = fmaf(d, d, s[0]);
-                s[1] += fmaxf(zl, 0.f) - zl * t + log1pf(expf(-fabsf(zl)));
+                s[1] += fmaxf(zl, 0.f) - zl * t + __logf(1.f + e);
                 s[2] = fmaf(t, p, s[2]); s[3] += t; s[4] += p;
                 if (kk == k - 2) { s[5] = fmaf(t, p, s[5]); s[6] += t; s[7] += p; }
                 if (kk == k - 1) { s[8] = fmaf(t, p, s[8]); s[9] += t; s[10] += p; }
@@ -620,11 +664,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* __re
     block_fold<2 * RVIP_MAXK, VE>(part, active, prow * gm.cg + cgi, cin, gm.rpi, lds, ws + (size_t)blockIdx.x * 2 * RVIP_MAXK * cin);
 }
 
-struct PostHeadBwd {                   // ws columns: [2*MAXK][cin]; K template = 2*MAXK
+struct PostHeadBwd {                   // ws columns: [2*MAXK][cin]: rows 0..MAXK-1 = dw per class, MAXK.. = db (channel 0 only)
     float* dw; float* db; int cin, k;
-    __device__ void run(int ch, const double (&t)[2 * RVIP_MAXK]) const {
-        for (int kk = 0; kk < k; ++kk) dw[ch * k + kk] = (float)t[kk];
-        if (ch == 0) for (int kk = 0; kk < k; ++kk) db[kk] = (float)t[RVIP_MAXK + kk];
+    __device__ void run_k(int ch, int kk, double t) const {
+        if (kk < RVIP_MAXK) { if (kk < k) dw[ch * k + kk] = (float)t; }
+        else if (ch == 0 && kk - RVIP_MAXK < k) db[kk - RVIP_MAXK] = (float)t;
     }
 };
 
@@ -714,9 +758,7 @@ __global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, c
 
 struct PostC1Wgrad {
     float* dw; int cout;
-    __device__ void run(int ch, const double (&t)[9]) const {
-        for (int k = 0; k < 9; ++k) dw[k * cout + ch] = (float)t[k];
-    }
+    __device__ void run_k(int ch, int k, double t) const { dw[k * cout + ch] = (float)t; }
 };
 
 // landmark = flat argmax over H*W per (slice, class), first maximum wins; optional > thr mask
@@ -1001,7 +1043,7 @@ extern "C" int rvip_head_bwd(const void* x, const float* w, const float* dlogit,
     int rc = check_launch();
     if (rc) return rc;
     PostHeadBwd p{dw, db, cin, k};
-    return launch_fold<2 * RVIP_MAXK, PostHeadBwd>(ws, g.nblk, cin, p, s);
+    return launch_fold_k<PostHeadBwd>(ws, g.nblk, cin, 2 * RVIP_MAXK, p, s);
 }
 
 extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cout, int dtype,
@@ -1023,14 +1065,14 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
         int rc2 = check_launch();
         if (rc2) return rc2;
         PostC1Wgrad p2{dw, cout};
-        return launch_fold<9, PostC1Wgrad>(ws, nb, cout, p2, s);
+        return launch_fold_k<PostC1Wgrad>(ws, nb, cout, 9, p2, s);
     }
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     else hipLaunchKernelGGL(c1_wgrad_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     int rc = check_launch();
     if (rc) return rc;
     PostC1Wgrad p{dw, cout};
-    return launch_fold<9, PostC1Wgrad>(ws, g.nblk, cout, p, s);
+    return launch_fold_k<PostC1Wgrad>(ws, g.nblk, cout, 9, p, s);
 }
 
 extern "C" int rvip_landmarks(const float* pred, long long* idx_out, uint8_t* mask_out, int n, int hw, int k, float thr, void* stream) {

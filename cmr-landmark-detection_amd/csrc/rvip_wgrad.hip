@@ -390,31 +390,47 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
     }
 }
 
-// dw[i] = sum_k slab[k][i] in split order.  256 threads = 32 elements x 8 split groups so that small kernels
-// (9*32*32 elements, hundreds of splits) still fill the chip; fixed summation order -> reproducible.
-__global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ slab, int nsplit, long long count, float* __restrict__ dw) {
-    __shared__ float sh[8][32];
+// dw[i] = sum_k slab[k][i] in a fixed order (reproducible).  A thread owns four consecutive elements (one 16-byte
+// load per slab); a workgroup = 32 such threads x G split groups, and every thread has all of its (<= U) loads in
+// flight before the first add: the fold of a small kernel over hundreds of slabs is a chain of load latencies.
+template <int G, int U>
+__global__ __launch_bounds__(32 * G) void wgrad_fold_kernel(const float4* __restrict__ slab, int nsplit, long long count4, float4* __restrict__ dw) {
+    __shared__ float4 sh[G][32];
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const long long i = blockIdx.x * 32LL + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < count) {
-        int k = g;
-        for (; k + 24 < nsplit; k += 32) {
-            s0 += slab[(size_t)k * count + i];
-            s1 += slab[(size_t)(k + 8) * count + i];
-            s2 += slab[(size_t)(k + 16) * count + i];
-            s3 += slab[(size_t)(k + 24) * count + i];
-        }
-        for (; k < nsplit; k += 8) s0 += slab[(size_t)k * count + i];
-    }
-    sh[g][e] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (g == 0 && i < count) {
-        float t = 0.f;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (i < count4) {
+        for (int k0 = g; k0 < nsplit; k0 += G * U) {
+            float4 v[U];
 #pragma unroll
-        for (int gg = 0; gg < 8; ++gg) t += sh[gg][e];
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * G;
+                v[u] = k < nsplit ? slab[(size_t)k * count4 + i] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+    sh[g][e] = acc;
+    __syncthreads();
+    if (g == 0 && i < count4) {
+        float4 t = sh[0][e];
+#pragma unroll
+        for (int gg = 1; gg < G; ++gg) { t.x += sh[gg][e].x; t.y += sh[gg][e].y; t.z += sh[gg][e].z; t.w += sh[gg][e].w; }
         dw[i] = t;
     }
+}
+
+static int launch_wgrad_fold(const float* slab, int nsplit, long long count, float* dw, hipStream_t s) {
+    if (count % 4 || ((uintptr_t)slab & 15) || ((uintptr_t)dw & 15)) return RVIP_EINVAL;
+    const long long count4 = count / 4;
+    const dim3 grid((unsigned)cdiv(count4, 32));
+    const float4* sl = reinterpret_cast<const float4*>(slab);
+    float4* out = reinterpret_cast<float4*>(dw);
+    if (nsplit > 32) hipLaunchKernelGGL((wgrad_fold_kernel<32, 8>), grid, dim3(1024), 0, s, sl, nsplit, count4, out);
+    else if (nsplit > 4) hipLaunchKernelGGL((wgrad_fold_kernel<8, 4>), grid, dim3(256), 0, s, sl, nsplit, count4, out);
+    else hipLaunchKernelGGL((wgrad_fold_kernel<4, 1>), grid, dim3(128), 0, s, sl, nsplit, count4, out);
+    return check_launch();
 }
 
 static void wgrad_geometry(int n, int h, int w, int cin, int cout, int& tw, int& tiles_x, int& tiles_y, int& ntiles, int& nsplit) {
@@ -554,8 +570,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
         }
         if (rc) return rc;
         const long long count2 = 9LL * a.cin * a.cout;
-        hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(count2, 32)), dim3(256), 0, s, a.slab, b.nsplit, count2, d->dw);
-        return check_launch();
+        return launch_wgrad_fold(a.slab, b.nsplit, count2, d->dw, s);
     }
     int tw;
     wgrad_geometry(a.n, a.h, a.w, a.cin, a.cout, tw, a.tiles_x, a.tiles_y, a.ntiles, a.nsplit);
@@ -565,6 +580,5 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     else rc = tw == 32 ? launch_wgrad<float, 32>(a, s) : launch_wgrad<float, 16>(a, s);
     if (rc) return rc;
     const long long count = 9LL * a.cin * a.cout;
-    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(count, 32)), dim3(256), 0, s, a.slab, a.nsplit, count, d->dw);
-    return check_launch();
+    return launch_wgrad_fold(a.slab, a.nsplit, count, d->dw, s);
 }

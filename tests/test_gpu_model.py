@@ -53,6 +53,7 @@ VARIANTS = [
     dict(DEPTH=3, DIM=[48, 40], LOSS_FUNCTION=M.bce_dice_loss),
     dict(LOSS_FUNCTION=M.BceDiceLoss(), FILTERS=12),
     dict(USE_UPSAMPLE=False),                       # Conv2DTranspose decoder (KerasLayers.py:761-765)
+    dict(DEPTH=5, DIM=[64, 64], FILTERS=4, RVIP_PRECISION='fp32'),   # cfg 4's depth (bottleneck 2x2), fp32: F % 4 == 0
 ]
 
 
@@ -227,6 +228,31 @@ def test_full_size_step_is_deterministic_and_finite():
     G = rvip.Generators.SyntheticSAXGenerator(32, dict(DIM=[256, 256], BATCHSIZE=32, GAUS=True, SIGMA=2, SHUFFLE=False))
     x, y = G[0]
     eng = model._engine(32)
+    outs = []
+    for _ in range(2):
+        eng.load_input(x, y)
+        eng.forward(training=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        outs.append((eng.loss.clone(), eng.pred.clone(), model._params.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.isfinite(outs[0][2]).all() and float(outs[0][2].abs().max()) > 0
+    l0 = model.train_on_batch(x, y)[0]
+    l1 = model.train_on_batch(x, y)[0]
+    assert np.isfinite(l0) and np.isfinite(l1)
+
+
+def test_cfg4_shape_step_is_deterministic_and_finite():
+    """BASELINE.json configs[3] shape (512x512, F=64, depth 5; bf16 stands in for fp16, batch 8): parameter count of
+    SURVEY.md 8(d) (138 376 578), bit-identical repeat of fwd+bwd from identical state, finite loss after two
+    optimizer steps."""
+    cfg = dict(DIM=[512, 512], FILTERS=64, DEPTH=5, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2,
+               LEARNING_RATE=1e-4, RVIP_PRECISION='bf16', LOSS_FUNCTION=M.mse, SEED=1)
+    model = rvip.get_model(cfg, metrics=[])
+    assert model.count_params() == 138376578
+    G = rvip.Generators.SyntheticSAXGenerator(8, dict(DIM=[512, 512], BATCHSIZE=8, GAUS=True, SIGMA=2, SHUFFLE=False))
+    x, y = G[0]
+    eng = model._engine(8)
     outs = []
     for _ in range(2):
         eng.load_input(x, y)
