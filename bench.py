@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--dim', type=int, default=256)
     ap.add_argument('--filters', type=int, default=32, help='base filters (BASELINE.json headline: 32; cfg 4: 64)')
     ap.add_argument('--depth', type=int, default=4, help='U-Net levels (headline: 4; cfg 4: 5)')
+    ap.add_argument('--frames', type=int, default=0, help='> 0: 3-D cine graph on [frames, dim, dim] volumes (cfg 5: 16), Conv3D 3x3x3, pool (1,2,2)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
@@ -70,6 +71,8 @@ def main():
     cfg = dict(DIM=[args.dim, args.dim], FILTERS=args.filters, DEPTH=args.depth, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
                MASK_CLASSES=2, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-4, RVIP_PRECISION=args.precision,
                LOSS_FUNCTION=M.mse, SEED=42)
+    if args.frames > 0:
+        cfg.update(DIM=[args.frames, args.dim, args.dim], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3])
     model = rvip.get_model(cfg, metrics=[])
     plan = model.plan
     B = args.batch
@@ -170,10 +173,10 @@ def main():
                     flops = 0.0
                     if fn is conv_fn:
                         d = a[0]._obj
-                        flops = 2.0 * d.n * d.h * d.w * 9 * (d.c0 + d.c1) * d.cout
+                        flops = 2.0 * d.n * d.h * d.w * 9 * max(d.kd, 1) * (d.c0 + d.c1) * d.cout
                     elif fn is wgrad_fn:
                         d = a[0]._obj
-                        flops = 2.0 * d.n * d.h * d.w * 9 * (d.c0 + d.c1) * d.cout
+                        flops = 2.0 * d.n * d.h * d.w * 9 * max(d.kd, 1) * (d.c0 + d.c1) * d.cout
                     agg.setdefault(fn.__name__, []).append((e0, e1, flops))
                     if flops > 0:
                         detail.append((fn.__name__, (d.n, d.h, d.w, d.c0 + d.c1, d.cout, d.up0, 1 if d.c1 else 0), e0, e1, flops))
@@ -218,8 +221,8 @@ def main():
     out = None
     if rank == 0:
         out = {
-            'metric': 'SAX slices/sec (fwd+bwd), 256x256 U-Net 2-heatmap',
-            'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'metric': 'SAX slices/sec (fwd+bwd), 256x256 U-Net 2-heatmap' if args.frames <= 0 else 'cine volumes/sec (fwd+bwd), %dx%dx%d 3-D U-Net' % (args.frames, args.dim, args.dim),
+            'value': round(value, 2), 'unit': 'slices/s' if args.frames <= 0 else 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': '%d-level 2D U-Net F=%d, %dx%d, batch %d per GPU, fwd+loss(MSE)+bwd+Adam%s' % (

@@ -103,9 +103,18 @@ class SyntheticSAXGenerator(BaseGenerator):
     def __preprocess_one_image__(self, i, ID):
         if self.IN_MEMORY and ID in self._cache:
             return self._cache[ID]
-        import scipy.ndimage
         rng = np.random.default_rng([self.SEED, ID])
-        h, w = self.DIM
+        if len(self.DIM) == 3:                       # cine volume [T,H,W]: every frame drawn like a slice
+            frames = [self._slice(rng, self.DIM[1], self.DIM[2]) for _ in range(self.DIM[0])]
+            out = (np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]))
+        else:
+            out = self._slice(rng, self.DIM[0], self.DIM[1])
+        if self.IN_MEMORY:
+            self._cache[ID] = out
+        return out
+
+    def _slice(self, rng, h, w):
+        import scipy.ndimage
         img = scipy.ndimage.gaussian_filter(rng.random((h, w)), min(8.0, h / 8.0))
         img = normalise_image(img, self.SCALER).astype(np.float32)
         lab = np.zeros((h, w), np.int32)
@@ -114,10 +123,7 @@ class SyntheticSAXGenerator(BaseGenerator):
             lab[int(rng.integers(m, h - m)), int(rng.integers(m, w - m))] = v
         mask = transform_to_binary_mask(lab, self.MASK_VALUES)
         mask = gaussian_heatmaps(mask, self.SIGMA) if self.GAUS else mask.astype(np.float32)
-        out = (img[..., None], mask.astype(np.float32))
-        if self.IN_MEMORY:
-            self._cache[ID] = out
-        return out
+        return img[..., None], mask.astype(np.float32)
 
 
 class ArrayGenerator(BaseGenerator):

@@ -35,7 +35,8 @@ class ConvStage:
         self.src1 = None
         self.c0 = self.c1 = 0
         self.cout = 0
-        self.h = self.w = 0       # output spatial size
+        self.h = self.w = 0       # output spatial size (in-plane)
+        self.d = 1                # output depth (frames of a 3-D volume; 1 for 2-D graphs)
         self.act_conv = None      # activation fused in the conv epilogue
         self.bn = None            # BN layer name
         self.act_post = None      # activation after BN (BN_FIRST)
@@ -127,8 +128,15 @@ class UnetPlan:
         stage.y = d.name
         return d
 
+    @staticmethod
+    def _dhw(shape):
+        """(depth, height, width) of a layer shape (spatial..., C); depth 1 for 2-D graphs"""
+        sp = tuple(shape[:-1])
+        return ((1,) + sp) if len(sp) == 2 else sp
+
     def _stage(self, src, **kw):
-        st = ConvStage(src0=src.name, c0=src.shape[-1], h=src.shape[0], w=src.shape[1] if self.ndims == 2 else 0, **kw)
+        d, h, w = self._dhw(src.shape)
+        st = ConvStage(src0=src.name, c0=src.shape[-1], d=d, h=h, w=w, **kw)
         self.stages.append(st)
         return st
 
@@ -165,7 +173,8 @@ class UnetPlan:
             up_shape = tuple(a * b for a, b in zip(lower.shape[:-1], self.m_pool))
             if self.use_upsample:                                         # KerasLayers.py:753-759
                 u = self._add('UpSampling', 'UpSampling%dD' % nd, [lower.name], up_shape + (lower.shape[-1],), size=self.m_pool)
-                su = ConvStage(src0=lower.name, c0=lower.shape[-1], up0=1, h=up_shape[0], w=up_shape[1] if nd == 2 else 0)
+                ud, uh, uw = self._dhw(up_shape + (0,))
+                su = ConvStage(src0=lower.name, c0=lower.shape[-1], up0=1, d=ud, h=uh, w=uw)
                 self.stages.append(su)
                 uc = self._conv(u, f, self.f_size, self.activation)
                 su.conv, su.act_conv, su.cout, su.z, su.y = uc.name, self.activation, f, uc.name, uc.name
@@ -174,19 +183,21 @@ class UnetPlan:
                 uc = self._add('ConvTranspose', 'Conv%dDTranspose' % nd, [lower.name], up_shape + (f,),
                                int(np.prod(self.f_size)) * cin * f + f, kernel=tuple(self.f_size), strides=self.m_pool,
                                activation=self.activation, cin=cin, cout=f)
-                su = ConvStage(src0=lower.name, c0=cin, up0=2, h=up_shape[0], w=up_shape[1] if nd == 2 else 0, transpose=True,
+                ud, uh, uw = self._dhw(up_shape + (0,))
+                su = ConvStage(src0=lower.name, c0=cin, up0=2, d=ud, h=uh, w=uw, transpose=True,
                                conv=uc.name, act_conv=self.activation, cout=f, z=uc.name, y=uc.name)
                 self.stages.append(su)
             cat = self._add('Concatenate', 'Concatenate', [uc.name, skip.name], up_shape + (f + skip.shape[-1],))
-            s1 = ConvStage(src0=uc.name, c0=f, src1=skip.name, c1=skip.shape[-1], h=up_shape[0], w=up_shape[1] if nd == 2 else 0)
+            ud, uh, uw = self._dhw(up_shape + (0,))
+            s1 = ConvStage(src0=uc.name, c0=f, src1=skip.name, c1=skip.shape[-1], d=ud, h=uh, w=uw)
             self.stages.append(s1)
             c = self._conv_layer(cat, f, s1)
             c = self._dropout(c, drops.pop(), s1)
             s2 = self._stage(c)
             lower = self._conv_layer(c, f, s2)
         head = self._conv(lower, self.mask_classes, (1,) * nd, 'sigmoid', name='unet')      # Unets.py:128
-        self.head = dict(conv=head.name, src=lower.name, cin=lower.shape[-1], k=self.mask_classes,
-                         h=lower.shape[0], w=lower.shape[1] if nd == 2 else 0)
+        hd_, hh_, hw_ = self._dhw(lower.shape)
+        self.head = dict(conv=head.name, src=lower.name, cin=lower.shape[-1], k=self.mask_classes, d=hd_, h=hh_, w=hw_)
 
     # -- inventories ------------------------------------------------------------------------------
     def weight_specs(self):

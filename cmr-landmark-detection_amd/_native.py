@@ -32,11 +32,13 @@ class Conv3x3Desc(C.Structure):
                 ('w_packed', vp), ('bias', vp),
                 ('y', vp), ('y1', vp), ('csplit', C.c_int32),
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
-                ('act', C.c_int32), ('dtype', C.c_int32)]
+                ('act', C.c_int32), ('dtype', C.c_int32),
+                ('depth', C.c_int32), ('kd', C.c_int32)]
 
 
 class PackEntry(C.Structure):
-    _fields_ = [('w_off', C.c_longlong), ('f_off', C.c_longlong), ('d_off', C.c_longlong), ('cin', C.c_int32), ('cout', C.c_int32)]
+    _fields_ = [('w_off', C.c_longlong), ('f_off', C.c_longlong), ('d_off', C.c_longlong), ('cin', C.c_int32), ('cout', C.c_int32),
+                ('taps', C.c_int32), ('reserved', C.c_int32)]
 
 
 class Wgrad3x3Desc(C.Structure):
@@ -45,7 +47,8 @@ class Wgrad3x3Desc(C.Structure):
                 ('dy', vp), ('dw', vp),
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('dtype', C.c_int32),
-                ('workspace', vp), ('workspace_bytes', C.c_size_t)]
+                ('workspace', vp), ('workspace_bytes', C.c_size_t),
+                ('depth', C.c_int32), ('kd', C.c_int32)]
 
 
 class ApplyDesc(C.Structure):
@@ -85,6 +88,8 @@ SIGNATURES = {
     'rvip_conv3x3_wgrad': (C.c_int, [C.POINTER(Wgrad3x3Desc), vp]),
     'rvip_conv3x3_c1_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_conv3x3_c1_wgrad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    'rvip_conv3d_c1_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rvip_conv3d_c1_wgrad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'rvip_reduce_workspace': (C.c_size_t, [C.c_longlong, C.c_int]),
     'rvip_bn_train_stats': (C.c_int, [vp, C.c_longlong, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int,
                                       vp, vp, vp, vp, vp, C.c_size_t, vp]),

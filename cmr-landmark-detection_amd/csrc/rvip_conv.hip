@@ -44,6 +44,7 @@ struct ConvArgs {
     int n, h, w, cin, cout, act;
     int tiles_x, tiles_y;
     int zs;                                   // zero-stuffed x2 read of source 0 (Conv2DTranspose): only odd (y, x) carry data
+    int depth, kd;                            // Conv3D: images per volume and depth taps (3); a plain 2-D conv has 1, 1
 };
 
 template <typename T, int TW, int NCT>
@@ -266,6 +267,7 @@ struct ConvArgs2 {
     int tiles_x, tiles_y, ntiles, wres;      // wres: weight stages resident (= nchunks) or 0 -> 2 rotating stages
     int lds_bias_off;
     int zs;
+    int depth, kd;                           // Conv3D as a K loop over depth taps: chunk kc reads image n + kc / nch - kd / 2
     int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
 };
@@ -288,7 +290,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.y * BN;
-    const int nchunks = (a.cin + KCE - 1) / KCE;
+    const int nch = (a.cin + KCE - 1) / KCE;         // chunks per depth tap
+    const int nchunks = nch * a.kd;
     const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
     const bool resident = a.wres > 0;
 
@@ -314,12 +317,14 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
         wrel[i] = (((tap * a.cout + co) * a.cin) + (dslot ^ ((row >> 2) & 3)) * VE) * (int)sizeof(T);
     }
     auto issue_weights = [&](int kc, int wstage) __attribute__((always_inline)) {
-        const int cbase = kc * KCE;
+        const int kdi = kc / nch;
+        const int cbase = (kc - kdi * nch) * KCE;
+        const int tapbase = (kdi * 9 * a.cout * a.cin + cbase) * (int)sizeof(T);
 #pragma unroll
         for (int i = 0; i < QW; ++i) {
             const int q = wv + NW * i;
             if (q < NQW) {
-                const unsigned off = (wch[i] < a.cin - cbase && !nofetch) ? (unsigned)(wrel[i] + cbase * (int)sizeof(T)) : OOB;
+                const unsigned off = (wch[i] < a.cin - cbase && !nofetch) ? (unsigned)(wrel[i] + tapbase) : OOB;
                 dma16(rsw, off, lds_base + 2 * IN_BYTES + wstage * W_BYTES + q * 1024);
             }
         }
@@ -342,12 +347,16 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
-        const int n = bx / a.tiles_y;
+        const int n_out = bx / a.tiles_y;
         const int ty0 = ty_i * TH, tx0 = tx_i * TW;
-        const int cbase = kc * KCE;
+        const int kdi = kc / nch;
+        const int dsh = kdi - (a.kd >> 1);               // depth tap: read the image dsh slices away, zeros outside the volume
+        const int n = n_out + dsh;
+        const bool dok = (unsigned)(n_out % a.depth + dsh) < (unsigned)a.depth;
+        const int cbase = (kc - kdi * nch) * KCE;
         const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
         const int cb = from0 ? cbase : cbase - a.c0;
-        const int crem = (from0 ? a.c0 : a.c1) - cb;     // channels of this source left from the chunk start
+        const int crem = dok ? (from0 ? a.c0 : a.c1) - cb : 0;     // channels of this source left from the chunk start
         const int base = from0 ? (((n * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 + cb) * (int)sizeof(T)
                                : (((n * a.h + ty0) * a.w + tx0) * a.c1 + cb) * (int)sizeof(T);
         const bool zs = from0 && a.zs;
@@ -582,7 +591,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.y * BN;
-    const int nchunks = (a.cin + KCE - 1) / KCE;
+    const int nch = (a.cin + KCE - 1) / KCE;         // chunks per depth tap
+    const int nchunks = nch * a.kd;
     const bool resident = a.wres > 0;
     const int first_tile = blockIdx.x;
     if (first_tile >= a.ntiles) return;
@@ -617,12 +627,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
             irel0[i] = ((((hy - 1) >> a.up0) * w0 + ((hx - 1) >> a.up0)) * a.c0 + ich[i]) * (int)sizeof(T);
         }
         auto issue_weights = [&](int kc, int wstage) __attribute__((always_inline)) {
-            const int cbase = kc * KCE;
+            const int kdi = kc / nch;
+            const int cbase = (kc - kdi * nch) * KCE;
+            const int tapbase = (kdi * 9 * a.cout * a.cin + cbase) * (int)sizeof(T);
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
                 const int q = lwv + 4 * i;
                 if (q < NQW) {
-                    const unsigned off = (wch[i] < a.cin - cbase) ? (unsigned)(wrel[i] + cbase * (int)sizeof(T)) : OOB;
+                    const unsigned off = (wch[i] < a.cin - cbase) ? (unsigned)(wrel[i] + tapbase) : OOB;
                     dma16(rsw, off, lds_base + 2 * IN_BYTES + wstage * W_BYTES + q * 1024);
                 }
             }
@@ -631,12 +643,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
             int bx = tile;
             const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
             const int ty_i = bx % a.tiles_y;
-            const int n = bx / a.tiles_y;
+            const int n_out = bx / a.tiles_y;
             const int ty0 = ty_i * TH, tx0 = tx_i * TW;
-            const int cbase = kc * KCE;
+            const int kdi = kc / nch;
+            const int dsh = kdi - (a.kd >> 1);               // depth tap: the image dsh slices away, zeros outside the volume
+            const int n = n_out + dsh;
+            const bool dok = (unsigned)(n_out % a.depth + dsh) < (unsigned)a.depth;
+            const int cbase = (kc - kdi * nch) * KCE;
             const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
             const int cb = from0 ? cbase : cbase - a.c0;
-            const int crem = (from0 ? a.c0 : a.c1) - cb;
+            const int crem = dok ? (from0 ? a.c0 : a.c1) - cb : 0;
             const int base = from0 ? (((n * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 + cb) * (int)sizeof(T)
                                    : (((n * a.h + ty0) * a.w + tx0) * a.c1 + cb) * (int)sizeof(T);
             const bool zs = from0 && a.zs;
@@ -845,10 +861,10 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     constexpr int KCE = 64 / (int)sizeof(T);
     constexpr int LDS_MAX = 160 * 1024;
     used = false;
-    const int nchunks = (int)cdiv(a0.cin, KCE);
+    const int nchunks = (int)cdiv(a0.cin, KCE) * a0.kd;
     const long long x0b = (long long)a0.n * (a0.h >> a0.up0) * (a0.w >> a0.up0) * a0.c0 * (long long)sizeof(T);
     const long long x1b = (long long)a0.n * a0.h * a0.w * a0.c1 * (long long)sizeof(T);
-    const long long wpb = 9LL * a0.cin * a0.cout * (long long)sizeof(T);
+    const long long wpb = 9LL * a0.kd * a0.cin * a0.cout * (long long)sizeof(T);
     if (x0b >= (1LL << 31) || x1b >= (1LL << 31) || wpb >= (1LL << 31)) return RVIP_OK;
     if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
     if (a0.y1 && a0.csplit % 32) return RVIP_OK;
@@ -859,7 +875,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -907,11 +923,11 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float
     constexpr int KCE = 64 / (int)sizeof(T);
     constexpr int LDS_MAX = 160 * 1024;
     used = false;
-    const int nchunks = (int)cdiv(a0.cin, KCE);
+    const int nchunks = (int)cdiv(a0.cin, KCE) * a0.kd;
     // eligibility: 32-bit byte offsets, chunks never straddle the concat boundary
     const long long x0b = (long long)a0.n * (a0.h >> a0.up0) * (a0.w >> a0.up0) * a0.c0 * (long long)sizeof(T);
     const long long x1b = (long long)a0.n * a0.h * a0.w * a0.c1 * (long long)sizeof(T);
-    const long long wpb = 9LL * a0.cin * a0.cout * (long long)sizeof(T);
+    const long long wpb = 9LL * a0.kd * a0.cin * a0.cout * (long long)sizeof(T);
     if (x0b >= (1LL << 31) || x1b >= (1LL << 31) || wpb >= (1LL << 31)) return RVIP_OK;
     if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
     if (a0.y1 && a0.csplit % 32) return RVIP_OK;
@@ -922,7 +938,7 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -1072,28 +1088,123 @@ __global__ __launch_bounds__(256) void conv3x3_c1_tiled(const T* __restrict__ x,
     }
 }
 
+// First layer of the 3-D graph (Conv3D, Cin = 1, 27 taps): the three input slices d-1, d, d+1 of the tile in LDS, the
+// [27][Cout] kernel in LDS as well (27 x VE registers per thread would not fit); otherwise as conv3x3_c1_tiled.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3d_c1_tiled(const T* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, unsigned char* y,
+                                                       int n, int depth, int h, int wd, int cout, int act, int tiles_x, int tiles_y) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float xs[3][10 * 34];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    float* ws = reinterpret_cast<float*>(dyn);                  // [27][cout]
+    const int tid = threadIdx.x, cg = cout / VE, cv = tid % cg, ps = tid / cg, pps = 256 / cg;
+    for (int i = tid; i < 27 * cout; i += 256) ws[i] = w[i];
+    float br[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) br[e] = bias ? bias[cv * VE + e] : 0.f;
+    const int ntiles = n * tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int bx = tile;
+        const int tx0 = (bx % tiles_x) * 32; bx /= tiles_x;
+        const int ty0 = (bx % tiles_y) * 8;
+        const int img = bx / tiles_y, dz = img % depth;
+        __syncthreads();
+        for (int i = tid; i < 3 * 340; i += 256) {
+            const int k = i / 340, r = i - k * 340;
+            const int gy = ty0 - 1 + r / 34, gx = tx0 - 1 + r % 34;
+            const bool ok = (unsigned)(dz + k - 1) < (unsigned)depth && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)wd;
+            xs[k][r] = ok ? ld1<T>(x + ((long long)(img + k - 1) * h + gy) * wd + gx) : 0.f;
+        }
+        __syncthreads();
+        for (int p = ps; p < 256; p += pps) {
+            const int py = p >> 5, px = p & 31;
+            const int gy = ty0 + py, gx = tx0 + px;
+            if (gy >= h || gx >= wd) continue;
+            float v[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = br[e];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float xv = xs[k][(py + t / 3) * 34 + px + t % 3];
+                    const float* wt = ws + (k * 9 + t) * cout + cv * VE;
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) v[e] = fmaf(xv, wt[e], v[e]);
+                }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = act_fwd(v[e], act);
+            Vec<T>::store(y + ((((size_t)img * h + gy) * wd + gx) * cout + cv * VE) * sizeof(T), v);
+        }
+    }
+}
+
 // all 3x3 kernels of the model in ONE launch: table-driven re-layout (see pack_w_kernel)
-struct PackEntry { long long w_off; long long f_off; long long d_off; int cin, cout; };
+struct PackEntry { long long w_off; long long f_off; long long d_off; int cin, cout; int taps, reserved; };
+// A workgroup moves tiles of one tap: 32 input channels x 64 output channels, read as 256-byte rows of the HWIO master,
+// written as 128-byte rows of w_dgrad (same orientation, taps reversed) and, transposed through LDS, as 64-byte rows of
+// w_fwd.  (The element-per-thread form scattered 2-byte stores Cin apart: 1.5 ms for the 138 M parameters of cfg 4.)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__ theta, const PackEntry* __restrict__ tab,
                                                        T* __restrict__ wf_base, T* __restrict__ wd_base) {
+    constexpr int TI = 32, TO = 64, LDW = TO + 1;
+    __shared__ float tile[TI * LDW];
     const PackEntry en = tab[blockIdx.y];
     const float* w = theta + en.w_off;
     T* wf = wf_base + en.f_off;
     T* wd = wd_base + en.d_off;
-    const long long total = 9LL * en.cin * en.cout;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int o = (int)(i % en.cout);
-        const int ci = (int)((i / en.cout) % en.cin);
-        const int t = (int)(i / ((long long)en.cout * en.cin));
-        const float v = w[i];
-        if constexpr (sizeof(T) == 4) {
-            wf[((size_t)t * en.cout + o) * en.cin + ci] = v;
-            wd[((size_t)(8 - t) * en.cin + ci) * en.cout + o] = v;
-        } else {
-            const uint16_t b = f32_to_bf16(v);
-            wf[((size_t)t * en.cout + o) * en.cin + ci].bits = b;
-            wd[((size_t)(8 - t) * en.cin + ci) * en.cout + o].bits = b;
+    const int nbi = (en.cin + TI - 1) / TI, nbo = (en.cout + TO - 1) / TO;
+    const int taps = en.taps > 0 ? en.taps : 9;
+    const int ntiles = taps * nbi * nbo;
+    const int tid = threadIdx.x;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int bo = tl % nbo, bi = (tl / nbo) % nbi, t = tl / (nbo * nbi);
+        const int ci0 = bi * TI, co0 = bo * TO;
+        __syncthreads();
+        // read: 32 rows x 16 float4
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + q * 256, r = idx >> 4, c4 = (idx & 15) * 4;
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ci0 + r < en.cin && co0 + c4 < en.cout) v = *reinterpret_cast<const float4*>(w + ((size_t)t * en.cin + ci0 + r) * en.cout + co0 + c4);
+            tile[r * LDW + c4] = v.x; tile[r * LDW + c4 + 1] = v.y; tile[r * LDW + c4 + 2] = v.z; tile[r * LDW + c4 + 3] = v.w;
+            // w_dgrad[8 - t][ci][co]: same row, 4 consecutive output channels
+            if (ci0 + r < en.cin && co0 + c4 < en.cout) {
+                T* dst = wd + ((size_t)(taps - 1 - t) * en.cin + ci0 + r) * en.cout + co0 + c4;
+                if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = v;
+                else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        // w_fwd[t][co][ci]: thread = (output channel, 8 input channels)
+        const int o = tid >> 2, i8 = (tid & 3) * 8;
+        if (co0 + o < en.cout && ci0 + i8 < en.cin) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[(i8 + e) * LDW + o];
+            T* dst = wf + ((size_t)t * en.cout + co0 + o) * en.cin + ci0 + i8;
+            if (en.cin & 7) {                               // ragged channel count: element stores
+                for (int e = 0; e < 8 && ci0 + i8 + e < en.cin; ++e) {
+                    if constexpr (sizeof(T) == 4) dst[e] = v[e];
+                    else dst[e].bits = f32_to_bf16(v[e]);
+                }
+            } else if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4*>(dst) = float4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<float4*>(dst + 4) = float4{v[4], v[5], v[6], v[7]};
+            } else {
+                uint4 pk;
+                pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                pk.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+                pk.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                *reinterpret_cast<uint4*>(dst) = pk;
+            }
         }
     }
 }
@@ -1118,37 +1229,6 @@ extern "C" int rvip_abi_version(void) { return 1; }
 extern "C" const char* rvip_build_info(void) { return "rvip_hip gfx950 wave64 mfma"; }
 extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
 
-extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
-    (void)hipGetLastError();
-    if (!d || !d->x0 || !d->w_packed || !d->y) return RVIP_EINVAL;
-    const int ve = d->dtype == RVIP_BF16 ? 8 : 4;
-    if (d->dtype != RVIP_BF16 && d->dtype != RVIP_F32) return RVIP_EINVAL;
-    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->c0 <= 0) return RVIP_EINVAL;
-    if (d->c0 % ve || d->c1 % ve || d->cout % 4) return RVIP_EINVAL;
-    if ((d->c1 > 0) != (d->x1 != nullptr)) return RVIP_EINVAL;
-    if (d->up0 && ((d->h | d->w) & 1)) return RVIP_EINVAL;
-    if (d->up0 < 0 || d->up0 > 2 || (d->up0 == 2 && d->c1 > 0)) return RVIP_EINVAL;
-    if (d->y1 && (d->csplit <= 0 || d->csplit >= d->cout || d->csplit % 4)) return RVIP_EINVAL;
-    if ((long long)d->n * d->h * d->w >= (1LL << 31)) return RVIP_EINVAL;
-    ConvArgs a;
-    a.x0 = (const unsigned char*)d->x0; a.x1 = (const unsigned char*)d->x1;
-    a.wp = (const unsigned char*)d->w_packed; a.bias = d->bias;
-    a.y = (unsigned char*)d->y; a.y1 = (unsigned char*)d->y1;
-    a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0 ? 1 : 0; a.zs = d->up0 == 2; a.csplit = d->csplit;
-    a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout; a.act = d->act;
-    a.tiles_x = a.tiles_y = 0;
-    hipStream_t s = (hipStream_t)stream;
-    const int gen = igemm_generation(a);
-    if (gen >= 2) {
-        bool used = false;
-        int rc;
-        if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used) : dispatch_igemm_ws<float>(a, s, used);
-        else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
-        if (rc || used) return rc;
-    }
-    return d->dtype == RVIP_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
-}
-
 static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     if (!d || !d->x0 || !d->w_packed || !d->y) return RVIP_EINVAL;
     const int ve = d->dtype == RVIP_BF16 ? 8 : 4;
@@ -1166,7 +1246,28 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0 ? 1 : 0; a.zs = d->up0 == 2; a.csplit = d->csplit;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout; a.act = d->act;
     a.tiles_x = a.tiles_y = 0;
+    a.depth = d->depth > 0 ? d->depth : 1;
+    a.kd = d->kd > 0 ? d->kd : 1;
+    if ((a.kd != 1 && a.kd != 3) || d->n % a.depth) return RVIP_EINVAL;
     return RVIP_OK;
+}
+
+extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
+    (void)hipGetLastError();
+    ConvArgs a;
+    int rc0 = conv_args_from_desc(d, a);
+    if (rc0) return rc0;
+    hipStream_t s = (hipStream_t)stream;
+    const int gen = igemm_generation(a);
+    if (gen >= 2) {
+        bool used = false;
+        int rc;
+        if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used) : dispatch_igemm_ws<float>(a, s, used);
+        else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
+        if (rc || used) return rc;
+    }
+    if (a.kd > 1) return RVIP_EUNSUPPORTED;        // the register-staged fallback is 2-D only
+    return d->dtype == RVIP_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
 }
 
 // Number of partial-statistics rows rvip_conv3x3_fwd_stats will write for this shape (0 = this shape is served by the
@@ -1239,12 +1340,29 @@ extern "C" int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* b
     return check_launch();
 }
 
+extern "C" int rvip_conv3d_c1_fwd(const void* x, const float* w, const float* bias, void* y, int n, int depth, int h, int w_,
+                                  int cout, int act, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !w || !y || n <= 0 || depth <= 0 || n % depth || h <= 0 || w_ <= 0) return RVIP_EINVAL;
+    if (dtype != RVIP_BF16 && dtype != RVIP_F32) return RVIP_EINVAL;
+    const int ve = dtype == RVIP_BF16 ? 8 : 4;
+    if (cout <= 0 || cout % ve || 256 % (cout / ve) || cout > 256) return RVIP_EINVAL;
+    const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
+    long long nt = (long long)n * tx * ty;
+    dim3 grid((unsigned)(nt < 4096 ? nt : 4096));
+    const size_t lds = (size_t)27 * cout * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(conv3d_c1_tiled<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
+    else hipLaunchKernelGGL(conv3d_c1_tiled<float>, grid, dim3(256), lds, s, (const float*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
+    return check_launch();
+}
+
 extern "C" int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
                                              void* wf_base, void* wd_base, void* stream) {
     (void)hipGetLastError();
     if (!theta || !table || entries <= 0 || max_elems <= 0 || !wf_base || !wd_base) return RVIP_EINVAL;
-    long long nb = cdiv(max_elems, 256 * 4);
-    if (nb > 64) nb = 64;
+    long long nb = cdiv(max_elems, 32 * 64);                   // tiles of the largest kernel; smaller ones leave blocks idle
+    if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     dim3 grid((unsigned)nb, (unsigned)entries);
     hipStream_t s = (hipStream_t)stream;

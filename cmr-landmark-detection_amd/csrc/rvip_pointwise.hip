@@ -712,7 +712,8 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const T* __restrict__ x, 
 // tiled form of the same reduction: halo of the single input channel in LDS, thread = (pixel slot, channel vector)
 template <typename T>
 __global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, const unsigned char* __restrict__ dy,
-                                                      int n, int h, int w, int cout, int tiles_x, int tiles_y, float* __restrict__ ws) {
+                                                      int n, int h, int w, int cout, int tiles_x, int tiles_y, float* __restrict__ ws,
+                                                      int depth, int dshift) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float xs[10 * 34];
     __shared__ float lds[256 * VE];
@@ -728,13 +729,15 @@ __global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, c
         const int tx0 = (bx % tiles_x) * 32; bx /= tiles_x;
         const int ty0 = (bx % tiles_y) * 8;
         const long long img = bx / tiles_y;
+        const long long ximg = img + dshift;                   // Conv3D depth tap: the slice dshift away, zeros outside the volume
+        const bool dok = (unsigned)((int)(img % depth) + dshift) < (unsigned)depth;
         __syncthreads();
         for (int i = tid; i < 340; i += 256) {
             const int gy = ty0 - 1 + i / 34, gx = tx0 - 1 + i % 34;
             float xv = 0.f;
-            if ((unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) {
-                if constexpr (sizeof(T) == 4) xv = x[(img * h + gy) * w + gx];
-                else xv = bf16_to_f32(x[(img * h + gy) * w + gx].bits);
+            if (dok && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) {
+                if constexpr (sizeof(T) == 4) xv = x[(ximg * h + gy) * w + gx];
+                else xv = bf16_to_f32(x[(ximg * h + gy) * w + gx].bits);
             }
             xs[i] = xv;
         }
@@ -1060,8 +1063,8 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
         long long nt = (long long)n * tx * ty;
         const int nb = (int)(nt < 1024 ? nt : 1024);
         if (workspace_bytes < (size_t)nb * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
-        if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws);
-        else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws);
+        if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0);
+        else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0);
         int rc2 = check_launch();
         if (rc2) return rc2;
         PostC1Wgrad p2{dw, cout};
@@ -1073,6 +1076,31 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
     if (rc) return rc;
     PostC1Wgrad p{dw, cout};
     return launch_fold_k<PostC1Wgrad>(ws, g.nblk, cout, 9, p, s);
+}
+
+// Conv3D first layer (Cin = 1): dw[27][Cout], one 9-tap pass per depth tap with x shifted inside the volume
+extern "C" int rvip_conv3d_c1_wgrad(const void* x, const void* dy, float* dw, int n, int depth, int h, int w_, int cout, int dtype,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !dy || !dw || !workspace || !RVIP_DT_OK(dtype) || n <= 0 || depth <= 0 || n % depth || h <= 0 || w_ <= 0) return RVIP_EINVAL;
+    const int ve = RVIP_VE(dtype);
+    if (cout <= 0 || cout % ve || 256 % (cout / ve)) return RVIP_EINVAL;
+    const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
+    long long nt = (long long)n * tx * ty;
+    const int nb = (int)(nt < 1024 ? nt : 1024);
+    if (workspace_bytes < (size_t)nb * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    for (int kdi = 0; kdi < 3; ++kdi) {
+        if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1);
+        else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1);
+        int rc = check_launch();
+        if (rc) return rc;
+        PostC1Wgrad p{dw + (size_t)kdi * 9 * cout, cout};
+        rc = launch_fold_k<PostC1Wgrad>(ws, nb, cout, 9, p, s);
+        if (rc) return rc;
+    }
+    return RVIP_OK;
 }
 
 extern "C" int rvip_landmarks(const float* pred, long long* idx_out, uint8_t* mask_out, int n, int hw, int k, float thr, void* stream) {

@@ -191,6 +191,7 @@ struct WgArgs2 {
     int n, h, w, cin, cout;
     int tiles_x, tiles_y, ntiles, nsplit;
     int zs;
+    int depth, dshift;                        // Conv3D depth tap: X is read from image n + dshift of the same volume (zeros outside)
     int dbg;                                  // ablation only (RVIP_DBG): 1 = no DMA after the first tile, 2 = no MFMA, 4 = DMAs fetch nothing
 };
 
@@ -259,14 +260,15 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
         const int ty_i = bx % a.tiles_y;
         const int n = bx / a.tiles_y;
         const int ty0 = ty_i * TH, tx0 = tx_i * TW;
-        const int xbase = ((n * hs + (ty0 >> shf)) * wsrc + (tx0 >> shf)) * csrc * ESZ;
+        const bool dok = (unsigned)(n % a.depth + a.dshift) < (unsigned)a.depth;
+        const int xbase = (((n + a.dshift) * hs + (ty0 >> shf)) * wsrc + (tx0 >> shf)) * csrc * ESZ;
         const int gbase = ((n * a.h + ty0) * a.w + tx0) * a.cout * ESZ;
 #pragma unroll
         for (int i = 0; i < QX; ++i) {
             const int q = wv + 4 * i;
             if (q < NQX) {
                 const int gy = ty0 + xhy[i], gx = tx0 + xhx[i];
-                bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+                bool ok = dok && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
                 if (zsx) ok = ok && ((gy & gx) & 1);
                 const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(xbase + xrel[i]) : OOB;
                 dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
@@ -539,13 +541,15 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0 ? 1 : 0; a.zs = d->up0 == 2;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->c0 + d->c1; a.cout = d->cout;
     hipStream_t s = (hipStream_t)stream;
-    int rc;
+    int rc = RVIP_OK;
+    const int depth = d->depth > 0 ? d->depth : 1, kd = d->kd > 0 ? d->kd : 1;
+    if ((kd != 1 && kd != 3) || d->n % depth) return RVIP_EINVAL;
     static const bool force_v1 = [] { const char* e = getenv("RVIP_WGRAD"); return e && e[0] == 'v' && e[1] == '1'; }();
     const long long esz = d->dtype == RVIP_BF16 ? 2 : 4;
     const long long x0b = (long long)a.n * (a.h >> a.up0) * (a.w >> a.up0) * a.c0 * esz, x1b = (long long)a.n * a.h * a.w * a.c1 * esz;
     const long long dyb = (long long)a.n * a.h * a.w * a.cout * esz;
     const Wg2Geom g2 = wgrad2_geometry(a.n, a.h, a.w, a.c0, a.c1, a.cout, d->dtype);
-    if (!force_v1 && g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) {
+    if ((!force_v1 || kd > 1) && g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) {
         WgArgs2 b;
         b.x0 = a.x0; b.x1 = a.x1; b.dy = a.dy; b.slab = a.slab;
         b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.dy_bytes = (unsigned)dyb;
@@ -553,25 +557,32 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
         b.tiles_x = g2.tiles_x; b.tiles_y = g2.tiles_y; b.ntiles = g2.ntiles; b.nsplit = g2.nsplit;
         { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
         if (d->workspace_bytes < (size_t)b.nsplit * 9 * a.cin * a.cout * sizeof(float)) return RVIP_EWORKSPACE;
-        if (d->dtype == RVIP_BF16) {
-            if (g2.tw == 32) {
-                if (g2.cib == 64 && g2.cob == 64) rc = launch_wgrad2<bf16_t, 32, 64, 64>(b, s);
-                else if (g2.cib == 64) rc = launch_wgrad2<bf16_t, 32, 64, 32>(b, s);
-                else if (g2.cob == 64) rc = launch_wgrad2<bf16_t, 32, 32, 64>(b, s);
-                else rc = launch_wgrad2<bf16_t, 32, 32, 32>(b, s);
-            } else {
-                if (g2.cib == 64 && g2.cob == 64) rc = launch_wgrad2<bf16_t, 16, 64, 64>(b, s);
-                else if (g2.cib == 64) rc = launch_wgrad2<bf16_t, 16, 64, 32>(b, s);
-                else if (g2.cob == 64) rc = launch_wgrad2<bf16_t, 16, 32, 64>(b, s);
-                else rc = launch_wgrad2<bf16_t, 16, 32, 32>(b, s);
-            }
-        } else {
-            rc = g2.tw == 32 ? launch_wgrad2<float, 32, 32, 32>(b, s) : launch_wgrad2<float, 16, 32, 32>(b, s);
-        }
-        if (rc) return rc;
+        // Conv3D: one pass per depth tap (X shifted by kdi - 1 images inside the volume) into dw[kdi][9][Cin][Cout]
         const long long count2 = 9LL * a.cin * a.cout;
-        return launch_wgrad_fold(a.slab, b.nsplit, count2, d->dw, s);
+        for (int kdi = 0; kdi < kd; ++kdi) {
+            b.depth = depth; b.dshift = kdi - (kd >> 1);
+            if (d->dtype == RVIP_BF16) {
+                if (g2.tw == 32) {
+                    if (g2.cib == 64 && g2.cob == 64) rc = launch_wgrad2<bf16_t, 32, 64, 64>(b, s);
+                    else if (g2.cib == 64) rc = launch_wgrad2<bf16_t, 32, 64, 32>(b, s);
+                    else if (g2.cob == 64) rc = launch_wgrad2<bf16_t, 32, 32, 64>(b, s);
+                    else rc = launch_wgrad2<bf16_t, 32, 32, 32>(b, s);
+                } else {
+                    if (g2.cib == 64 && g2.cob == 64) rc = launch_wgrad2<bf16_t, 16, 64, 64>(b, s);
+                    else if (g2.cib == 64) rc = launch_wgrad2<bf16_t, 16, 64, 32>(b, s);
+                    else if (g2.cob == 64) rc = launch_wgrad2<bf16_t, 16, 32, 64>(b, s);
+                    else rc = launch_wgrad2<bf16_t, 16, 32, 32>(b, s);
+                }
+            } else {
+                rc = g2.tw == 32 ? launch_wgrad2<float, 32, 32, 32>(b, s) : launch_wgrad2<float, 16, 32, 32>(b, s);
+            }
+            if (rc) return rc;
+            rc = launch_wgrad_fold(a.slab, b.nsplit, count2, d->dw + (size_t)kdi * count2, s);
+            if (rc) return rc;
+        }
+        return RVIP_OK;
     }
+    if (kd > 1) return RVIP_EUNSUPPORTED;         // the register-staged fallback is 2-D only
     int tw;
     wgrad_geometry(a.n, a.h, a.w, a.cin, a.cout, tw, a.tiles_x, a.tiles_y, a.ntiles, a.nsplit);
     const size_t need = (size_t)a.nsplit * 9 * a.cin * a.cout * sizeof(float);

@@ -80,9 +80,10 @@ class ParamStore:
         # Conv2DTranspose(3, strides=2, 'same') layers (USE_UPSAMPLE=False) are kept on the device as the EQUIVALENT forward
         # conv over the zero-stuffed input: Weq[t][ci][co] = W_hwoi[2-t][co][ci] (taps reversed, last two axes swapped)
         self.transposed = {st.conv for st in plan.stages if st.transpose}
+        self.taps = 27 if plan.ndims == 3 else 9          # Conv3D(3x3x3): taps (kd, kh, kw) row-major
         for st in plan.stages:
             if st.src0 != 'input_1':
-                k = 9 * st.cin * st.cout
+                k = self.taps * st.cin * st.cout
                 entries.append((st.conv, self.off[(st.conv, 'kernel')][0], off, st.cin, st.cout))
                 off += -(-k // ALIGN) * ALIGN
         self.wf_all = torch.empty(max(off, ALIGN), dtype=self.tdtype, device=device)
@@ -91,7 +92,8 @@ class ParamStore:
         self.pack_max = 1
         for i, (name, w_off, p_off, cin, cout) in enumerate(entries):
             tab[i].w_off, tab[i].f_off, tab[i].d_off, tab[i].cin, tab[i].cout = w_off, p_off, p_off, cin, cout
-            k = 9 * cin * cout
+            tab[i].taps = self.taps
+            k = self.taps * cin * cout
             self.packed[name] = (self.wf_all[p_off:p_off + k], self.wd_all[p_off:p_off + k])
             self.pack_max = max(self.pack_max, k)
         self.pack_entries = len(entries)
@@ -183,10 +185,21 @@ class Engine:
     def __init__(self, params, batch, loss_kind='mse', w_bce=0.5, w_dice=1.0, world=1, masks=None):
         torch = require_gpu()
         L = N.lib()
-        self.P, self.plan, self.n = params, params.plan, int(batch)
-        plan, P, n = self.plan, params, self.n
-        if plan.ndims != 2:
-            raise NotImplementedError('3-D (Conv3D) graphs are a later round; DIM must have 2 entries')
+        self.P, self.plan, self.batch = params, params.plan, int(batch)
+        plan, P = self.plan, params
+        # 3-D graphs (Conv3D on [B,T,H,W,C] volumes, cfg 5): every tensor is held as B*T images [B*T,H,W,C]; the depth axis
+        # only enters the 3x3x3 convolutions (depth taps read the neighbouring images of the same volume), the pooling and
+        # up-sampling of the reference's 3-D template act in-plane (M_POOL (1,2,2)).
+        self.depth = int(plan.dim[0]) if plan.ndims == 3 else 1
+        self.kd = 3 if plan.ndims == 3 else 1
+        if plan.ndims == 3:
+            if tuple(plan.f_size) != (3, 3, 3) or tuple(plan.m_pool)[0] != 1 or tuple(plan.m_pool)[1:] != (2, 2):
+                raise NotImplementedError('3-D graphs: F_SIZE (3,3,3) and M_POOL (1,2,2) (the reference template) are built')
+            if any(st.transpose for st in plan.stages):
+                raise NotImplementedError('3-D graphs: Conv3DTranspose (USE_UPSAMPLE false) is not built')
+        elif tuple(plan.f_size) != (3, 3) or tuple(plan.m_pool) != (2, 2):
+            raise NotImplementedError('2-D graphs: F_SIZE (3,3) and M_POOL (2,2) are built')
+        self.n = n = self.batch * self.depth
         ve = 8 if P.dt == N.BF16 else 4
         for st in plan.stages:
             if st.cout % ve or (st.src0 != 'input_1' and (st.c0 % ve or st.c1 % ve)):
@@ -199,8 +212,9 @@ class Engine:
         self.loss_kind = N.LOSS_MSE if loss_kind == 'mse' else N.LOSS_BCE_DICE
         self.w_bce, self.w_dice = float(w_bce), float(w_dice)
         self.masks = masks or {}                  # dropout layer name -> uint8 device tensor (parity runs)
-        H, W = plan.dim
+        H, W = plan.dim[-2:]
         K = plan.mask_classes
+        self.out_shape = (self.batch,) + tuple(plan.dim) + (K,)
         self.act, self.grd, self.gskip = {}, {}, {}
         shape = {}
 
@@ -293,6 +307,7 @@ class Engine:
                 list.append(self, (item[0], item[1], self.label))
         fwd_t, fwd_i, bwd = _Labelled(), _Labelled(), _Labelled()
         esz = 2 if dt == N.BF16 else 4
+        unbiased = 1 if self.kd == 1 else 0     # TF 2.3: fused 4-D BN feeds the unbiased variance to the moving average, 5-D does not
 
         for st in plan.stages:
             rows = n * st.h * st.w
@@ -302,7 +317,10 @@ class Engine:
             bias = P.p(st.conv, 'bias')
             act_conv = A[st.act_conv]
             # ---- conv ----
-            if first:
+            if first and self.kd == 3:
+                call = (L.rvip_conv3d_c1_fwd, (_ptr(self.act['input_1']), P.p(st.conv, 'kernel'), bias, _ptr(z),
+                                               n, self.depth, st.h, st.w, st.cout, act_conv, dt))
+            elif first:
                 call = (L.rvip_conv3x3_c1_fwd, (_ptr(self.act['input_1']), P.p(st.conv, 'kernel'), bias, _ptr(z),
                                                 n, st.h, st.w, st.cout, act_conv, dt))
             else:
@@ -313,6 +331,7 @@ class Engine:
                 d.bias = bias.value
                 d.y, d.y1, d.csplit = z.data_ptr(), None, 0
                 d.n, d.h, d.w, d.cout, d.act, d.dtype = n, st.h, st.w, st.cout, act_conv, dt
+                d.depth, d.kd = self.depth, self.kd
                 self._keep.append(d)
                 call = (L.rvip_conv3x3_fwd, (C.byref(d),))
             # ---- BN statistics / coefficients ----
@@ -323,7 +342,7 @@ class Engine:
                 fwd_t.append((L.rvip_conv3x3_fwd_stats, (C.byref(d), ws, wsb)))
                 fwd_t.append((L.rvip_bn_stats_finalize, (
                     ws, fused_rows, C.c_longlong(rows), st.cout, P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'),
-                    P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), 1,
+                    P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), unbiased,
                     self._bn(st, 'mean'), self._bn(st, 'invstd'), self._bn(st, 'scale'), self._bn(st, 'shift'))))
             else:
                 fwd_t.append(call)
@@ -332,7 +351,7 @@ class Engine:
                 if fused_rows <= 0:
                     fwd_t.append((L.rvip_bn_train_stats, (
                         _ptr(z), C.c_longlong(rows), st.cout, dt, P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'),
-                        P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), 1,
+                        P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), unbiased,
                         self._bn(st, 'mean'), self._bn(st, 'invstd'), self._bn(st, 'scale'), self._bn(st, 'shift'), ws, wsb)))
                 fwd_i.append((L.rvip_bn_infer_coeffs, (
                     P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'), P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'),
@@ -409,6 +428,10 @@ class Engine:
             if st.bn:
                 bwd.append((L.rvip_bn_bwd_reduce, (C.byref(b),)))
             bwd.append((L.rvip_bn_bwd_apply, (C.byref(b),)))
+            if first and self.kd == 3:
+                bwd.append((L.rvip_conv3d_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, self.depth,
+                                                     st.h, st.w, st.cout, dt, _ptr(self.ws_wg), C.c_size_t(self.ws_wg_bytes))))
+                continue
             if first:
                 bwd.append((L.rvip_conv3x3_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, st.h, st.w,
                                                       st.cout, dt, _ptr(self.ws_wg), C.c_size_t(self.ws_wg_bytes))))
@@ -418,6 +441,7 @@ class Engine:
             wg.x1, wg.c1 = (self.act[st.src1].data_ptr(), st.c1) if st.src1 else (None, 0)
             wg.dy, wg.dw = dz.data_ptr(), P.g(st.conv, 'kernel').value
             wg.n, wg.h, wg.w, wg.cout, wg.dtype = n, st.h, st.w, st.cout, dt
+            wg.depth, wg.kd = self.depth, self.kd
             wg.workspace, wg.workspace_bytes = self.ws_wg.data_ptr(), self.ws_wg_bytes
             self._keep.append(wg)
             bwd.append((L.rvip_conv3x3_wgrad, (C.byref(wg),)))
@@ -425,6 +449,7 @@ class Engine:
             dg.x0, dg.c0, dg.up0, dg.x1, dg.c1 = dz.data_ptr(), st.cout, 0, None, 0
             dg.w_packed, dg.bias = P.packed[st.conv][1].data_ptr(), None
             dg.n, dg.h, dg.w, dg.cout, dg.act, dg.dtype = n, st.h, st.w, st.cin, 0, dt
+            dg.depth, dg.kd = self.depth, self.kd
             dg.y1, dg.csplit = None, 0
             if st.src1:
                 dg.y, dg.y1, dg.csplit = self.grd[st.src0].data_ptr(), self.gskip[st.src1].data_ptr(), st.c0

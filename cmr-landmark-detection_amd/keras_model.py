@@ -297,7 +297,7 @@ class Model:
         eng = self._engine(x.shape[0])
         eng.load_input(x)
         eng.forward(training=False)
-        return eng.pred.detach().cpu().numpy()
+        return eng.pred.detach().cpu().numpy().reshape(eng.out_shape)
 
     def predict(self, x, batch_size=None, verbose=0, **_):
         """ndarray [N,*DIM,1] or a Sequence yielding (x, y) / x batches; returns float32 [N,*DIM,C] in order."""
@@ -320,7 +320,7 @@ class Model:
         eng.load_input(x)
         eng.forward(training=False)
         idx, mask = eng.landmarks(thr, want_mask=True)
-        return idx.cpu().numpy(), mask.cpu().numpy()
+        return idx.cpu().numpy().reshape(eng.out_shape[:-3] + eng.out_shape[-1:]), mask.cpu().numpy().reshape(eng.out_shape)
 
     def evaluate(self, x, y=None, verbose=0, return_dict=False, **_):
         tot, cnt = None, 0

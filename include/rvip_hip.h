@@ -83,6 +83,11 @@ typedef struct rvip_conv3x3_desc {
     int32_t      n, h, w, cout;
     int32_t      act;                 /* RVIP_ACT_* applied after bias */
     int32_t      dtype;               /* RVIP_F32 / RVIP_BF16 (x0, x1, w_packed, y, y1) */
+    /* Conv3D(3x3x3, 'same') on NDHWC (KerasLayers.py:679 f_size[:ndims]; cfg 5): the N images are volumes of `depth`
+     * consecutive slices and the contraction also runs over kd = 3 depth taps (slice d-1, d, d+1 of the same
+     * volume, zeros outside); w_packed is then [27][Cout][C0+C1], tap = (kd, kh, kw) row-major.  0 / 0 (or 1 / 1)
+     * = the plain 2-D convolution. */
+    int32_t      depth, kd;
 } rvip_conv3x3_desc;
 
 int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
@@ -103,8 +108,9 @@ int rvip_pack_conv3x3_weights(const float* w_hwio, int cin, int cout, int dtype,
 
 /* The same re-layout for ALL 3x3 kernels of a model in one launch.  `theta` is the flat fp32 parameter block;
  * `table` is a DEVICE array of `entries` records {int64 w_off (floats into theta), int64 f_off, int64 d_off
- * (elements into wf_base / wd_base), int32 cin, int32 cout}; max_elems = max over entries of 9*cin*cout. */
-typedef struct rvip_pack_entry { long long w_off, f_off, d_off; int32_t cin, cout; } rvip_pack_entry;
+ * (elements into wf_base / wd_base), int32 cin, int32 cout, int32 taps (9, or 27 for a 3x3x3 kernel; 0 = 9),
+ * int32 reserved}; max_elems = max over entries of taps*cin*cout. */
+typedef struct rvip_pack_entry { long long w_off, f_off, d_off; int32_t cin, cout; int32_t taps, reserved; } rvip_pack_entry;
 int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
                                   void* wf_base, void* wd_base, void* stream);
 
@@ -120,6 +126,7 @@ typedef struct rvip_wgrad3x3_desc {
     int32_t      n, h, w, cout;
     int32_t      dtype;
     void*        workspace;  size_t workspace_bytes;
+    int32_t      depth, kd;           /* Conv3D: as in rvip_conv3x3_desc; dw is then [27][C0+C1][Cout] */
 } rvip_wgrad3x3_desc;
 
 size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout);
@@ -132,6 +139,12 @@ int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* bias, void* 
                         int n, int h, int w_, int cout, int act, int dtype, void* stream);
 int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cout,
                           int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* The same first layer of the 3-D graph: Conv3D(3x3x3, 'same') with Cin = 1 on n = N*depth slices (volumes of `depth`
+ * consecutive slices), weights fp32 DHWIO [27][1][Cout]; wgrad writes dw[27][Cout].  Cout/VE must divide 256. */
+int rvip_conv3d_c1_fwd(const void* x, const float* w, const float* bias, void* y,
+                       int n, int depth, int h, int w_, int cout, int act, int dtype, void* stream);
+int rvip_conv3d_c1_wgrad(const void* x, const void* dy, float* dw, int n, int depth, int h, int w_, int cout,
+                         int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-channel reductions use a two-stage deterministic scheme: stage 1 writes one partial row per

@@ -241,6 +241,49 @@ def conv2d_same_bwd(x, w, dy):
     return dx, dw, dy2.sum(0)
 
 
+def conv3d_same_fwd(x, w, b=None):
+    """Conv3D(padding='same', strides=1) on NDHWC, DHWIO kernel (KerasLayers.py:679 slices f_size[:ndims]; cfg 5):
+    cross-correlation, zero pad (k-1)//2 before / the rest after, like the 2-D op."""
+    kd, kh, kw, ci, co = w.shape
+    n, d, h, wd, _ = x.shape
+    pd, pt, pl = (kd - 1) // 2, (kh - 1) // 2, (kw - 1) // 2
+    xp = np.pad(x, ((0, 0), (pd, kd - 1 - pd), (pt, kh - 1 - pt), (pl, kw - 1 - pl), (0, 0)))
+    y = np.zeros((n, d, h, wd, co), dtype=np.result_type(x, w))
+    for a in range(kd):
+        for i in range(kh):
+            for j in range(kw):
+                y += xp[:, a:a + d, i:i + h, j:j + wd, :] @ w[a, i, j]
+    if b is not None:
+        y += b
+    return y
+
+
+def conv3d_same_bwd(x, w, dy):
+    """Returns (dx, dw, db) of conv3d_same_fwd."""
+    kd, kh, kw, ci, co = w.shape
+    n, d, h, wd, _ = x.shape
+    pd, pt, pl = (kd - 1) // 2, (kh - 1) // 2, (kw - 1) // 2
+    xp = np.pad(x, ((0, 0), (pd, kd - 1 - pd), (pt, kh - 1 - pt), (pl, kw - 1 - pl), (0, 0)))
+    dxp = np.zeros_like(xp, dtype=np.result_type(x, w, dy))
+    dw = np.zeros_like(w, dtype=dxp.dtype)
+    dy2 = dy.reshape(-1, co)
+    for a in range(kd):
+        for i in range(kh):
+            for j in range(kw):
+                dxp[:, a:a + d, i:i + h, j:j + wd, :] += dy @ w[a, i, j].T
+                dw[a, i, j] = xp[:, a:a + d, i:i + h, j:j + wd, :].reshape(-1, ci).T @ dy2
+    dx = dxp[:, pd:pd + d, pt:pt + h, pl:pl + wd, :]
+    return dx, dw, dy2.sum(0)
+
+
+def conv_same_fwd(x, w, b=None):
+    return conv3d_same_fwd(x, w, b) if w.ndim == 5 else conv2d_same_fwd(x, w, b)
+
+
+def conv_same_bwd(x, w, dy):
+    return conv3d_same_bwd(x, w, dy) if w.ndim == 5 else conv2d_same_bwd(x, w, dy)
+
+
 def conv2d_transpose_same_fwd(x, w, b=None, stride=2):
     """Conv2DTranspose(k, strides=s, padding='same'): the input-gradient of a SAME stride-s conv
     (pad_before = 0 for k=3,s=2): out[s*i + k] += in[i] . W[k] cropped to s*N.  Kernel HWOI."""
@@ -362,11 +405,42 @@ def maxpool2x2_bwd(dy, idx, in_shape, pool=(2, 2)):
     return dx
 
 
+def maxpool3d_fwd(x, pool=(1, 2, 2)):
+    """MaxPooling3D(pool), valid, NDHWC; first maximum in row-major (d, h, w) window order."""
+    pd, ph, pw = pool
+    n, d, h, w, c = x.shape
+    od, oh, ow = d // pd, h // ph, w // pw
+    win = x[:, :od * pd, :oh * ph, :ow * pw, :].reshape(n, od, pd, oh, ph, ow, pw, c)
+    win = win.transpose(0, 1, 3, 5, 7, 2, 4, 6).reshape(n, od, oh, ow, c, pd * ph * pw)
+    idx = win.argmax(-1)
+    y = np.take_along_axis(win, idx[..., None], -1)[..., 0]
+    return y, idx
+
+
+def maxpool3d_bwd(dy, idx, in_shape, pool=(1, 2, 2)):
+    pd, ph, pw = pool
+    n, d, h, w, c = in_shape
+    od, oh, ow = d // pd, h // ph, w // pw
+    dwin = np.zeros((n, od, oh, ow, c, pd * ph * pw), dtype=dy.dtype)
+    np.put_along_axis(dwin, idx[..., None], dy[..., None], -1)
+    dx = np.zeros(in_shape, dtype=dy.dtype)
+    dx[:, :od * pd, :oh * ph, :ow * pw, :] = dwin.reshape(n, od, oh, ow, c, pd, ph, pw).transpose(0, 1, 5, 2, 6, 3, 7, 4).reshape(
+        n, od * pd, oh * ph, ow * pw, c)
+    return dx
+
+
 def upsample_nearest_fwd(x, size=(2, 2)):
-    return x.repeat(size[0], axis=1).repeat(size[1], axis=2)
+    for ax, sz in enumerate(size):
+        if sz != 1:
+            x = x.repeat(sz, axis=1 + ax)
+    return x
 
 
 def upsample_nearest_bwd(dy, size=(2, 2)):
+    if len(size) == 3:
+        n, d, h, w, c = dy.shape
+        sd, sh, sw = size
+        return dy.reshape(n, d // sd, sd, h // sh, sh, w // sw, sw, c).sum((2, 4, 6))
     n, h, w, c = dy.shape
     sh, sw = size
     return dy.reshape(n, h // sh, sh, w // sw, sw, c).sum((2, 4))
@@ -450,7 +524,7 @@ def knife_edges(layers, cache, rel=3e-6):
     out = []
     t = cache['tensors']
     for l in layers:
-        if l['type'] == 'Conv2D' and l.get('activation') == 'relu' and l['name'] in cache.get('pre', {}):
+        if l['type'] in ('Conv2D', 'Conv3D') and l.get('activation') == 'relu' and l['name'] in cache.get('pre', {}):
             a = np.abs(cache['pre'][l['name']])
             n = int((a < rel * max(a.max(), 1e-30)).sum())
             if n:
@@ -460,8 +534,12 @@ def knife_edges(layers, cache, rel=3e-6):
             n = int((a < rel * max(a.max(), 1e-30)).sum())
             if n:
                 out.append((l['name'], n))
-        elif l['type'] == 'MaxPooling2D':
+        elif l['type'] in ('MaxPooling2D', 'MaxPooling3D'):
             x = t[l['inputs'][0]]
+            if x.ndim == 5:                                  # (1,2,2) pooling: frames are independent images
+                if tuple(l['pool']) != (1, 2, 2):
+                    continue
+                x = x.reshape((-1,) + x.shape[2:])
             n_, h, w, c = x.shape
             win = x[:, :h // 2 * 2, :w // 2 * 2, :].reshape(n_, h // 2, 2, w // 2, 2, c).transpose(0, 1, 3, 5, 2, 4).reshape(-1, 4)
             srt = np.sort(win, -1)
@@ -473,7 +551,11 @@ def knife_edges(layers, cache, rel=3e-6):
 
 
 def landmark_argmax(heat):
-    """Flat argmax per (slice, channel), row-major over (H, W), first max wins."""
+    """Flat argmax per (slice, channel), row-major over (H, W), first max wins.  5-D volumes
+    [B,T,H,W,C] are taken frame by frame -> [B,T,C]."""
+    if heat.ndim == 5:
+        b, t = heat.shape[:2]
+        return landmark_argmax(heat.reshape((b * t,) + heat.shape[2:])).reshape(b, t, -1)
     n, h, w, c = heat.shape
     return heat.transpose(0, 3, 1, 2).reshape(n, c, h * w).argmax(-1).astype(np.int64)
 
@@ -545,7 +627,7 @@ class OracleUNet:
         self._mat = set()
         for l in self.layers:
             t = l['type']
-            if t in ('InputLayer', 'MaxPooling2D') or (t.startswith('Conv') and l['name'] != 'unet'):
+            if t in ('InputLayer', 'MaxPooling2D', 'MaxPooling3D') or (t.startswith('Conv') and l['name'] != 'unet'):
                 self._mat.add(l['name'])
             elif t in ('BatchNormalization', 'Activation', 'Dropout'):
                 if not any(c in ('Activation', 'Dropout') for c in consumers.get(l['name'], [])):
@@ -558,8 +640,9 @@ class OracleUNet:
         self.iterations = 0
         self.opt_m = None
         self.opt_v = None
-        if len(self.layers[0]['shape']) != 3:
-            raise NotImplementedError('oracle executes 2-D graphs; 3-D (Conv3D) is a later round')
+        self.ndims = len(self.layers[0]['shape']) - 1
+        if self.ndims == 3 and any(l['type'] == 'Conv3DTranspose' for l in self.layers):
+            raise NotImplementedError('oracle: Conv3DTranspose (USE_UPSAMPLE false on 3-D graphs) is not restated')
 
     # -- forward ---------------------------------------------------------------------------
     def forward(self, x, training=False, dropout_masks=None):
@@ -572,11 +655,11 @@ class OracleUNet:
             ins = [t[i] for i in l['inputs']]
             if ty == 'InputLayer':
                 out = x
-            elif ty == 'Conv2D':
+            elif ty in ('Conv2D', 'Conv3D'):
                 w, b = self.params[name]
                 if self.quant is not None and name in self._qweights:
                     w = self.quant(w)
-                pre = conv2d_same_fwd(ins[0], w, b)
+                pre = conv_same_fwd(ins[0], w, b)
                 out = act_fwd(pre, l['activation'])
                 cache.setdefault('pre', {})[name] = pre
                 if name == 'unet':
@@ -604,7 +687,10 @@ class OracleUNet:
             elif ty == 'MaxPooling2D':
                 out, idx = maxpool2x2_fwd(ins[0], l['pool'])
                 cache[name] = idx
-            elif ty == 'UpSampling2D':
+            elif ty == 'MaxPooling3D':
+                out, idx = maxpool3d_fwd(ins[0], l['pool'])
+                cache[name] = idx
+            elif ty in ('UpSampling2D', 'UpSampling3D'):
                 out = upsample_nearest_fwd(ins[0], l['size'])
             elif ty == 'Concatenate':
                 out = np.concatenate(ins, axis=-1)
@@ -638,18 +724,18 @@ class OracleUNet:
             dy = dt.pop(name)
             ins = l['inputs']
             q = self.quant
-            if q is not None and (name in self._mat or ty in ('UpSampling2D', 'Concatenate')):
+            if q is not None and (name in self._mat or ty in ('UpSampling2D', 'UpSampling3D', 'Concatenate')):
                 dy = q(dy)                                  # a materialised gradient tensor (sum rounded once)
             if ty == 'InputLayer':
                 continue
-            if ty == 'Conv2D':
+            if ty in ('Conv2D', 'Conv3D'):
                 w, _ = self.params[name]
                 if q is not None and name in self._qweights:
                     w = q(w)
                 dpre = dy if (name == 'unet' and d_is_logit_grad) else act_bwd(t[name], dy, l['activation'])
                 if q is not None and name != 'unet':
                     dpre = q(dpre)                          # dz: what wgrad / dgrad read
-                dx, dw, db = conv2d_same_bwd(t[ins[0]], w, dpre)
+                dx, dw, db = conv_same_bwd(t[ins[0]], w, dpre)
                 if q is not None:
                     dx = q(dx)
                 grads[name] = [dw, db]
@@ -674,7 +760,9 @@ class OracleUNet:
                     acc(ins[0], dy)
             elif ty == 'MaxPooling2D':
                 acc(ins[0], maxpool2x2_bwd(dy, cache[name], t[ins[0]].shape, l['pool']))
-            elif ty == 'UpSampling2D':
+            elif ty == 'MaxPooling3D':
+                acc(ins[0], maxpool3d_bwd(dy, cache[name], t[ins[0]].shape, l['pool']))
+            elif ty in ('UpSampling2D', 'UpSampling3D'):
                 acc(ins[0], upsample_nearest_bwd(dy, l['size']))
             elif ty == 'Concatenate':
                 off = 0
@@ -701,13 +789,14 @@ class OracleUNet:
         return val, grads, pred, cache
 
     def apply_bn_moving(self, cache):
-        """moving stats of every BN layer, each with its own count N*H*W (fused 4-D kernel: unbiased var)."""
+        """moving stats of every BN layer, each with its own count N*H*W (fused 4-D kernel: unbiased var; 5-D inputs
+        take TF 2.3's non-fused path: biased var, SURVEY 8(a) note 3)."""
         for l in self.layers:
             if l['type'] == 'BatchNormalization' and l['name'] in cache:
                 cnt = float(np.prod(cache['tensors'][l['inputs'][0]].shape[:-1]))
                 _, _, mean, var = cache[l['name']]
                 p = self.params[l['name']]
-                mm, mv = bn_moving_update(p[2], p[3], mean, var, cnt)
+                mm, mv = bn_moving_update(p[2], p[3], mean, var, cnt, fused=self.ndims == 2)
                 p[2], p[3] = mm.astype(self.dtype), mv.astype(self.dtype)
 
     def apply_adam(self, grads):
@@ -742,9 +831,14 @@ class OracleUNet:
 # ----------------------------------------------------------------------------------------------
 def synthetic_batch(batch, dim, n_classes=2, sigma=2.0, seed=42, blur=8.0):
     """x [B,H,W,1] float32 in [0,1] (low-pass noise, per-slice min-max, cf. Generators.py:379);
-    y [B,H,W,C] Gaussian blobs at seeded centres, globally min-max'ed per slice (cf. :385-391)."""
+    y [B,H,W,C] Gaussian blobs at seeded centres, globally min-max'ed per slice (cf. :385-391).
+    A 3-entry dim (T,H,W) gives volumes [B,T,H,W,*]: every frame is drawn like a slice (cine stack)."""
     import scipy.ndimage
     rng = np.random.default_rng(seed)
+    if len(dim) == 3:
+        t, h, w = dim
+        xs, ys = synthetic_batch(batch * t, (h, w), n_classes, sigma, seed, blur)
+        return xs.reshape(batch, t, h, w, 1), ys.reshape(batch, t, h, w, n_classes)
     h, w = dim
     x = np.empty((batch, h, w, 1), np.float32)
     y = np.empty((batch, h, w, n_classes), np.float32)

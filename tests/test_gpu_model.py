@@ -54,6 +54,7 @@ VARIANTS = [
     dict(LOSS_FUNCTION=M.BceDiceLoss(), FILTERS=12),
     dict(USE_UPSAMPLE=False),                       # Conv2DTranspose decoder (KerasLayers.py:761-765)
     dict(DEPTH=5, DIM=[64, 64], FILTERS=4, RVIP_PRECISION='fp32'),   # cfg 4's depth (bottleneck 2x2), fp32: F % 4 == 0
+    dict(DIM=[4, 32, 32], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32),   # cfg 5's graph (Conv3D, MaxPooling3D, UpSampling3D); 3-D runs on the LDS-DMA kernels only: concat halves must be whole 128-byte rows (F % 32 in fp32)
 ]
 
 
@@ -97,7 +98,7 @@ def test_fp32_training_steps_match_oracle(variant):
             g32 = ref32.backward(c32, O.bce_dice_loss(y, p32, w_bce=kind[1], w_dice=kind[2], logits=c32['logits'])[1].astype(np.float32),
                                  d_is_logit_grad=True)
         assert abs(float(eng.loss.item()) - lv) <= 2e-5 * max(1.0, abs(lv)), (step, float(eng.loss.item()), lv)
-        np.testing.assert_allclose(eng.pred.cpu().numpy(), rpred, atol=1e-4)
+        np.testing.assert_allclose(eng.pred.cpu().numpy().reshape(rpred.shape), rpred, atol=1e-4)
         # A ReLU pre-activation (or a pooling near-tie) within fp32 noise of the kink makes the gradient of ANY float32
         # evaluation a coin flip at that element (one flipped element moves a layer gradient of this tiny net by several
         # per cent).  The float64 oracle tells us when that is the case; only then the bound is flip-tolerant.
@@ -173,6 +174,8 @@ def test_reference_default_config_224_fp32_forward():
 def _assert_landmarks_and_masks(pg, pr, eps=2e-5):
     """argmax indices and >0.5 masks must be IDENTICAL, except where the reference itself is within `eps` (fp32
     rounding of a different summation order) of a tie / of the threshold."""
+    if pr.ndim == 5:                                           # volumes: frame by frame
+        pg, pr = pg.reshape((-1,) + pg.shape[2:]), pr.reshape((-1,) + pr.shape[2:])
     pr32 = pr.astype(np.float32)
     ig, ir = O.landmark_argmax(pg), O.landmark_argmax(pr32)
     n, h, w, c = pr.shape

@@ -133,6 +133,86 @@ def test_conv3x3_fwd_dgrad_wgrad(shape, dtype):
     assert torch.equal(dw, dw2)                               # bitwise reproducible reduction
 
 
+def pack_all(w, dtype):
+    """DHWIO / HWIO fp32 master -> packed operands via the table-driven one-launch re-layout (taps = 27 or 9)"""
+    taps = int(np.prod(w.shape[:-2]))
+    ci, co = w.shape[-2:]
+    wm = f32(w)
+    wf = torch.empty(taps * ci * co, dtype=tdt(dtype), device=dev())
+    wd = torch.empty(taps * ci * co, dtype=tdt(dtype), device=dev())
+    tab = (N.PackEntry * 1)()
+    tab[0].w_off, tab[0].f_off, tab[0].d_off, tab[0].cin, tab[0].cout, tab[0].taps = 0, 0, 0, ci, co, taps
+    tabd = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev())
+    N.call('rvip_pack_all_conv3x3_weights', P(wm), P(tabd), 1, taps * ci * co, ndt(dtype), P(wf), P(wd), stream())
+    return wf, wd
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 4, 24, 40, 8, 8), (1, 3, 16, 16, 16, 40), (2, 5, 40, 36, 72, 64), (1, 1, 16, 16, 8, 8)])
+def test_conv3d_fwd_dgrad_wgrad(shape, dtype):
+    """Conv3D(3x3x3, 'same') (KerasLayers.py:679 with 3 DIM entries; cfg 5) = the 3x3 implicit GEMM with a K loop over
+    three depth taps reading the neighbouring slices of the same volume; dgrad = the same kernel on the 27 reversed
+    taps; wgrad = one pass per depth tap.  Volumes of different batch entries must not leak into each other."""
+    nb, dep, h, w, ci, co = shape
+    n = nb * dep
+    rng = np.random.default_rng(sum(shape))
+    x = rnd(rng.standard_normal((nb, dep, h, w, ci)), dtype)
+    wt = rnd(rng.standard_normal((3, 3, 3, ci, co)) * 0.15, dtype)
+    b = rng.standard_normal(co).astype(np.float32)
+    dy = rnd(rng.standard_normal((nb, dep, h, w, co)), dtype)
+    xd, dyd, bd = up(x, dtype), up(dy, dtype), f32(b)
+    wf, wd = pack_all(wt, dtype)
+    y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    d = conv_desc(xd, ci, 0, None, 0, wf, bd, y, None, 0, n, h, w, co, N.ACT['relu'], dtype)
+    d.depth, d.kd = dep, 3
+    N.call('rvip_conv3x3_fwd', C.byref(d), stream())
+    ref = O.act_fwd(O.conv3d_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), 'relu')
+    close(down(y).reshape(ref.shape), ref, dtype, 'fwd')
+    dx = torch.empty((n, h, w, ci), dtype=tdt(dtype), device=dev())
+    d2 = conv_desc(dyd, co, 0, None, 0, wd, None, dx, None, 0, n, h, w, ci, 0, dtype)
+    d2.depth, d2.kd = dep, 3
+    N.call('rvip_conv3x3_fwd', C.byref(d2), stream())
+    rdx, rdw, _ = O.conv3d_same_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64))
+    close(down(dx).reshape(rdx.shape), rdx, dtype, 'dgrad')
+    L = N.lib()
+    wsb = L.rvip_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.full((3, 3, 3, ci, co), 7.0, dtype=torch.float32, device=dev())
+    g = N.Wgrad3x3Desc()
+    g.x0, g.c0, g.up0, g.x1, g.c1 = xd.data_ptr(), ci, 0, None, 0
+    g.dy, g.dw = dyd.data_ptr(), dw.data_ptr()
+    g.n, g.h, g.w, g.cout, g.dtype = n, h, w, co, ndt(dtype)
+    g.depth, g.kd = dep, 3
+    g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
+    N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+    got = down(dw)
+    scale = float(np.abs(rdw).max())
+    assert np.abs(got - rdw).max() <= (2e-3 if dtype == 'bf16' else 2e-5) * scale, np.abs(got - rdw).max() / scale
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv3d_first_layer(dtype):
+    nb, dep, h, w, co = 2, 3, 20, 40, 16
+    n = nb * dep
+    rng = np.random.default_rng(5)
+    x = rnd(rng.random((nb, dep, h, w, 1)), dtype)
+    wt = (rng.standard_normal((3, 3, 3, 1, co)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    dy = rnd(rng.standard_normal((nb, dep, h, w, co)), dtype)
+    xd, dyd, wdv, bd = up(x, dtype), up(dy, dtype), f32(wt), f32(b)
+    y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    N.call('rvip_conv3d_c1_fwd', P(xd), P(wdv), P(bd), P(y), n, dep, h, w, co, N.ACT['relu'], ndt(dtype), stream())
+    ref = O.act_fwd(O.conv3d_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), 'relu')
+    close(down(y).reshape(ref.shape), ref, dtype, 'c1 3-D fwd')
+    L = N.lib()
+    wsb = L.rvip_reduce_workspace(n * h * w, 16 * co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.empty((3, 3, 3, 1, co), dtype=torch.float32, device=dev())
+    N.call('rvip_conv3d_c1_wgrad', P(xd), P(dyd), P(dw), n, dep, h, w, co, ndt(dtype), P(ws), C.c_size_t(wsb), stream())
+    _, rdw, _ = O.conv3d_same_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64))
+    assert np.abs(down(dw) - rdw).max() <= 2e-5 * float(np.abs(rdw).max())
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 40, 72, 32, 32), (3, 16, 16, 32, 24), (2, 24, 40, 8, 8)])
 def test_conv3x3_fused_batchnorm_statistics(shape, dtype):

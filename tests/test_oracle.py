@@ -234,3 +234,80 @@ def test_landmark_helpers():
     assert O.landmark_argmax(h).tolist() == [[2 * 5 + 3, 1 * 5 + 1]]
     c = O.centroid_landmarks(h)
     assert c[0, 0].tolist() == [2.0, 3.0] and c[0, 1].tolist() == [2.0, 2.5]
+
+
+# ----------------------------------------------------------------------------------------------
+# 3-D graph (BASELINE.json configs[4]: Conv3D 3x3x3, MaxPooling3D / UpSampling3D (1,2,2))
+# ----------------------------------------------------------------------------------------------
+CINE = dict(DIM=[3, 16, 16], FILTERS=4, DEPTH=2, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2,
+            M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], LEARNING_RATE=1e-3)
+
+
+def test_conv3d_pool3d_upsample3d_vs_torch():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 4, 6, 5, 3))
+    w = rng.standard_normal((3, 3, 3, 3, 4))
+    b = rng.standard_normal(4)
+    y = O.conv3d_same_fwd(x, w, b)
+    tx = torch.tensor(x).permute(0, 4, 1, 2, 3).requires_grad_(True)
+    tw = torch.tensor(w).permute(4, 3, 0, 1, 2).requires_grad_(True)
+    ty = torch.nn.functional.conv3d(tx, tw, torch.tensor(b), padding=1)
+    np.testing.assert_allclose(ty.permute(0, 2, 3, 4, 1).detach().numpy(), y, atol=1e-12)
+    dy = rng.standard_normal(y.shape)
+    ty.backward(torch.tensor(dy).permute(0, 4, 1, 2, 3))
+    dx, dw, db = O.conv3d_same_bwd(x, w, dy)
+    np.testing.assert_allclose(tx.grad.permute(0, 2, 3, 4, 1).numpy(), dx, atol=1e-12)
+    np.testing.assert_allclose(tw.grad.permute(2, 3, 4, 1, 0).numpy(), dw, atol=1e-11)
+    np.testing.assert_allclose(dy.reshape(-1, 4).sum(0), db, atol=1e-12)
+    # pooling (1,2,2) with first-max ties, and its gradient, against torch max_pool3d
+    xp = np.round(rng.standard_normal((2, 3, 6, 8, 2)) * 2) / 2            # coarse values -> ties
+    yp, idx = O.maxpool3d_fwd(xp, (1, 2, 2))
+    tp = torch.tensor(xp).permute(0, 4, 1, 2, 3).requires_grad_(True)
+    typ = torch.nn.functional.max_pool3d(tp, (1, 2, 2))
+    np.testing.assert_array_equal(typ.permute(0, 2, 3, 4, 1).detach().numpy(), yp)
+    g = rng.standard_normal(yp.shape)
+    dxp = O.maxpool3d_bwd(g, idx, xp.shape, (1, 2, 2))
+    assert np.isclose(dxp.sum(), g.sum()) and ((dxp != 0).sum() <= g.size)
+    # first maximum in row-major window order gets the gradient
+    win = xp[0, 0, 0:2, 0:2, 0].reshape(-1)
+    k = int(win.argmax())
+    assert dxp[0, 0, k // 2, k % 2, 0] == g[0, 0, 0, 0, 0]
+    # nearest up-sampling (1,2,2): adjoint pair
+    u = O.upsample_nearest_fwd(yp, (1, 2, 2))
+    assert u.shape == xp.shape and np.array_equal(u[:, :, ::2, ::2], yp) and np.array_equal(u[:, :, 1::2, 1::2], yp)
+    assert np.isclose((u * xp).sum(), (yp * O.upsample_nearest_bwd(xp, (1, 2, 2))).sum())
+
+
+def test_cine_graph_inventory_and_gradient():
+    """configs[4] inventory (25 894 658 parameters) and a finite-difference check of the 3-D
+    executor on a tiny instance (float64)."""
+    big = O.build_graph(dict(DIM=[16, 256, 256], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, ACTIVATION='relu',
+                             MASK_CLASSES=2, M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3]))
+    assert O.count_params(big) == (25894658, 25888770, 5888)
+    assert [l['type'] for l in big[:7]] == ['InputLayer', 'Conv3D', 'BatchNormalization', 'Dropout', 'Conv3D',
+                                            'BatchNormalization', 'MaxPooling3D']
+    assert big[6]['shape'] == (16, 128, 128, 32) and big[-1]['shape'] == (16, 256, 256, 2)
+    net = O.OracleUNet(CINE, dtype=np.float64, seed=3)
+    x, y = O.synthetic_batch(2, CINE['DIM'], 2, seed=1)
+    x, y = x.astype(np.float64), y.astype(np.float64)
+    loss, grads = net.loss_and_grads(x, y, 'mse')[:2]
+    rng = np.random.default_rng(0)
+    for lname in ('conv3d_1', 'conv3d_5', 'batch_normalization_2', 'unet'):
+        arr = net.params[lname][0]
+        for _ in range(3):
+            idx = tuple(int(rng.integers(0, s)) for s in arr.shape)
+            old = arr[idx]
+            eps = 1e-6
+            arr[idx] = old + eps
+            lp = net.loss_and_grads(x, y, 'mse')[0]
+            arr[idx] = old - eps
+            lm = net.loss_and_grads(x, y, 'mse')[0]
+            arr[idx] = old
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - grads[lname][0][idx]) <= 1e-6 * max(1.0, abs(fd)) + 2e-9, (lname, idx, fd, grads[lname][0][idx])
+    # BN moving average of 5-D inputs: biased variance (TF 2.3 non-fused path)
+    cache = net.loss_and_grads(x, y, 'mse')[3]
+    mv0 = net.params['batch_normalization'][3].copy()
+    net.apply_bn_moving(cache)
+    _, _, _, var = cache['batch_normalization']
+    np.testing.assert_allclose(net.params['batch_normalization'][3], mv0 * 0.99 + var * 0.01, rtol=1e-12)
