@@ -203,8 +203,9 @@ def main():
         achieved = fl / (ms * 1e-3) / 1e12
         traffic = None
         try:                                   # HBM bytes per launch of this kernel family from the committed PMC pass
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))['kernels']['conv3x3_igemm_dma']
-            traffic = pm['hbm_bytes_per_launch']
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))['kernels']
+            fam = [pm[k] for k in ('conv3x3_igemm_dma', 'conv3x3_igemm_ws') if k in pm]      # both generations serve this entry point
+            traffic = round(sum(f['hbm_bytes_per_launch'] * f['launches_sampled'] for f in fam) / sum(f['launches_sampled'] for f in fam))
         except Exception:
             pass
         roof = dict(bound='mfma', kernel='conv3x3_igemm (fwd + dgrad launches)', achieved=round(achieved, 2),
