@@ -87,9 +87,24 @@ def main():
         eng.forward(training=True)
         eng.backward()
 
+    overlap = eng.overlap_ok()                 # N > 1: gradient all-reduce in two buckets, the first under the encoder's backward
+
+    def fwd_bwd_head():                        # forward + backward of head, decoder, bottleneck -> gradient bucket 0
+        eng.stage_input()
+        eng.forward(training=True)
+        eng.backward_part(0)
+
     def step():                                # eager: fwd + bwd + [RCCL all-reduce] + Adam
-        fwd_bwd()
-        eng.allreduce_grads()
+        if overlap:
+            fwd_bwd_head()
+            w0 = eng.allreduce_bucket_async(0)
+            eng.backward_part(1)
+            w1 = eng.allreduce_bucket_async(1)
+            w0.wait()
+            w1.wait()
+        else:
+            fwd_bwd()
+            eng.allreduce_grads()
         eng.optimizer_step()
 
     def capture(fn):
@@ -113,6 +128,18 @@ def main():
             if world == 1:
                 g_all = capture(lambda: (fwd_bwd(), eng.optimizer_step()))
                 run, launch = g_all.replay, 'hipGraph'
+            elif overlap:                      # collectives stay outside the graphs: A1 -> [bucket 0 all-reduce || A2] -> bucket 1 -> B
+                g_a1, g_a2, g_b = capture(fwd_bwd_head), capture(lambda: eng.backward_part(1)), capture(eng.optimizer_step)
+
+                def run():
+                    g_a1.replay()
+                    w0 = eng.allreduce_bucket_async(0)
+                    g_a2.replay()
+                    w1 = eng.allreduce_bucket_async(1)
+                    w0.wait()
+                    w1.wait()
+                    g_b.replay()
+                launch = 'hipGraph x3 + two overlapped all-reduce buckets'
             else:                              # the collective stays outside the graphs: A (fwd+bwd) -> all-reduce -> B (Adam)
                 g_a, g_b = capture(fwd_bwd), capture(eng.optimizer_step)
 
