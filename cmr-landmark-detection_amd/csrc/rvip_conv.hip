@@ -45,6 +45,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;
     int zs;                                   // zero-stuffed x2 read of source 0 (Conv2DTranspose): only odd (y, x) carry data
     int depth, kd;                            // Conv3D: images per volume and depth taps (3); a plain 2-D conv has 1, 1
+    int down2;                                // store the 2x2 block sums of the result at half resolution (gradient of UpSampling2D)
 };
 
 template <typename T, int TW, int NCT>
@@ -268,9 +269,67 @@ struct ConvArgs2 {
     int lds_bias_off;
     int zs;
     int depth, kd;                           // Conv3D as a K loop over depth taps: chunk kc reads image n + kc / nch - kd / 2
+    int down2;                               // epilogue_down2 instead of the plain epilogue
     int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
 };
+
+// Epilogue of the data gradient of an UpSampling2D -> conv pair (KerasLayers.py:756-758): the gradient w.r.t. the
+// low-resolution tensor is the sum over each 2x2 block of the full-resolution data gradient.  The block's two rows are
+// two pixel tiles of the same lane (TW = 32) or lanes j and j ^ 16 (TW = 16), its two columns lanes j and j ^ 1; the
+// even lane stores the sum at [N, H/2, W/2, Cout].  No bias, activation, channel split or statistics in this mode.
+// Returns nothing; issues (NPT / ROWS) * NCT * (bf16 ? 2 : 4) buffer stores per wave, ROWS = TW == 32 ? 2 : 1.
+template <typename T, int TW, int NCT, int NPT>
+__device__ __forceinline__ void epilogue_down2(f32x16 (&acc)[NCT][NPT], int pbase, int j, int hf, int n, int ty0, int tx0, int co0,
+                                               const ConvArgs2& a, __amdgpu_buffer_rsrc_t ry) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int ROWS = TW == 32 ? 2 : 1;
+    const int hl = a.h >> 1, wl = a.w >> 1;
+#pragma unroll
+    for (int pt = 0; pt < NPT; pt += ROWS) {
+        const int P = pbase + pt * 32 + j;
+        const int gy = ty0 + P / TW, gx = tx0 + P % TW;
+        const bool keep = gy < a.h && gx < a.w && !(j & 1) && (TW == 32 || !(j & 16));
+        const unsigned pix = (unsigned)((n * hl + (gy >> 1)) * wl + (gx >> 1));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int cbase = co0 + ct * 32;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = acc[ct][pt][r];
+                acc[ct][pt][r] = 0.f;
+                if constexpr (ROWS == 2) { t += acc[ct][pt + 1][r]; acc[ct][pt + 1][r] = 0.f; }
+                else t += __shfl_xor(t, 16);
+                v[r] = t + __shfl_xor(t, 1);
+            }
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = cbase + 8 * q + 4 * hf;
+                    const unsigned off = (keep && co < a.cout) ? (pix * a.cout + co) * 4u : OOB;
+                    const u32x4v dta = {__builtin_bit_cast(unsigned, v[4 * q]), __builtin_bit_cast(unsigned, v[4 * q + 1]),
+                                        __builtin_bit_cast(unsigned, v[4 * q + 2]), __builtin_bit_cast(unsigned, v[4 * q + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    unsigned ax = (uint32_t)f32_to_bf16(v[8 * qq + 0]) | ((uint32_t)f32_to_bf16(v[8 * qq + 1]) << 16);
+                    unsigned ay = (uint32_t)f32_to_bf16(v[8 * qq + 2]) | ((uint32_t)f32_to_bf16(v[8 * qq + 3]) << 16);
+                    unsigned bxx = (uint32_t)f32_to_bf16(v[8 * qq + 4]) | ((uint32_t)f32_to_bf16(v[8 * qq + 5]) << 16);
+                    unsigned byy = (uint32_t)f32_to_bf16(v[8 * qq + 6]) | ((uint32_t)f32_to_bf16(v[8 * qq + 7]) << 16);
+                    auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
+                    auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
+                    const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
+                    const int co = cbase + 16 * qq + 8 * hf;
+                    const unsigned off = (keep && co < a.cout) ? (pix * a.cout + co) * 2u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
+                }
+            }
+        }
+    }
+}
 
 template <typename T, int TW, int NCT, int NW, bool STATS>
 __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
@@ -432,8 +491,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
         for (int kc = 0; kc < nchunks; ++kc, ++it) {
             // item `it` has landed for me; after the barrier for everyone, and everyone has finished item it-1.
             // The epilogue's NST buffer stores are YOUNGER than this item's DMA: leave them in flight.
-            if (kc == 0 && it > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kc == 0 && it > 0) {
+                if (a.down2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TW == 32 ? NST / 2 : NST) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             {   // prefetch the next item into the other stage
                 int ntile = tile, nkc = kc + 1;
                 if (nkc == nchunks) { nkc = 0; ntile = tile + gridDim.x; }
@@ -532,7 +593,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
         }
         };
         // the activation is launch-uniform: specialise the hot cases so the epilogue stays a few hundred instructions
-        if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
+        if (a.down2) epilogue_down2<T, TW, NCT, 2>(acc, wv * 64, j, hf, n, ty0, tx0, co0, a, ry);
+        else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
         else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
         else epilogue([&](float t) { return act_fwd(t, a.act); });
     }
@@ -822,7 +884,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
             }
         }
         };
-        if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
+        if (a.down2) epilogue_down2<T, TW, NCT, NPT>(acc, wv * (NPT * 32), j, hf, n, ty0, tx0, co0, a, ry);
+        else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
         else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
         else epilogue([&](float t) { return act_fwd(t, a.act); });
     }
@@ -869,13 +932,13 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
     if (a0.y1 && a0.csplit % 32) return RVIP_OK;
     const long long npx = (long long)a0.n * a0.h * a0.w;
-    const long long yb = npx * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
+    const long long yb = (a0.down2 ? npx / 4 : npx) * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
     if (yb >= (1LL << 31) || y1b >= (1LL << 31)) return RVIP_OK;
     if (sizeof(T) == 2 && a0.cout % 8) return RVIP_OK;
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -932,13 +995,13 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float
     if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
     if (a0.y1 && a0.csplit % 32) return RVIP_OK;
     const long long npx = (long long)a0.n * a0.h * a0.w;
-    const long long yb = npx * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
+    const long long yb = (a0.down2 ? npx / 4 : npx) * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
     if (yb >= (1LL << 31) || y1b >= (1LL << 31)) return RVIP_OK;
     if (sizeof(T) == 2 && a0.cout % 8) return RVIP_OK;
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -1249,6 +1312,8 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     a.depth = d->depth > 0 ? d->depth : 1;
     a.kd = d->kd > 0 ? d->kd : 1;
     if ((a.kd != 1 && a.kd != 3) || d->n % a.depth) return RVIP_EINVAL;
+    a.down2 = d->down2 ? 1 : 0;
+    if (a.down2 && (d->y1 || d->bias || d->act != RVIP_ACT_NONE || ((d->h | d->w) & 1))) return RVIP_EINVAL;
     return RVIP_OK;
 }
 
@@ -1266,7 +1331,7 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
         else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
         if (rc || used) return rc;
     }
-    if (a.kd > 1) return RVIP_EUNSUPPORTED;        // the register-staged fallback is 2-D only
+    if (a.kd > 1 || a.down2) return RVIP_EUNSUPPORTED;        // the register-staged fallback is 2-D only and has the plain epilogue
     return d->dtype == RVIP_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
 }
 

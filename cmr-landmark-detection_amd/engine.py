@@ -245,9 +245,9 @@ class Engine:
                 alloc(st.pooled, st.h // 2, st.w // 2, st.cout, self.grd)
             if st.y in skip_names:
                 alloc(st.y, st.h, st.w, st.cout, self.gskip)
-        self.up_tmp = {}
+        self.up_tmp = {}                   # full-resolution data gradient of an up-conv, when it is not summed in the epilogue
         for st in plan.stages:
-            if st.up0:
+            if st.up0 == 2 or (st.up0 == 1 and os.environ.get('RVIP_FUSE_DOWN2', '1') == '0'):
                 self.up_tmp[st.conv] = torch.empty((n, st.h, st.w, st.c0), dtype=T, device=dev)
 
         f32 = dict(dtype=torch.float32, device=dev)
@@ -459,15 +459,18 @@ class Engine:
             dg.n, dg.h, dg.w, dg.cout, dg.act, dg.dtype = n, st.h, st.w, st.cin, 0, dt
             dg.depth, dg.kd = self.depth, self.kd
             dg.y1, dg.csplit = None, 0
+            fuse_down = st.up0 == 1 and os.environ.get('RVIP_FUSE_DOWN2', '1') != '0'
             if st.src1:
                 dg.y, dg.y1, dg.csplit = self.grd[st.src0].data_ptr(), self.gskip[st.src1].data_ptr(), st.c0
+            elif fuse_down:                 # UpSampling2D: the 2x2 block sums leave the data-gradient epilogue directly
+                dg.y, dg.down2 = self.grd[st.src0].data_ptr(), 1
             elif st.up0:
                 dg.y = self.up_tmp[st.conv].data_ptr()
             else:
                 dg.y = self.grd[st.src0].data_ptr()
             self._keep.append(dg)
             bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
-            if st.up0:                      # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions
+            if st.up0 and not fuse_down:    # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions
                 back = L.rvip_upsample2x_bwd if st.up0 == 1 else L.rvip_subsample_odd
                 bwd.append((back, (_ptr(self.up_tmp[st.conv]), _ptr(self.grd[st.src0]), n, st.h // 2, st.w // 2, st.c0, dt)))
         self.fwd_train, self.fwd_infer, self.bwd = fwd_t, fwd_i, bwd

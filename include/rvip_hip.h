@@ -88,6 +88,9 @@ typedef struct rvip_conv3x3_desc {
      * volume, zeros outside); w_packed is then [27][Cout][C0+C1], tap = (kd, kh, kw) row-major.  0 / 0 (or 1 / 1)
      * = the plain 2-D convolution. */
     int32_t      depth, kd;
+    /* down2 != 0: y is [N, H/2, W/2, Cout] and receives the sum of every 2x2 block of the result: the data gradient
+     * of an UpSampling2D -> conv pair in one pass (no bias / activation / y1 in this mode; H, W even). */
+    int32_t      down2;
 } rvip_conv3x3_desc;
 
 int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);

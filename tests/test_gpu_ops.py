@@ -297,6 +297,26 @@ def test_conv3x3_virtual_upsample_concat_and_split(dtype):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 24, 40, 32, 64), (1, 16, 16, 16, 40), (2, 8, 72, 8, 8),       # igemm v2: 512 px, TW=16, 256 px
+                                   (1, 32, 64, 16, 256), (2, 16, 16, 8, 256), (1, 8, 40, 8, 264)])   # igemm v3 (K >= 256): same three tilings
+def test_conv3x3_dgrad_with_fused_2x2_sum(shape, dtype):
+    """down2: the data gradient of an UpSampling2D -> Conv2D pair written directly at half resolution (sum of each 2x2
+    block, KerasLayers.py:756-758 autodiff) = conv on dy with the rotated kernel followed by the 2x2 sum."""
+    n, h, w, ci, co = shape                     # forward conv ci -> co at h x w; its dgrad contracts over co, outputs ci
+    rng = np.random.default_rng(sum(shape))
+    wt = rnd(rng.standard_normal((3, 3, ci, co)) * 0.2, dtype)
+    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
+    _, wd = pack(wt, dtype)
+    dyd = up(dy, dtype)
+    glo = torch.full((n, h // 2, w // 2, ci), 5.0, dtype=tdt(dtype), device=dev())
+    d = conv_desc(dyd, co, 0, None, 0, wd, None, glo, None, 0, n, h, w, ci, 0, dtype)
+    d.down2 = 1
+    N.call('rvip_conv3x3_fwd', C.byref(d), stream())
+    rdx = O.conv2d_same_bwd(np.zeros((n, h, w, ci)), wt.astype(np.float64), dy.astype(np.float64))[0]
+    close(down(glo), O.upsample_nearest_bwd(rdx), dtype, 'down2 dgrad')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 12, 20, 16, 8), (1, 8, 8, 8, 24)])
 def test_conv2d_transpose_as_zero_stuffed_conv(shape, dtype):
     """Conv2DTranspose(3, strides=2, 'same') = the 3x3 igemm over the zero-stuffed read (up0 = 2) with the kernel in its
