@@ -33,12 +33,12 @@ class Conv3x3Desc(C.Structure):
                 ('y', vp), ('y1', vp), ('csplit', C.c_int32),
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('act', C.c_int32), ('dtype', C.c_int32),
-                ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32)]
+                ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32), ('subpix', C.c_int32)]
 
 
 class PackEntry(C.Structure):
     _fields_ = [('w_off', C.c_longlong), ('f_off', C.c_longlong), ('d_off', C.c_longlong), ('cin', C.c_int32), ('cout', C.c_int32),
-                ('taps', C.c_int32), ('reserved', C.c_int32)]
+                ('taps', C.c_int32), ('mode', C.c_int32)]
 
 
 class Wgrad3x3Desc(C.Structure):
@@ -83,6 +83,7 @@ SIGNATURES = {
     'rvip_conv3x3_fwd_stats': (C.c_int, [C.POINTER(Conv3x3Desc), vp, C.c_size_t, vp]),
     'rvip_bn_stats_finalize': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp, vp]),
     'rvip_pack_conv3x3_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    'rvip_pack_subpixel_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'rvip_pack_all_conv3x3_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_conv3x3_wgrad_workspace': (C.c_size_t, [C.c_int] * 5),
     'rvip_conv3x3_wgrad': (C.c_int, [C.POINTER(Wgrad3x3Desc), vp]),

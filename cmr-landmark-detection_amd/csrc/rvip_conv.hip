@@ -46,6 +46,7 @@ struct ConvArgs {
     int zs;                                   // zero-stuffed x2 read of source 0 (Conv2DTranspose): only odd (y, x) carry data
     int depth, kd;                            // Conv3D: images per volume and depth taps (3); a plain 2-D conv has 1, 1
     int down2;                                // store the 2x2 block sums of the result at half resolution (gradient of UpSampling2D)
+    int subpix;                               // UpSampling2D -> conv as four 2x2-tap phase convolutions on the low-resolution input
 };
 
 template <typename T, int TW, int NCT>
@@ -270,6 +271,7 @@ struct ConvArgs2 {
     int zs;
     int depth, kd;                           // Conv3D as a K loop over depth taps: chunk kc reads image n + kc / nch - kd / 2
     int down2;                               // epilogue_down2 instead of the plain epilogue
+    int subpix;                              // TAPS == 4 kernels: blockIdx.z = output phase (a, b); y is [N, 2h, 2w, Cout]
     int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
 };
@@ -635,11 +637,17 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
 // (each owns NPIX/4 pixels x BN channels, so a weight fragment is reused by up to 4 pixel fragments: 0.75 KiB of LDS
 // reads per MFMA instead of 1 KiB).  One s_barrier per work item joins the two roles.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int TW, int NCT, int NPIX, bool STATS>
+// TAPS = 4: sub-pixel form of UpSampling2D(2) -> conv3x3 (KerasLayers.py:756-758).  Output pixel (2i+a, 2j+b) only sees the
+// low-resolution pixels (i+a-1 .. i+a) x (j+b-1 .. j+b), each through a SUM of the 3x3 taps that fall on it, so the layer
+// is four 2x2-tap convolutions on the low-resolution image (16 instead of 36 multiply-adds per low-resolution pixel and
+// channel pair).  blockIdx.z = phase 2a+b; weights [4 phases][4 taps (u,v)][Cout][Cin] from rvip_pack_subpixel_weights;
+// the same 3x3 halo is staged and tap (u,v) reads halo position (py + a + u, px + b + v).
+template <typename T, int TW, int NCT, int NPIX, bool STATS, int TAPS = 9>
 __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
+    static_assert(TAPS == 9 || TAPS == 4, "taps");
     constexpr int TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
     constexpr int NHROWS = (NHALO + 15) / 16 * 16;
-    constexpr int BN = NCT * 32, WROWS = 9 * BN;
+    constexpr int BN = NCT * 32, WROWS = TAPS * BN;
     constexpr int IN_BYTES = NHROWS * 64, W_BYTES = WROWS * 64;
     constexpr int VE = Vec<T>::VE, KCE = 4 * VE;
     constexpr int NQI = NHROWS / 16, NQW = WROWS / 16;                 // 1 KiB DMA pieces per stage
@@ -653,6 +661,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.y * BN;
+    const int ph = (TAPS == 4) ? (int)blockIdx.z : 0, pa = ph >> 1, pb = ph & 1;      // output phase of the sub-pixel form
     const int nch = (a.cin + KCE - 1) / KCE;         // chunks per depth tap
     const int nchunks = nch * a.kd;
     const bool resident = a.wres > 0;
@@ -691,7 +700,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
         auto issue_weights = [&](int kc, int wstage) __attribute__((always_inline)) {
             const int kdi = kc / nch;
             const int cbase = (kc - kdi * nch) * KCE;
-            const int tapbase = (kdi * 9 * a.cout * a.cin + cbase) * (int)sizeof(T);
+            const int tapbase = ((kdi + ph) * TAPS * a.cout * a.cin + cbase) * (int)sizeof(T);
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
                 const int q = lwv + 4 * i;
@@ -762,13 +771,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y1 ? a.y1 : a.y), 0, a.y1 ? a.y1_bytes : 0, 0x00020000);
     // pixel tile pt of this wave sits 32/TW halo rows below tile pt-1: one base per (tx, g), the rest is an immediate
     constexpr int PT_STRIDE = (32 / TW) * HWD * 64;
-    int in_base[3][2];
+    constexpr int TXN = TAPS == 9 ? 3 : 2;
+    int in_base[TXN][2];
     {
         const int P = wv * (NPT * 32) + j;
         const int py = P / TW, px = P % TW;
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-            const int hx = px + tx;
+        for (int tx = 0; tx < TXN; ++tx) {
+            const int hx = px + tx + (TAPS == 4 ? pb : 0);
 #pragma unroll
             for (int g = 0; g < 2; ++g) in_base[tx][g] = (py * HWD + hx) * 64 + (((2 * g + hf) ^ ((hx >> 2) & 3)) << 4);
         }
@@ -803,7 +813,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
         for (int kc = 0; kc < nchunks; ++kc, ++it) {
             asm volatile("s_barrier" ::: "memory");              // item `it` is in LDS (the loaders waited for their DMAs)
             if (a.dbg & 2) continue;
-            const unsigned char* sin = lin + (it & 1) * IN_BYTES;
+            const unsigned char* sin = lin + (it & 1) * IN_BYTES + (TAPS == 4 ? pa * HWD * 64 : 0);
             const unsigned char* sw = lw + (resident ? kc : (it & 1)) * W_BYTES;
             // 18 (tap, k-half) steps, two-deep software pipeline (see v2): reads of step i+1 above the MFMAs of step i
             uint4 fa[2][NCT], fb[2][NPT];
@@ -812,13 +822,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) fa[buf][ct] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + (w_addr[ct] ^ (g << 5)));
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) fb[buf][pt] = *reinterpret_cast<const uint4*>(sin + in_base[tap % 3][g] + (tap / 3) * HWD * 64 + pt * PT_STRIDE);
+                for (int pt = 0; pt < NPT; ++pt) fb[buf][pt] = *reinterpret_cast<const uint4*>(sin + in_base[tap % TXN][g] + (tap / TXN) * HWD * 64 + pt * PT_STRIDE);
             };
             load_step(0, 0);
 #pragma unroll
-            for (int st = 0; st < 18; ++st) {
+            for (int st = 0; st < 2 * TAPS; ++st) {
                 const int cur = st & 1;
-                if (st + 1 < 18) load_step(st + 1, cur ^ 1);
+                if (st + 1 < 2 * TAPS) load_step(st + 1, cur ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
@@ -834,7 +844,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
             const int P = wv * (NPT * 32) + pt * 32 + j;
             const int gy = ty0 + P / TW, gx = tx0 + P % TW;
             const bool pix_ok = gy < a.h && gx < a.w;
-            const unsigned pix = (unsigned)((n * a.h + gy) * a.w + gx);
+            const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gy + pa) * 2 * a.w + 2 * gx + pb)
+                                           : (unsigned)((n * a.h + gy) * a.w + gx);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int cbase = co0 + ct * 32;                                   // wave-uniform
@@ -916,29 +927,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     }
 }
 
-template <typename T, int TW, int NCT, int NPIX>
+template <typename T, int TW, int NCT, int NPIX, int TAPS = 9>
 static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry) {
     constexpr int TH = NPIX / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
-    constexpr int IN_BYTES = NHROWS * 64, W_BYTES = 9 * NCT * 32 * 64;
+    constexpr int IN_BYTES = NHROWS * 64, W_BYTES = TAPS * NCT * 32 * 64;
     constexpr int KCE = 64 / (int)sizeof(T);
     constexpr int LDS_MAX = 160 * 1024;
     used = false;
     const int nchunks = (int)cdiv(a0.cin, KCE) * a0.kd;
     const long long x0b = (long long)a0.n * (a0.h >> a0.up0) * (a0.w >> a0.up0) * a0.c0 * (long long)sizeof(T);
     const long long x1b = (long long)a0.n * a0.h * a0.w * a0.c1 * (long long)sizeof(T);
-    const long long wpb = 9LL * a0.kd * a0.cin * a0.cout * (long long)sizeof(T);
+    const long long wpb = (TAPS == 4 ? 16LL : 9LL * a0.kd) * a0.cin * a0.cout * (long long)sizeof(T);
+    if ((TAPS == 4) != (a0.subpix != 0)) return RVIP_OK;
     if (x0b >= (1LL << 31) || x1b >= (1LL << 31) || wpb >= (1LL << 31)) return RVIP_OK;
     if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
     if (a0.y1 && a0.csplit % 32) return RVIP_OK;
     const long long npx = (long long)a0.n * a0.h * a0.w;
-    const long long yb = (a0.down2 ? npx / 4 : npx) * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
+    const long long yb = (a0.down2 ? npx / 4 : (TAPS == 4 ? npx * 4 : npx)) * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
     if (yb >= (1LL << 31) || y1b >= (1LL << 31)) return RVIP_OK;
     if (sizeof(T) == 2 && a0.cout % 8) return RVIP_OK;
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = a0.subpix;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -949,23 +961,28 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (lds > LDS_MAX) return RVIP_OK;
     static int attr_lds = 0;
     if (!dry && lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, false, TAPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, true>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        if constexpr (TAPS == 9) {
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, true, TAPS>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        }
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
         attr_lds = LDS_MAX;
     }
     const int cot = (int)cdiv(a0.cout, NCT * 32);
-    int gx = 256 / cot;
+    constexpr int NZ = TAPS == 4 ? 4 : 1;
+    int gx = 256 / (cot * NZ);
     if (gx < 1) gx = 1;
     if (gx > b.ntiles) gx = b.ntiles;
     b.stats = stats;
     { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
     if (rows_out) *rows_out = gx;
     if (dry) { used = true; return RVIP_OK; }
-    if (stats) hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, true>), dim3((unsigned)gx, (unsigned)cot), dim3(512), lds, s, b);
-    else hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, false>), dim3((unsigned)gx, (unsigned)cot), dim3(512), lds, s, b);
+    if (stats) {
+        if constexpr (TAPS == 9) hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, true, TAPS>), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3(512), lds, s, b);
+        else return RVIP_EUNSUPPORTED;
+    } else hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, false, TAPS>), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3(512), lds, s, b);
     used = true;
     return check_launch();
 }
@@ -973,6 +990,11 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
 template <typename T>
 static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float* stats = nullptr, int* rows_out = nullptr, bool dry = false) {
     const bool two = a.cout > 32;
+    if (a.subpix) {                     // a.h, a.w = the low-resolution grid
+        if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry);
+        if (a.w > 16) return two ? launch_igemm_ws<T, 32, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 256, 4>(a, s, used, stats, rows_out, dry);
+        return two ? launch_igemm_ws<T, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry);
+    }
     if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, 32, 2, 512>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512>(a, s, used, stats, rows_out, dry);
     if (a.w > 16) return two ? launch_igemm_ws<T, 32, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 256>(a, s, used, stats, rows_out, dry);
     return two ? launch_igemm_ws<T, 16, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 16, 1, 256>(a, s, used, stats, rows_out, dry);
@@ -1001,7 +1023,7 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = 0;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -1203,6 +1225,32 @@ __global__ __launch_bounds__(256) void conv3d_c1_tiled(const T* __restrict__ x, 
     }
 }
 
+// Phase kernels of the sub-pixel form: w_phase[2a+b][2u+v][co][ci] = sum of W[kh][kw][ci][co] over the taps that land on
+// low-resolution offset (u, v) for output phase (a, b): rows a=0: u=0 <- {0}, u=1 <- {1,2}; a=1: u=0 <- {0,1}, u=1 <- {2}
+// (columns alike).  Summed in fp32, rounded once.
+template <typename T>
+__device__ __forceinline__ void pack_subpixel_range(const float* __restrict__ w, int cin, int cout, T* __restrict__ wp) {
+    const long long total = 16LL * cin * cout;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ci = (int)(i % cin);
+        const int co = (int)((i / cin) % cout);
+        const int tap = (int)((i / ((long long)cin * cout)) & 3), ph = (int)(i / (4LL * cin * cout));
+        const int a = ph >> 1, b = ph & 1, u = tap >> 1, v = tap & 1;
+        const int kh0 = a == 0 ? (u == 0 ? 0 : 1) : (u == 0 ? 0 : 2), kh1 = a == 0 ? (u == 0 ? 0 : 2) : (u == 0 ? 1 : 2);
+        const int kw0 = b == 0 ? (v == 0 ? 0 : 1) : (v == 0 ? 0 : 2), kw1 = b == 0 ? (v == 0 ? 0 : 2) : (v == 0 ? 1 : 2);
+        float acc = 0.f;
+        for (int kh = kh0; kh <= kh1; ++kh)
+            for (int kw = kw0; kw <= kw1; ++kw) acc += w[((size_t)(kh * 3 + kw) * cin + ci) * cout + co];
+        if constexpr (sizeof(T) == 4) wp[i] = acc;
+        else wp[i].bits = f32_to_bf16(acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_subpixel_kernel(const float* __restrict__ w, int cin, int cout, T* __restrict__ wp) {
+    pack_subpixel_range<T>(w, cin, cout, wp);
+}
+
 // all 3x3 kernels of the model in ONE launch: table-driven re-layout (see pack_w_kernel)
 struct PackEntry { long long w_off; long long f_off; long long d_off; int cin, cout; int taps, reserved; };
 // A workgroup moves tiles of one tap: 32 input channels x 64 output channels, read as 256-byte rows of the HWIO master,
@@ -1217,6 +1265,10 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     const float* w = theta + en.w_off;
     T* wf = wf_base + en.f_off;
     T* wd = wd_base + en.d_off;
+    if (en.reserved == 1) {              // mode 1: the phase kernels of the sub-pixel up-conv form, [4][4][Cout][Cin] at f_off
+        pack_subpixel_range<T>(w, en.cin, en.cout, wf);
+        return;
+    }
     const int nbi = (en.cin + TI - 1) / TI, nbo = (en.cout + TO - 1) / TO;
     const int taps = en.taps > 0 ? en.taps : 9;
     const int ntiles = taps * nbi * nbo;
@@ -1278,6 +1330,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 // layers with few chunks per tile (+8..+15 % for v3 at Cin <= 64 and at Cin = 128 on 128x128 maps).
 static int igemm_generation(const ConvArgs& a, bool stats = false) {
     static const int forced = [] { const char* e = getenv("RVIP_IGEMM"); return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '3') ? e[1] - '0' : 0; }();
+    if (a.subpix) return 3;                            // only the wave-specialised kernel has the 4-tap phase form
     if (forced) return forced;
     if (a.cin >= 256) return 3;
     if (stats) return 2;
@@ -1314,6 +1367,11 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     if ((a.kd != 1 && a.kd != 3) || d->n % a.depth) return RVIP_EINVAL;
     a.down2 = d->down2 ? 1 : 0;
     if (a.down2 && (d->y1 || d->bias || d->act != RVIP_ACT_NONE || ((d->h | d->w) & 1))) return RVIP_EINVAL;
+    a.subpix = d->subpix ? 1 : 0;
+    if (a.subpix) {                      // UpSampling2D -> conv as four phase convolutions on the low-resolution grid
+        if (d->up0 != 1 || d->c1 || d->y1 || a.kd != 1 || a.down2) return RVIP_EINVAL;
+        a.up0 = 0; a.h = d->h / 2; a.w = d->w / 2;
+    }
     return RVIP_OK;
 }
 
@@ -1331,7 +1389,7 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
         else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
         if (rc || used) return rc;
     }
-    if (a.kd > 1 || a.down2) return RVIP_EUNSUPPORTED;        // the register-staged fallback is 2-D only and has the plain epilogue
+    if (a.kd > 1 || a.down2 || a.subpix) return RVIP_EUNSUPPORTED;        // the register-staged fallback is 2-D only and has the plain epilogue
     return d->dtype == RVIP_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
 }
 
@@ -1419,6 +1477,18 @@ extern "C" int rvip_conv3d_c1_fwd(const void* x, const float* w, const float* bi
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(conv3d_c1_tiled<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
     else hipLaunchKernelGGL(conv3d_c1_tiled<float>, grid, dim3(256), lds, s, (const float*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
+    return check_launch();
+}
+
+extern "C" int rvip_pack_subpixel_weights(const float* w, int cin, int cout, int dtype, void* w_phase, void* stream) {
+    (void)hipGetLastError();
+    if (!w || !w_phase || cin <= 0 || cout <= 0) return RVIP_EINVAL;
+    const long long total = 16LL * cin * cout;
+    const int blocks = (int)(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(pack_subpixel_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (bf16_t*)w_phase);
+    else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_subpixel_kernel<float>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (float*)w_phase);
+    else return RVIP_EINVAL;
     return check_launch();
 }
 

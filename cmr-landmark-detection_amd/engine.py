@@ -81,20 +81,30 @@ class ParamStore:
         # conv over the zero-stuffed input: Weq[t][ci][co] = W_hwoi[2-t][co][ci] (taps reversed, last two axes swapped)
         self.transposed = {st.conv for st in plan.stages if st.transpose}
         self.taps = 27 if plan.ndims == 3 else 9          # Conv3D(3x3x3): taps (kd, kh, kw) row-major
+        # UpSampling2D -> conv layers run in their sub-pixel form (four 2x2-tap phase convolutions on the low-resolution
+        # input, 2.25x fewer multiply-adds in the forward pass): they also get phase kernels [4][4][Cout][Cin] (mode 1)
+        sub_on = plan.ndims == 2 and os.environ.get('RVIP_SUBPIX', '1') != '0'
         for st in plan.stages:
             if st.src0 != 'input_1':
                 k = self.taps * st.cin * st.cout
-                entries.append((st.conv, self.off[(st.conv, 'kernel')][0], off, st.cin, st.cout))
+                entries.append((st.conv, self.off[(st.conv, 'kernel')][0], off, st.cin, st.cout, 0))
                 off += -(-k // ALIGN) * ALIGN
+                if sub_on and st.up0 == 1 and not st.src1:
+                    entries.append((st.conv, self.off[(st.conv, 'kernel')][0], off, st.cin, st.cout, 1))
+                    off += -(-16 * st.cin * st.cout // ALIGN) * ALIGN
         self.wf_all = torch.empty(max(off, ALIGN), dtype=self.tdtype, device=device)
         self.wd_all = torch.empty(max(off, ALIGN), dtype=self.tdtype, device=device)
         tab = (N.PackEntry * max(len(entries), 1))()
         self.pack_max = 1
-        for i, (name, w_off, p_off, cin, cout) in enumerate(entries):
+        self.subpix = {}
+        for i, (name, w_off, p_off, cin, cout, mode) in enumerate(entries):
             tab[i].w_off, tab[i].f_off, tab[i].d_off, tab[i].cin, tab[i].cout = w_off, p_off, p_off, cin, cout
-            tab[i].taps = self.taps
-            k = self.taps * cin * cout
-            self.packed[name] = (self.wf_all[p_off:p_off + k], self.wd_all[p_off:p_off + k])
+            tab[i].taps, tab[i].mode = self.taps, mode
+            k = (16 if mode else self.taps) * cin * cout
+            if mode:
+                self.subpix[name] = self.wf_all[p_off:p_off + k]
+            else:
+                self.packed[name] = (self.wf_all[p_off:p_off + k], self.wd_all[p_off:p_off + k])
             self.pack_max = max(self.pack_max, k)
         self.pack_entries = len(entries)
         self.pack_table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(device)
@@ -332,6 +342,8 @@ class Engine:
                 d.y, d.y1, d.csplit = z.data_ptr(), None, 0
                 d.n, d.h, d.w, d.cout, d.act, d.dtype = n, st.h, st.w, st.cout, act_conv, dt
                 d.depth, d.kd = self.depth, self.kd
+                if st.conv in P.subpix:
+                    d.w_packed, d.subpix = P.subpix[st.conv].data_ptr(), 1
                 self._keep.append(d)
                 call = (L.rvip_conv3x3_fwd, (C.byref(d),))
             # ---- BN statistics / coefficients ----

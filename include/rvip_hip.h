@@ -91,6 +91,10 @@ typedef struct rvip_conv3x3_desc {
     /* down2 != 0: y is [N, H/2, W/2, Cout] and receives the sum of every 2x2 block of the result: the data gradient
      * of an UpSampling2D -> conv pair in one pass (no bias / activation / y1 in this mode; H, W even). */
     int32_t      down2;
+    /* subpix != 0 (with up0 = 1, no x1 / y1): the UpSampling2D -> conv pair in its sub-pixel form - four 2x2-tap phase
+     * convolutions on the low-resolution x0, 16 instead of 36 multiply-adds per low-resolution pixel; same result up to
+     * the summation order of the taps.  w_packed is then the [4][4][Cout][C0] block of rvip_pack_subpixel_weights. */
+    int32_t      subpix;
 } rvip_conv3x3_desc;
 
 int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
@@ -109,11 +113,15 @@ int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_ws, size_t s
 int rvip_pack_conv3x3_weights(const float* w_hwio, int cin, int cout, int dtype,
                               void* w_fwd, void* w_dgrad, void* stream);
 
+/* Phase kernels of the sub-pixel form of UpSampling2D -> conv (rvip_conv3x3_desc.subpix): w_phase[2a+b][2u+v][Cout][Cin]. */
+int rvip_pack_subpixel_weights(const float* w_hwio, int cin, int cout, int dtype, void* w_phase, void* stream);
+
 /* The same re-layout for ALL 3x3 kernels of a model in one launch.  `theta` is the flat fp32 parameter block;
  * `table` is a DEVICE array of `entries` records {int64 w_off (floats into theta), int64 f_off, int64 d_off
  * (elements into wf_base / wd_base), int32 cin, int32 cout, int32 taps (9, or 27 for a 3x3x3 kernel; 0 = 9),
- * int32 reserved}; max_elems = max over entries of taps*cin*cout. */
-typedef struct rvip_pack_entry { long long w_off, f_off, d_off; int32_t cin, cout; int32_t taps, reserved; } rvip_pack_entry;
+ * int32 mode (0: the two operands above; 1: the [4][4][Cout][Cin] phase kernels of rvip_pack_subpixel_weights at
+ * f_off, d_off unused)}; max_elems = max over entries of taps*cin*cout. */
+typedef struct rvip_pack_entry { long long w_off, f_off, d_off; int32_t cin, cout; int32_t taps, mode; } rvip_pack_entry;
 int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
                                   void* wf_base, void* wd_base, void* stream);
 

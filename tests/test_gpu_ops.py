@@ -317,6 +317,31 @@ def test_conv3x3_dgrad_with_fused_2x2_sum(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 48, 80, 32, 32), (1, 32, 32, 16, 40), (2, 16, 72, 8, 8), (1, 64, 64, 72, 64)])
+def test_upsample_conv_subpixel_form(shape, dtype):
+    """UpSampling2D(2) -> Conv2D(3x3, same) (KerasLayers.py:756-758) as four 2x2-tap phase convolutions on the
+    low-resolution input: same result as the conv on the materialised up-sampled tensor (fp32: summation order
+    only; bf16: the phase kernels are sums of taps rounded once)."""
+    n, h, w, ci, co = shape                     # h, w = output (up-sampled) size
+    rng = np.random.default_rng(sum(shape))
+    lo = rnd(rng.standard_normal((n, h // 2, w // 2, ci)), dtype)
+    wt = rnd(rng.standard_normal((3, 3, ci, co)) * 0.2, dtype)
+    b = rng.standard_normal(co).astype(np.float32)
+    wm, bd, lod = f32(wt), f32(b), up(lo, dtype)
+    wph = torch.empty(16 * ci * co, dtype=tdt(dtype), device=dev())
+    N.call('rvip_pack_subpixel_weights', P(wm), ci, co, ndt(dtype), P(wph), stream())
+    y = torch.full((n, h, w, co), 9.0, dtype=tdt(dtype), device=dev())
+    d = conv_desc(lod, ci, 1, None, 0, wph, bd, y, None, 0, n, h, w, co, N.ACT['relu'], dtype)
+    d.subpix = 1
+    N.call('rvip_conv3x3_fwd', C.byref(d), stream())
+    ref = O.act_fwd(O.conv2d_same_fwd(O.upsample_nearest_fwd(lo).astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), 'relu')
+    got = down(y)
+    scale = float(np.abs(ref).max())
+    tol = (2.0 ** -6 if dtype == 'bf16' else 2e-5) * scale      # bf16: + one rounding of the summed taps
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max() / scale
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 12, 20, 16, 8), (1, 8, 8, 8, 24)])
 def test_conv2d_transpose_as_zero_stuffed_conv(shape, dtype):
     """Conv2DTranspose(3, strides=2, 'same') = the 3x3 igemm over the zero-stuffed read (up0 = 2) with the kernel in its
