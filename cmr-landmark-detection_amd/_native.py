@@ -48,7 +48,7 @@ class Wgrad3x3Desc(C.Structure):
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('dtype', C.c_int32),
                 ('workspace', vp), ('workspace_bytes', C.c_size_t),
-                ('depth', C.c_int32), ('kd', C.c_int32)]
+                ('depth', C.c_int32), ('kd', C.c_int32), ('defer_fold', C.c_int32)]
 
 
 class ApplyDesc(C.Structure):
@@ -70,7 +70,12 @@ class BnBwdDesc(C.Structure):
                 ('drop_rate', C.c_float), ('mask', vp), ('state', vp), ('layer_id', C.c_int32),
                 ('rows', C.c_longlong), ('c', C.c_int32),
                 ('dtype', C.c_int32),
-                ('workspace', vp), ('workspace_bytes', C.c_size_t)]
+                ('workspace', vp), ('workspace_bytes', C.c_size_t),
+                ('bias_rows', vp), ('bias_rows_bytes', C.c_size_t)]
+
+
+class FoldEntry(C.Structure):
+    _fields_ = [('src', vp), ('dst', vp), ('nrows', C.c_int32), ('reserved', C.c_int32), ('width', C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/rvip_hip.h declares
@@ -87,6 +92,9 @@ SIGNATURES = {
     'rvip_pack_all_conv3x3_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_conv3x3_wgrad_workspace': (C.c_size_t, [C.c_int] * 5),
     'rvip_conv3x3_wgrad': (C.c_int, [C.POINTER(Wgrad3x3Desc), vp]),
+    'rvip_conv3x3_wgrad_splits': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
+    'rvip_fold_rows_batch': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp]),
+    'rvip_bn_bwd_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'rvip_conv3x3_c1_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_conv3x3_c1_wgrad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'rvip_conv3d_c1_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

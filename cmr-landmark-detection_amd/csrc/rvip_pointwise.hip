@@ -145,6 +145,77 @@ static int launch_fold_k(const float* ws, int nblk, int width, int K, Post post,
     return check_launch();
 }
 
+// Deferred folds, batched: dst[i] = sum over r of src[r * width + i] for a TABLE of reductions in one launch (blockIdx.y =
+// entry).  The bias gradients (bn_bwd_apply) and weight gradients (wgrad slabs) are only read by the optimiser, so their
+// ~40 single-purpose fold launches per step collapse into a few.  Fixed summation order per entry -> reproducible.
+struct FoldEntry { const float* src; float* dst; int nrows; int pad; long long width; };
+
+// narrow rows (C floats), many rows: 1024 threads = 32 columns x 32 row groups, double accumulation
+__global__ __launch_bounds__(1024) void fold_batch_narrow(const FoldEntry* __restrict__ tab) {
+    __shared__ double sh[16][32];
+    const FoldEntry en = tab[blockIdx.y];
+    if ((long long)blockIdx.x * 32 >= en.width) return;
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long col = (long long)blockIdx.x * 32 + c;
+    double s = 0.0;
+    if (col < en.width) {
+        for (int b0 = g; b0 < en.nrows; b0 += 32 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + u * 32;
+                v[u] = b < en.nrows ? en.src[(size_t)b * en.width + col] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
+        }
+    }
+    const double o = __shfl_xor(s, 32);
+    if (!(g & 1)) sh[g >> 1][c] = s + o;
+    __syncthreads();
+    if (g == 0 && col < en.width) {
+        double acc = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) acc += sh[gg][c];
+        en.dst[col] = (float)acc;
+    }
+}
+
+// wide rows (9*Cin*Cout floats, a multiple of 4), few to hundreds of rows: 256 threads = 32 float4 columns x 8 row groups
+__global__ __launch_bounds__(256) void fold_batch_wide(const FoldEntry* __restrict__ tab) {
+    __shared__ float4 sh[8][32];
+    const FoldEntry en = tab[blockIdx.y];
+    const long long count4 = en.width >> 2;
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const float4* src = reinterpret_cast<const float4*>(en.src);
+    float4* dst = reinterpret_cast<float4*>(en.dst);
+    for (long long base = (long long)blockIdx.x * 32; base < count4; base += (long long)gridDim.x * 32) {
+        const long long i = base + e;
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (i < count4) {
+            for (int k0 = g; k0 < en.nrows; k0 += 8 * 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u * 8;
+                    v[u] = k < en.nrows ? src[(size_t)k * count4 + i] : float4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+        }
+        __syncthreads();
+        sh[g][e] = acc;
+        __syncthreads();
+        if (g == 0 && i < count4) {
+            float4 t = sh[0][e];
+#pragma unroll
+            for (int gg = 1; gg < 8; ++gg) { t.x += sh[gg][e].x; t.y += sh[gg][e].y; t.z += sh[gg][e].z; t.w += sh[gg][e].w; }
+            dst[i] = t;
+        }
+    }
+}
+
 struct PostSum {                      // out[ch] = total (plain sum), K = 1
     float* out;
     __device__ void run(int ch, const double (&t)[1]) const { out[ch] = (float)t[0]; }
@@ -940,17 +1011,39 @@ extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
     BnBwdArgs a; RedGeom g;
     int rc = fill_bnbwd(d, a, g);
     if (rc) return rc;
-    if (!d->dz || !d->dbias) return RVIP_EINVAL;
+    if (!d->dz || (!d->dbias && !d->bias_rows)) return RVIP_EINVAL;
     if (d->gamma && !d->coef) return RVIP_EINVAL;
-    if (d->workspace_bytes < (size_t)g.nblk * d->c * sizeof(float)) return RVIP_EWORKSPACE;
+    const bool defer = d->bias_rows != nullptr;      // leave the [nblk][C] partial rows to a later rvip_fold_rows_batch
+    if ((defer ? d->bias_rows_bytes : d->workspace_bytes) < (size_t)g.nblk * d->c * sizeof(float)) return RVIP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    float* ws = (float*)d->workspace;
+    float* ws = defer ? d->bias_rows : (float*)d->workspace;
     if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     rc = check_launch();
-    if (rc) return rc;
+    if (rc || defer) return rc;
     PostSum p{d->dbias};
     return launch_fold<1, PostSum>(ws, g.nblk, d->c, p, s);
+}
+
+extern "C" int rvip_bn_bwd_rows(long long rows, int c, int dtype) {
+    RedGeom g;
+    if (!RVIP_DT_OK(dtype) || !red_geom(rows, c, RVIP_VE(dtype), g)) return 0;
+    return g.nblk;
+}
+
+extern "C" int rvip_fold_rows_batch(const void* table, int entries, long long max_width, int wide, void* stream) {
+    (void)hipGetLastError();
+    if (!table || entries <= 0 || max_width <= 0) return RVIP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (wide) {
+        if (max_width % 4) return RVIP_EINVAL;
+        long long nb = cdiv(max_width / 4, 32);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(fold_batch_wide, dim3((unsigned)nb, (unsigned)entries), dim3(256), 0, s, (const FoldEntry*)table);
+    } else {
+        hipLaunchKernelGGL(fold_batch_narrow, dim3((unsigned)cdiv(max_width, 32), (unsigned)entries), dim3(1024), 0, s, (const FoldEntry*)table);
+    }
+    return check_launch();
 }
 
 extern "C" int rvip_maxpool2x2_bwd(const void* y, const void* dpooled, const void* add, void* dx, int n, int h, int w, int c,

@@ -577,6 +577,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
                 rc = g2.tw == 32 ? launch_wgrad2<float, 32, 32, 32>(b, s) : launch_wgrad2<float, 16, 32, 32>(b, s);
             }
             if (rc) return rc;
+            if (d->defer_fold && kd == 1) return RVIP_OK;      // slabs stay in the caller's workspace for rvip_fold_rows_batch
             rc = launch_wgrad_fold(a.slab, b.nsplit, count2, d->dw + (size_t)kdi * count2, s);
             if (rc) return rc;
         }
@@ -589,7 +590,23 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     if (d->workspace_bytes < need) return RVIP_EWORKSPACE;
     if (d->dtype == RVIP_BF16) rc = tw == 32 ? launch_wgrad<bf16_t, 32>(a, s) : launch_wgrad<bf16_t, 16>(a, s);
     else rc = tw == 32 ? launch_wgrad<float, 32>(a, s) : launch_wgrad<float, 16>(a, s);
-    if (rc) return rc;
+    if (rc || d->defer_fold) return rc;
     const long long count = 9LL * a.cin * a.cout;
     return launch_wgrad_fold(a.slab, a.nsplit, count, d->dw, s);
+}
+
+// number of split-K slabs rvip_conv3x3_wgrad writes for this shape (rows of the deferred fold; 0 = invalid descriptor)
+extern "C" int rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d) {
+    if (!d || (d->dtype != RVIP_BF16 && d->dtype != RVIP_F32) || d->n <= 0 || d->h <= 0 || d->w <= 0) return 0;
+    static const bool force_v1 = [] { const char* e = getenv("RVIP_WGRAD"); return e && e[0] == 'v' && e[1] == '1'; }();
+    const int up = d->up0 ? 1 : 0;
+    const long long esz = d->dtype == RVIP_BF16 ? 2 : 4;
+    const long long x0b = (long long)d->n * (d->h >> up) * (d->w >> up) * d->c0 * esz, x1b = (long long)d->n * d->h * d->w * d->c1 * esz;
+    const long long dyb = (long long)d->n * d->h * d->w * d->cout * esz;
+    const int kd = d->kd > 0 ? d->kd : 1;
+    const Wg2Geom g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype);
+    if ((!force_v1 || kd > 1) && g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) return g2.nsplit;
+    int tw, tx, ty, nt, ns;
+    wgrad_geometry(d->n, d->h, d->w, d->c0 + d->c1, d->cout, tw, tx, ty, nt, ns);
+    return ns;
 }

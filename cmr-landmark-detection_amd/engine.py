@@ -302,6 +302,7 @@ class Engine:
         return _ptr(self.bn_scratch, o + idx * ca)
 
     def _build_lists(self):
+        torch = _torch()
         L, P, plan, n = N.lib(), self.P, self.plan, self.n
         dt = P.dt
         A = N.ACT
@@ -413,8 +414,28 @@ class Engine:
         n_enc = 2 * plan.depth
         self.bwd_split = None
         self.grad_split = P.off[(plan.stages[n_enc].conv, 'kernel')][0] if len(plan.stages) > n_enc else 0
+        # Deferred folds: the partial rows of the bias gradients and the split-K slabs of the weight gradients (read only by
+        # the optimiser) stay in private regions and are summed by two table-driven launches per gradient bucket instead of
+        # one small fold launch per layer (~40 per step).
+        defer = self.kd == 1 and os.environ.get('RVIP_DEFER_FOLDS', '1') != '0'
+        narrow, wide = [], []                  # (src tensor, dst pointer, nrows, width) of the current bucket
+        self._fold_bufs = []
+
+        def flush_folds():
+            for entries, is_wide in ((narrow, 0), (wide, 1)):
+                if not entries:
+                    continue
+                tab = (N.FoldEntry * len(entries))()
+                for i, (src, dst, nrows, width) in enumerate(entries):
+                    tab[i].src, tab[i].dst, tab[i].nrows, tab[i].width = src.data_ptr(), dst.value, nrows, width
+                tabd = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.ws.device)
+                self._fold_bufs.append(tabd)
+                bwd.label = 'deferred folds (%s, %d layers)' % ('weight gradients' if is_wide else 'bias gradients', len(entries))
+                bwd.append((L.rvip_fold_rows_batch, (_ptr(tabd), len(entries), C.c_longlong(max(e[3] for e in entries)), is_wide)))
+                del entries[:]
         for si, st in reversed(list(enumerate(plan.stages))):
             if si == n_enc - 1:
+                flush_folds()                  # bucket 0 (head, decoder, bottleneck) is complete here
                 self.bwd_split = len(bwd)
             rows = n * st.h * st.w
             first = st.src0 == 'input_1'
@@ -444,6 +465,12 @@ class Engine:
                     b.mask = self.masks[st.drop[0]].data_ptr()
             b.rows, b.c, b.dtype = rows, st.cout, dt
             b.workspace, b.workspace_bytes = self.ws.data_ptr(), self.ws_bytes
+            if defer:
+                nr = L.rvip_bn_bwd_rows(C.c_longlong(rows), st.cout, dt)
+                rbuf = torch.empty(nr * st.cout, dtype=torch.float32, device=self.ws.device)
+                self._fold_bufs.append(rbuf)
+                b.bias_rows, b.bias_rows_bytes = rbuf.data_ptr(), rbuf.numel() * 4
+                narrow.append((rbuf, P.g(st.conv, 'bias'), nr, st.cout))
             self._keep.append(b)
             if st.bn:
                 bwd.append((L.rvip_bn_bwd_reduce, (C.byref(b),)))
@@ -463,6 +490,12 @@ class Engine:
             wg.n, wg.h, wg.w, wg.cout, wg.dtype = n, st.h, st.w, st.cout, dt
             wg.depth, wg.kd = self.depth, self.kd
             wg.workspace, wg.workspace_bytes = self.ws_wg.data_ptr(), self.ws_wg_bytes
+            if defer:
+                ns = L.rvip_conv3x3_wgrad_splits(C.byref(wg))
+                sbuf = torch.empty(ns * 9 * st.cin * st.cout, dtype=torch.float32, device=self.ws.device)
+                self._fold_bufs.append(sbuf)
+                wg.workspace, wg.workspace_bytes, wg.defer_fold = sbuf.data_ptr(), sbuf.numel() * 4, 1
+                wide.append((sbuf, P.g(st.conv, 'kernel'), ns, 9 * st.cin * st.cout))
             self._keep.append(wg)
             bwd.append((L.rvip_conv3x3_wgrad, (C.byref(wg),)))
             dg = N.Conv3x3Desc()
@@ -485,6 +518,7 @@ class Engine:
             if st.up0 and not fuse_down:    # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions
                 back = L.rvip_upsample2x_bwd if st.up0 == 1 else L.rvip_subsample_odd
                 bwd.append((back, (_ptr(self.up_tmp[st.conv]), _ptr(self.grd[st.src0]), n, st.h // 2, st.w // 2, st.c0, dt)))
+        flush_folds()
         self.fwd_train, self.fwd_infer, self.bwd = fwd_t, fwd_i, bwd
         self.opt = [(L.rvip_adam_step, (_ptr(P.theta), _ptr(P.grad), _ptr(P.adam_m), _ptr(P.adam_v), C.c_longlong(P.count),
                                         C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0), _ptr(P.state)))]

@@ -138,10 +138,22 @@ typedef struct rvip_wgrad3x3_desc {
     int32_t      dtype;
     void*        workspace;  size_t workspace_bytes;
     int32_t      depth, kd;           /* Conv3D: as in rvip_conv3x3_desc; dw is then [27][C0+C1][Cout] */
+    /* defer_fold != 0 (2-D only): stop after stage 1 - the rvip_conv3x3_wgrad_splits(d) slabs [splits][9*(C0+C1)*Cout]
+     * stay in `workspace` (which the caller must then keep private to this layer) and dw is not written; sum them later,
+     * together with other layers', with rvip_fold_rows_batch(..., wide = 1). */
+    int32_t      defer_fold;
 } rvip_wgrad3x3_desc;
 
 size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout);
 int    rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream);
+int    rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d);
+
+/* Batched stage 2 for reductions whose result only the optimiser reads (bias gradients, weight gradients):
+ * dst[i] = sum_r src[r*width + i], r < nrows, for `entries` records of a DEVICE table in ONE launch, fixed order.
+ * wide = 0: rows of C floats (double accumulation; rvip_bn_bwd_apply with bias_rows); wide = 1: rows of 9*Cin*Cout
+ * floats, width % 4 == 0, 16-byte aligned (rvip_conv3x3_wgrad with defer_fold).  max_width = max over the entries. */
+typedef struct rvip_fold_entry { const float* src; float* dst; int32_t nrows; int32_t reserved; long long width; } rvip_fold_entry;
+int rvip_fold_rows_batch(const void* table, int entries, long long max_width, int wide, void* stream);
 
 /* First layer, Cin = 1 (bandwidth-bound, no MFMA): y = act(conv3x3(x[N,H,W,1]) + bias); weights are
  * the fp32 HWIO master [9][1][Cout].  wgrad: dw[9][Cout] and nothing else (the input has no grad).
@@ -220,9 +232,13 @@ typedef struct rvip_bnbwd_desc {
     long long    rows; int32_t c;
     int32_t      dtype;
     void*        workspace; size_t workspace_bytes;
+    /* bias_rows != NULL: rvip_bn_bwd_apply leaves the rvip_bn_bwd_rows(rows, c, dtype) partial rows [rows][C] of the
+     * bias gradient there instead of folding them into dbias (fold later with rvip_fold_rows_batch, wide = 0). */
+    float*       bias_rows; size_t bias_rows_bytes;
 } rvip_bnbwd_desc;
 int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);
+int rvip_bn_bwd_rows(long long rows, int c, int dtype);
 
 /* MaxPooling2D backward: dx = route(dpooled -> first max of each 2x2 window of y) + add (add may be
  * NULL; it carries the skip-connection gradient that reaches the same tensor). */
