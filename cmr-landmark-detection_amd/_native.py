@@ -114,6 +114,8 @@ SIGNATURES = {
     'rvip_head_grad': (C.c_int, [vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     'rvip_head_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'rvip_landmarks': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    'rvip_postprocess_workspace': (C.c_size_t, [C.c_int] * 4),
+    'rvip_postprocess': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, C.c_size_t, vp]),
     'rvip_adam_step': (C.c_int, [vp, vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]),
     'rvip_state_tick': (C.c_int, [vp, vp]),
     'rvip_convert': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, vp]),

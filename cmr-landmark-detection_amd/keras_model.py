@@ -322,6 +322,33 @@ class Model:
         idx, mask = eng.landmarks(thr, want_mask=True)
         return idx.cpu().numpy().reshape(eng.out_shape[:-3] + eng.out_shape[-1:]), mask.cpu().numpy().reshape(eng.out_shape)
 
+    def predict_rvip(self, x, thr=0.5, cc_filter=False):
+        """The reference's post-threshold of a predicted batch on the device (predict_model.py:149-156 flat labels,
+        Postprocess.py:108-120 largest 4-connected component per slice and label when `cc_filter`, evaluate_cv.py:418-442
+        mean (y, x) per label).  Returns (flat uint8 [N,*DIM], points float32 [N,(T,)C,2] with NaN for absent labels,
+        sizes int32 [N,(T,)C])."""
+        import ctypes as C
+        import torch
+        from . import _native as N
+        x = np.asarray(x, np.float32)
+        eng = self._engine(x.shape[0])
+        eng.load_input(x)
+        eng.forward(training=False)
+        n, H, W, K = eng.pred.shape
+        L = N.lib()
+        dev = eng.pred.device
+        flat = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+        pts = torch.empty((n, K, 2), dtype=torch.float32, device=dev)
+        sizes = torch.empty((n, K), dtype=torch.int32, device=dev)
+        wsb = L.rvip_postprocess_workspace(n, H, W, K)
+        ws = torch.empty(wsb // 4 + 16, dtype=torch.int32, device=dev)
+        N.check(L.rvip_postprocess(eng.pred.data_ptr(), flat.data_ptr(), pts.data_ptr(), sizes.data_ptr(), n, H, W, K,
+                                   C.c_float(thr), 1 if cc_filter else 0, ws.data_ptr(), C.c_size_t(wsb),
+                                   C.c_void_p(eng.stream())), 'rvip_postprocess')
+        lead = eng.out_shape[:-3]
+        return (flat.cpu().numpy().reshape(eng.out_shape[:-1]), pts.cpu().numpy().reshape(lead + (K, 2)),
+                sizes.cpu().numpy().reshape(lead + (K,)))
+
     def evaluate(self, x, y=None, verbose=0, return_dict=False, **_):
         tot, cnt = None, 0
         if isinstance(x, np.ndarray):

@@ -283,6 +283,18 @@ int rvip_head_bwd(const void* x, const float* w, const float* dlogit, void* dx, 
 int rvip_landmarks(const float* pred, long long* idx_out, uint8_t* mask_out, int n, int hw, int k, float thr,
                    void* stream);
 
+/* The reference's post-threshold of a predicted batch, on the device (the step after the hot path):
+ *   flat[n][h][w] uint8   = 0, then c+1 where pred[..., c] > thr, later channels overriding earlier ones
+ *                           (predict_model.py:149-156, evaluate_cv.py preds_flat)
+ *   cc_filter != 0        : per slice and label only the largest 4-connected component survives, ties -> the one met
+ *                           first in raster order (Postprocess.py:108-120 clean_3d_prediction_2d_cc, cv2 connectivity 4)
+ *   points[n][k][2] float = mean (y, x) of the surviving pixels of label c+1, NaN when there are none
+ *                           (evaluate_cv.py:418-442 get_mean_rvip_2d);  sizes[n][k] int32 = their number.
+ * workspace: rvip_postprocess_workspace(n, h, w, k) bytes. */
+size_t rvip_postprocess_workspace(int n, int h, int w, int k);
+int rvip_postprocess(const float* pred, uint8_t* flat, float* points, int* sizes, int n, int h, int w, int k, float thr,
+                     int cc_filter, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Keras Adam (ModelUtils.py:106-107; beta1 .9, beta2 .999, eps 1e-7 outside the bias correction) over a
  * flat fp32 parameter block; t = state[STEP]+1, lr = state[LR].  rvip_state_tick increments STEP. */
 int rvip_adam_step(float* theta, const float* grad, float* m, float* v, long long count,

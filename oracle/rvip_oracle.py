@@ -577,6 +577,43 @@ def centroid_landmarks(heat, thr=0.5):
     return out
 
 
+def flat_labels(pred, thr=0.5):
+    """predict_model.py:149-156 / evaluate_cv.py (preds_flat): 0, then c+1 where pred[..., c] > thr; later channels
+    override earlier ones.  pred [N,H,W,C] -> uint8 [N,H,W]."""
+    out = np.zeros(pred.shape[:-1], np.uint8)
+    for c in range(pred.shape[-1]):
+        out[pred[..., c] > thr] = c + 1
+    return out
+
+
+def clean_2d_cc(flat):
+    """Postprocess.py:108-120 clean_3d_prediction_2d_cc: per slice and label value keep the largest 4-connected
+    component (cv2.connectedComponentsWithStats(mask, 4); np.argmax -> the first of equally large ones, and cv2 / scipy
+    both number components in raster order of their first pixel).  `np.unique(s)[1:]` is the reference's way of skipping
+    the background: a slice without background loses its smallest label instead (kept as is)."""
+    import scipy.ndimage
+    four = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    out = np.zeros_like(flat)
+    for i, s in enumerate(flat):
+        for val in np.unique(s)[1:]:
+            lab, n = scipy.ndimage.label(s == val, structure=four)
+            sizes = np.bincount(lab.ravel())[1:]
+            out[i][lab == 1 + int(np.argmax(sizes))] = val
+    return out
+
+
+def mean_rvip_points(flat, n_labels=2):
+    """evaluate_cv.py:418-442 get_mean_rvip_2d per slice: mean (y, x) of every label's pixels, NaN (the reference's
+    None) when absent.  Like the reference it takes `np.unique(slice)[1:]` as the labels, so on a slice without any
+    background pixel the smallest label present gets no point.  -> float64 [N, n_labels, 2]"""
+    out = np.full((flat.shape[0], n_labels, 2), np.nan)
+    for i, s in enumerate(flat):
+        for v in np.unique(s)[1:]:
+            ys, xs = np.where(s == v)
+            out[i, int(v) - 1] = (ys.mean(), xs.mean())
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # optimiser: Keras OptimizerV2 Adam (ModelUtils.py:106-107)
 # ----------------------------------------------------------------------------------------------

@@ -135,6 +135,13 @@ def test_fp32_training_steps_match_oracle(variant):
     idx, mask = model.predict_landmarks(xt[:3])
     np.testing.assert_array_equal(idx, O.landmark_argmax(pg[:3]))
     np.testing.assert_array_equal(mask.astype(bool), O.threshold_mask(pg[:3]))
+    if len(cfg['DIM']) == 2:                 # the reference's post-threshold (flat labels, CC filter, mean RVIP points) on the device
+        flat, pts, sizes = model.predict_rvip(xt[:3], cc_filter=True)
+        rflat = O.clean_2d_cc(O.flat_labels(pg[:3]))
+        np.testing.assert_array_equal(flat, rflat)
+        rp = O.mean_rvip_points(rflat, pg.shape[-1])
+        assert np.array_equal(np.isnan(pts), np.isnan(rp))
+        np.testing.assert_allclose(pts[~np.isnan(rp)], rp[~np.isnan(rp)], rtol=1e-6)
 
 
 def test_train_on_batch_logs_and_metrics():

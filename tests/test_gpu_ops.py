@@ -601,3 +601,40 @@ def test_bad_arguments_are_refused_not_launched():
     g.n, g.h, g.w, g.cout, g.dtype = 1, 4, 4, 8, N.F32
     g.workspace, g.workspace_bytes = x.data_ptr(), 16
     assert L.rvip_conv3x3_wgrad(C.byref(g), stream()) == -3                          # workspace too small
+
+
+@pytest.mark.parametrize('cc', [0, 1])
+def test_postprocess_flat_labels_cc_filter_and_points(cc):
+    """rvip_postprocess vs the restatement of predict_model.py:149-156, Postprocess.py:108-120 (largest 4-connected
+    component, first on ties) and evaluate_cv.py:418-442 (mean y/x per label): labels bit-exact, points to fp32."""
+    rng = np.random.default_rng(7)
+    n, h, w, k = 5, 40, 56, 2
+    pred = (rng.random((n, h, w, k)) * 0.3).astype(np.float32)
+    for i in range(n):                                   # a few blobs per channel, some touching only diagonally, one snake
+        for c in range(k):
+            for _ in range(3 + i % 2):
+                y0, x0, r = int(rng.integers(2, h - 8)), int(rng.integers(2, w - 8)), int(rng.integers(1, 5))
+                pred[i, y0:y0 + r, x0:x0 + r, c] = 0.9
+    pred[0, 10:12, 10:12, 0] = 0.9; pred[0, 12:14, 12:14, 0] = 0.9          # diagonal neighbours: separate under 4-connectivity
+    pred[1, 5, 3:50, 1] = 0.8; pred[1, 5:30, 49, 1] = 0.8; pred[1, 29, 3:50, 1] = 0.8   # long snake (many sweeps)
+    pred[2, :, :, 1] = 0.1                               # label 2 absent on slice 2
+    pred[3, 20:24, 20:24, 0] = 0.9; pred[3, 20:24, 30:34, 0] = 0.9          # equal sizes: the first in raster order wins
+    pred[4, :, :, 0] = np.maximum(pred[4, :, :, 0], 0.6)  # no background on slice 4: np.unique(s)[1:] then skips label 1 (reference quirk)
+    pd = f32(pred)
+    flat = torch.empty((n, h, w), dtype=torch.uint8, device=dev())
+    pts = torch.empty((n, k, 2), dtype=torch.float32, device=dev())
+    sizes = torch.empty((n, k), dtype=torch.int32, device=dev())
+    L = N.lib()
+    wsb = L.rvip_postprocess_workspace(n, h, w, k)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.int32, device=dev())
+    N.call('rvip_postprocess', P(pd), P(flat), P(pts), P(sizes), n, h, w, k, 0.5, cc, P(ws), C.c_size_t(wsb), stream())
+    torch.cuda.synchronize()
+    ref = O.flat_labels(pred)
+    if cc:
+        ref = O.clean_2d_cc(ref)
+    np.testing.assert_array_equal(flat.cpu().numpy(), ref)
+    rp = O.mean_rvip_points(ref, k)
+    got = pts.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(rp)) and np.isnan(rp[2, 1]).all() and np.isnan(rp[4, 0]).all()
+    np.testing.assert_allclose(got[~np.isnan(rp)], rp[~np.isnan(rp)], rtol=1e-6)
+    np.testing.assert_array_equal(sizes.cpu().numpy(), np.stack([(ref == v + 1).sum((1, 2)) for v in range(k)], 1))

@@ -311,3 +311,30 @@ def test_cine_graph_inventory_and_gradient():
     net.apply_bn_moving(cache)
     _, _, _, var = cache['batch_normalization']
     np.testing.assert_allclose(net.params['batch_normalization'][3], mv0 * 0.99 + var * 0.01, rtol=1e-12)
+
+
+def test_post_threshold_restatement():
+    """predict_model.py:149-156 flat labels, Postprocess.py:108-120 largest 4-connected component per slice and label,
+    evaluate_cv.py:418-442 mean point per label -- including the reference's np.unique(x)[1:] behaviour on slices
+    without background."""
+    pred = np.zeros((3, 6, 8, 2), np.float32)
+    pred[0, 0:2, 0:2, 0] = 0.9          # label 1: 4 px
+    pred[0, 2:4, 2:5, 0] = 0.9          # label 1: 6 px, touches the first only diagonally -> separate component
+    pred[0, 5, 0:3, 1] = 0.8            # label 2: 3 px
+    pred[0, 0, 5:8, 1] = 0.8            # label 2: 3 px, earlier in raster order -> wins the tie
+    pred[0, 2, 2, 1] = 0.7              # overlap: channel 1 overrides channel 0
+    pred[1, :, :, 0] = 0.6              # slice without background: labels {1, 2}
+    pred[1, 1:3, 1:3, 1] = 0.9
+    flat = O.flat_labels(pred)
+    assert flat[0, 2, 2] == 2 and flat[0, 0, 0] == 1 and flat[2].sum() == 0
+    assert set(np.unique(flat[1])) == {1, 2}
+    cl = O.clean_2d_cc(flat)
+    assert (cl[0] == 1).sum() == 5 and cl[0, 0, 0] == 0 and cl[0, 3, 4] == 1      # 6 px minus the overridden one; small blob gone
+    assert (cl[0, 0, 5:8] == 2).all() and (cl[0, 5, 0:3] == 0).all() and cl[0, 2, 2] == 0   # single-pixel label 2 dropped too
+    assert (cl[1] == 1).sum() == 0 and (cl[1] == 2).sum() == 4                       # no background: label 1 is skipped
+    pts = O.mean_rvip_points(cl)
+    np.testing.assert_allclose(pts[0, 1], (0.0, 6.0))
+    np.testing.assert_allclose(pts[1, 1], (1.5, 1.5))
+    assert np.isnan(pts[1, 0]).all() and np.isnan(pts[2]).all()
+    raw = O.mean_rvip_points(flat)                                                  # without the filter: slice 1 has no zero
+    assert np.isnan(raw[1, 0]).all() and not np.isnan(raw[1, 1]).any()
