@@ -5,6 +5,7 @@ device's own dropout stream reproduced on the host.
 north_star bar: fp32 heat-maps within 1e-3 max-abs of the CPU reference, argmax landmark indices bit-exact,
 >0.5 masks identical.  The bf16 path reports its own (looser) error."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -294,3 +295,47 @@ def test_fit_with_generator_and_callbacks(tmp_path):
     m2.load_weights(str(tmp_path / 'model.npz'))
     xb, _ = val[0]
     assert m2.predict(xb).shape == (8, 64, 64, 2)
+
+
+def _dp_gpu_worker(rank, world, port, overlap, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      RVIP_OVERLAP_ALLREDUCE=overlap)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cfg = _cfg(BATCH_NORMALISATION=False, DROPOUT_MIN=0.0, DROPOUT_MAX=0.0, DIM=[32, 32], FILTERS=8)
+        model = rvip.get_model(cfg, metrics=[])
+        x, y = O.synthetic_batch(8, cfg['DIM'], 2, seed=5)
+        losses = [model.train_on_batch(x, y)[0] for _ in range(2)]        # global batch 8 -> 4 per rank (Model._shard)
+        q.put((rank, losses, [w.copy() for w in model.get_weights()], bool(model._engine(4).overlap_ok())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', ['1', '0'])
+def test_two_rank_data_parallel_step_matches_single_rank(overlap):
+    """Two ranks (gloo, both on this one GPU) through the product's sharding + bucketed / single all-reduce + Adam give
+    the weights of one rank training on the whole batch (no BN: per-replica statistics would differ by design)."""
+    import torch.multiprocessing as mp
+    cfg = _cfg(BATCH_NORMALISATION=False, DROPOUT_MIN=0.0, DROPOUT_MAX=0.0, DIM=[32, 32], FILTERS=8)
+    single = rvip.get_model(cfg, metrics=[])
+    x, y = O.synthetic_batch(8, cfg['DIM'], 2, seed=5)
+    ref_losses = [single.train_on_batch(x, y)[0] for _ in range(2)]
+    ref_w = single.get_weights()
+    torch.cuda.synchronize()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000) + (1 if overlap == '1' else 0)
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    for rank, losses, w, ov in res:
+        assert ov == (overlap == '1')
+        for a_, b_ in zip(w, ref_w):
+            np.testing.assert_allclose(a_, b_, atol=2e-6, rtol=2e-5)
+    for rank, losses, _, _ in res:                       # the logged loss is the global one (loss sums are all-reduced)
+        for step in range(2):
+            assert abs(losses[step] - ref_losses[step]) <= 2e-5 * max(1.0, abs(ref_losses[step])), (rank, step)
