@@ -392,6 +392,222 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
     }
 }
 
+// wgrad v3: the same kernel with the producer / consumer split of igemm v3.  A workgroup is 8 waves: waves 0..3 contract
+// (exactly the four waves of v2), waves 4..7 only issue the LDS-DMA pieces of the next pixel tile; one s_barrier per tile
+// joins them.  In v2 every wave issues ~19 DMA instructions (~150 issue cycles each) in front of its 144 MFMAs per tile.
+template <typename T, int TW, int CIB, int COB>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
+    constexpr int TH = 256 / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
+    constexpr int NHROWS = (NHALO + 15) / 16 * 16;
+    constexpr int ESZ = (int)sizeof(T), VE = Vec<T>::VE;
+    constexpr int RBX = CIB * ESZ, RBG = COB * ESZ;                 // row bytes: 64 or 128
+    static_assert((RBX == 64 || RBX == 128) && (RBG == 64 || RBG == 128), "row bytes");
+    constexpr int X_BYTES = NHROWS * RBX, G_BYTES = 256 * RBG, ST_BYTES = X_BYTES + G_BYTES;
+    constexpr int NQX = X_BYTES / 1024, NQG = G_BYTES / 1024;
+    constexpr int QX = (NQX + 3) / 4, QG = (NQG + 3) / 4;
+    constexpr int NPAIR = (CIB / 32) * (COB / 32) > 4 ? 4 : (CIB * ESZ / 64) * 0 + ((CIB / 32) * (COB / 32));
+    constexpr int NCI = (ESZ == 2) ? CIB / 32 : 1, NCO = (ESZ == 2) ? COB / 32 : 1;   // 32-channel MFMA tiles per block
+    constexpr int PAIRS = NCI * NCO;                                  // 1, 2 or 4
+    constexpr int PSPLIT = 4 / PAIRS;
+    constexpr unsigned OOB = 0x80000000u;
+    (void)NPAIR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
+    const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wv8 >= 4;
+    const int wv = wv8 & 3;                                           // compute wave id / loader wave id
+    const int split = blockIdx.x, ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
+    const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
+    const int pair = wv % PAIRS, part = wv / PAIRS;
+    const int ci_t = pair % NCI, co_t = pair / NCI;
+
+    const bool from0 = ci0 < a.c0;                                    // a block never straddles the concat (host)
+    const i32x4w rsx = from0 ? make_rsrc_w(a.x0, a.x0_bytes) : make_rsrc_w(a.x1, a.x1_bytes);
+    const i32x4w rsg = make_rsrc_w(a.dy, a.dy_bytes);
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+
+    // Tile-independent lane geometry of the DMA pieces this wave issues.  A piece's byte offset is
+    //   tile_base (wave-uniform) + rel (per lane, precomputed)      -- also for the x2 reads: tiles start on even
+    // coordinates, so ((ty0 - 1 + hy) >> 1) = ty0/2 + ((hy - 1) >> 1) -- and validity is a handful of compares
+    // folded into one select (no branches in the per-tile issue code).
+    constexpr int SLX = RBX / 16, RPPX = 1024 / RBX, SLG = RBG / 16, RPPG = 1024 / RBG;
+    const int csrc = from0 ? a.c0 : a.c1, cb0 = from0 ? ci0 : ci0 - a.c0;
+    const int hs = from0 ? h0 : a.h, wsrc = from0 ? w0 : a.w, shf = from0 ? a.up0 : 0;
+    const bool zsx = from0 && a.zs;
+    int xhy[QX], xhx[QX], xrel[QX], grel[QG], gpy[QG], gpx[QG];
+#pragma unroll
+    for (int i = 0; i < QX; ++i) {
+        const int row = (wv + 4 * i) * RPPX + lane / SLX, slot = lane % SLX;
+        const int hy = row / HWD, hx = row - hy * HWD;
+        const int p = (RBX == 128) ? ((((slot >> 2) ^ ((hx >> 1) & 1)) << 2) | (slot & 3)) : slot;   // swizzle by the halo x coordinate
+        const int c = cb0 + p * VE;
+        const bool ok = row < NHALO && c < csrc;
+        xhy[i] = ok ? hy - 1 : -100000;                           // a statically dead piece fails the range test below
+        xhx[i] = hx - 1;
+        xrel[i] = ((((hy - 1) >> shf) * wsrc + ((hx - 1) >> shf)) * csrc + c) * ESZ;
+    }
+#pragma unroll
+    for (int i = 0; i < QG; ++i) {
+        const int P = (wv + 4 * i) * RPPG + lane / SLG, slot = lane % SLG;
+        const int p = (RBG == 128) ? ((((slot >> 2) ^ ((P >> 1) & 1)) << 2) | (slot & 3)) : slot;
+        const int c = co0 + p * VE;
+        gpy[i] = (c < a.cout) ? P / TW : -100000;
+        gpx[i] = P % TW;
+        grel[i] = (((P / TW) * a.w + (P % TW)) * a.cout + c) * ESZ;
+    }
+    auto issue = [&](int tile, int stage) __attribute__((always_inline)) {
+        int bx = tile;
+        const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty_i = bx % a.tiles_y;
+        const int n = bx / a.tiles_y;
+        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+        const bool dok = (unsigned)(n % a.depth + a.dshift) < (unsigned)a.depth;
+        const int xbase = (((n + a.dshift) * hs + (ty0 >> shf)) * wsrc + (tx0 >> shf)) * csrc * ESZ;
+        const int gbase = ((n * a.h + ty0) * a.w + tx0) * a.cout * ESZ;
+#pragma unroll
+        for (int i = 0; i < QX; ++i) {
+            const int q = wv + 4 * i;
+            if (q < NQX) {
+                const int gy = ty0 + xhy[i], gx = tx0 + xhx[i];
+                bool ok = dok && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+                if (zsx) ok = ok && ((gy & gx) & 1);
+                const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(xbase + xrel[i]) : OOB;
+                dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < QG; ++i) {
+            const int q = wv + 4 * i;
+            if (q < NQG) {
+                const int gy = ty0 + gpy[i], gx = tx0 + gpx[i];
+                const bool ok = (unsigned)gy < (unsigned)a.h && gx < a.w;
+                const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(gbase + grel[i]) : OOB;
+                dma16w(rsg, off, lds_base + stage * ST_BYTES + X_BYTES + q * 1024);
+            }
+        }
+    };
+
+    if (loader) {
+        if (split < a.ntiles) issue(split, 0);
+        int it = 0;
+        for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
+            // my pieces of this tile have landed; after the barrier everybody's have, and the compute waves are done
+            // with the previous tile, whose stage the next one may overwrite
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tile + a.nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + a.nsplit, (it + 1) & 1);
+        }
+        asm volatile("s_barrier" ::: "memory");                       // matches the compute waves' barrier before the fold
+        if constexpr (PSPLIT > 1) {
+            for (int psel = 0; psel < PSPLIT; ++psel) __syncthreads();
+        }
+        return;
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int it = 0;
+    for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
+        asm volatile("s_barrier" ::: "memory");                       // the tile is in LDS (the loaders waited for their DMAs)
+        if (a.dbg & 2) continue;
+        const unsigned char* lx = smem + (it & 1) * ST_BYTES;
+        const unsigned char* lg = lx + X_BYTES;
+        if constexpr (ESZ == 2) {
+            // Every transposed read of the tile = one of 6 (X) / 2 (G) per-lane base addresses + a compile-time offset:
+            // the 64-byte-half swizzle of a 128-byte row depends only on bit 1 of the halo x coordinate, which is the
+            // same for every k-step (k-steps start on multiples of 16 pixels) and every tap ROW; only the tap COLUMN
+            // (tx = 0..2) changes it.  No address arithmetic is left between the MFMAs.
+            constexpr int STEPS = 16 / PSPLIT;
+            const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, grp = lane >> 4;
+            const int kk = 8 * (grp >> 1) + q4;
+            const int cb = (16 * (grp & 1) + 4 * p4) * 2;
+            const int wave_px = part * STEPS * 16;                       // first pixel of this wave's share (multiple of 64)
+            const unsigned char* xp[3][2];
+            const unsigned char* gp[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pxl = kk + 4 * u;                              // x within the k-step (0..15)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const int hx = pxl + tx;
+                    xp[tx][u] = lx + ((wave_px / TW) * HWD + hx) * RBX + ((RBX == 128) ? ((ci_t ^ ((hx >> 1) & 1)) << 6) : 0) + cb;
+                }
+                gp[u] = lg + (wave_px + pxl) * RBG + ((RBG == 128) ? ((co_t ^ ((pxl >> 1) & 1)) << 6) : 0) + cb;
+            }
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                constexpr int dummy = 0; (void)dummy;
+                const int srow = (s * 16) / TW, scol = (s * 16) % TW;     // compile-time after unrolling
+                const s16x4 g0 = tr_read(gp[0] + s * 16 * RBG);
+                const s16x4 g1 = tr_read(gp[1] + s * 16 * RBG);
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int off = ((srow + t / 3) * HWD + scol) * RBX;
+                    const s16x4 x0 = tr_read(xp[t % 3][0] + off);
+                    const s16x4 x1 = tr_read(xp[t % 3][1] + off);
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+            // f32: 32 channels per operand (128-byte rows), lane = channel, one pixel per half-wave
+            constexpr int STEPS = 128 / PSPLIT;
+            const int choff = (j & 15) * 4, chalf = j >> 4;
+#pragma unroll 2
+            for (int s = 0; s < STEPS; ++s) {
+                const int P = (part * STEPS + s) * 2 + hf;
+                const int py = P / TW, px = P % TW;
+                const float g = *reinterpret_cast<const float*>(lg + P * RBG + ((chalf ^ ((px >> 1) & 1)) << 6) + choff);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int hx = px + t % 3;
+                    const int rr = (py + t / 3) * HWD + hx;
+                    const float x = *reinterpret_cast<const float*>(lx + rr * RBX + ((chalf ^ ((hx >> 1) & 1)) << 6) + choff);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, g, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // results: one 9 x 32 x 32 fp32 block per (ci_t, co_t) pair; waves that split the pixels fold through LDS
+    asm volatile("s_barrier" ::: "memory");                           // every stage has been consumed by every compute wave
+    float* out = a.slab + (size_t)split * 9 * a.cin * a.cout;
+    if constexpr (PSPLIT == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + ci_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf, co = co0 + co_t * 32 + j;
+                if (ci < a.cin && co < a.cout) out[((size_t)t * a.cin + ci) * a.cout + co] = acc[t][r];
+            }
+    } else {
+        float* red = reinterpret_cast<float*>(smem) + pair * 9 * 32 * 32;   // [PAIRS][9][32][32]
+        for (int psel = 0; psel < PSPLIT; ++psel) {
+            if (part == psel) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int idx = (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j;
+                        red[idx] = (psel == 0 ? 0.f : red[idx]) + acc[t][r];
+                    }
+            }
+            __syncthreads();
+        }
+        const float* redall = reinterpret_cast<const float*>(smem);
+        for (int e = tid; e < PAIRS * 9 * 32 * 32; e += 256) {
+            const int pr = e / (9 * 32 * 32), rem = e % (9 * 32 * 32);
+            const int t = rem >> 10, ci = ci0 + (pr % NCI) * 32 + ((rem >> 5) & 31), co = co0 + (pr / NCI) * 32 + (rem & 31);
+            if (ci < a.cin && co < a.cout) out[((size_t)t * a.cin + ci) * a.cout + co] = redall[e];
+        }
+    }
+}
+
 // dw[i] = sum_k slab[k][i] in a fixed order (reproducible).  A thread owns four consecutive elements (one 16-byte
 // load per slab); a workgroup = 32 such threads x G split groups, and every thread has all of its (<= U) loads in
 // flight before the first add: the fold of a small kernel over hundreds of slabs is a chain of load latencies.
@@ -474,8 +690,8 @@ static Wg2Geom wgrad2_geometry(int n, int h, int w, int c0, int c1, int cout, in
     return g;
 }
 
-template <typename T, int TW, int CIB, int COB>
-static int launch_wgrad2(const WgArgs2& a, hipStream_t s) {
+template <typename T, int TW, int CIB, int COB, bool WS>
+static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
     constexpr int TH = 256 / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int ESZ = (int)sizeof(T);
@@ -485,15 +701,27 @@ static int launch_wgrad2(const WgArgs2& a, hipStream_t s) {
     static_assert(2 * ST >= 4 * 9 * 32 * 32 * 4 || true, "fold buffer");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma<T, TW, CIB, COB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = WS ? hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma<T, TW, CIB, COB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
         attr_done = true;
     }
     dim3 grid((unsigned)a.nsplit, (unsigned)cdiv(a.cin, CIB), (unsigned)cdiv(a.cout, COB));
-    hipLaunchKernelGGL((wgrad3x3_dma<T, TW, CIB, COB>), grid, dim3(256), lds, s, a);
+    if constexpr (WS) hipLaunchKernelGGL((wgrad3x3_ws<T, TW, CIB, COB>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((wgrad3x3_dma<T, TW, CIB, COB>), grid, dim3(256), lds, s, a);
     return check_launch();
 }
+
+// RVIP_WGRAD=v2 keeps the 4-wave kernel (A/B measurements); default: the wave-specialised one for bf16
+template <typename T, int TW, int CIB, int COB>
+static int launch_wgrad2(const WgArgs2& a, hipStream_t s) {
+    static const bool v2 = [] { const char* e = getenv("RVIP_WGRAD"); return e && e[0] == 'v' && e[1] == '2'; }();
+    if constexpr (sizeof(T) == 2) {
+        if (!v2) return launch_wgrad2x<T, TW, CIB, COB, true>(a, s);
+    }
+    return launch_wgrad2x<T, TW, CIB, COB, false>(a, s);
+}
+
 
 template <typename T, int TW>
 static int launch_wgrad(const WgArgs& a, hipStream_t s) {
