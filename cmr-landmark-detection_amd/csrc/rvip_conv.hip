@@ -642,8 +642,11 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
 // is four 2x2-tap convolutions on the low-resolution image (16 instead of 36 multiply-adds per low-resolution pixel and
 // channel pair).  blockIdx.z = phase 2a+b; weights [4 phases][4 taps (u,v)][Cout][Cin] from rvip_pack_subpixel_weights;
 // the same 3x3 halo is staged and tap (u,v) reads halo position (py + a + u, px + b + v).
-template <typename T, int TW, int NCT, int NPIX, bool STATS, int TAPS = 9>
-__global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
+// NCW = number of compute waves: 4 (one per SIMD, 128 pixels each at NPIX = 512) or 8 (two per SIMD, 64 pixels each: the
+// epilogue stores are spread over twice as many waves, which is what the store-bound layers with one or two K chunks per
+// tile need); the four loader waves are the same in both.
+template <typename T, int TW, int NCT, int NPIX, bool STATS, int TAPS = 9, int NCW = 4>
+__global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     static_assert(TAPS == 9 || TAPS == 4, "taps");
     constexpr int TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
     constexpr int NHROWS = (NHALO + 15) / 16 * 16;
@@ -652,7 +655,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     constexpr int VE = Vec<T>::VE, KCE = 4 * VE;
     constexpr int NQI = NHROWS / 16, NQW = WROWS / 16;                 // 1 KiB DMA pieces per stage
     constexpr int QI = (NQI + 3) / 4, QW = (NQW + 3) / 4;              // per loader wave
-    constexpr int NPT = NPIX / 128;                                    // 32-pixel tiles per compute wave
+    constexpr int NPT = NPIX / (32 * NCW);                              // 32-pixel tiles per compute wave
+    static_assert(NPT >= 1 && NPT * 32 * NCW == NPIX, "pixel tiles");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lin = smem;                       // [2][IN_BYTES]
@@ -670,9 +674,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     float* lbias = reinterpret_cast<float*>(smem + a.lds_bias_off);        // [BN] bias of this output-channel tile
     if (tid < BN) lbias[tid] = (a.bias && co0 + tid < a.cout) ? a.bias[co0 + tid] : 0.f;
 
-    if (wv >= 4) {
+    if (wv >= NCW) {
         // ------------------------------------------------ loader waves ------------------------------------------------
-        const int lwv = wv - 4;
+        const int lwv = wv - NCW;
         const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
         const i32x4 rs0 = make_rsrc(a.x0, a.x0_bytes);
         const i32x4 rs1 = make_rsrc(a.x1 ? a.x1 : a.x0, a.x1 ? a.x1_bytes : 0u);
@@ -902,7 +906,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     }
     if constexpr (STATS) {
         asm volatile("s_barrier" ::: "memory");                            // every stage has been consumed
-        float* lst = reinterpret_cast<float*>(smem);                       // [4 compute waves][2][BN]
+        float* lst = reinterpret_cast<float*>(smem);                       // [NCW compute waves][2][BN]
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -921,13 +925,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
             const int k = tid / BN, c = tid % BN;
             float t = 0.f;
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) t += lst[(w4 * 2 + k) * BN + c];
+            for (int w4 = 0; w4 < NCW; ++w4) t += lst[(w4 * 2 + k) * BN + c];
             if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * 2 + k) * a.cout + co0 + c] = t;
         }
     }
 }
 
-template <typename T, int TW, int NCT, int NPIX, int TAPS = 9>
+template <typename T, int TW, int NCT, int NPIX, int TAPS = 9, int NCW = 4>
 static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry) {
     constexpr int TH = NPIX / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
@@ -961,10 +965,10 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (lds > LDS_MAX) return RVIP_OK;
     static int attr_lds = 0;
     if (!dry && lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, false, TAPS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, false, TAPS, NCW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         if constexpr (TAPS == 9) {
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, true, TAPS>),
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, true, TAPS, NCW>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         }
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
@@ -980,22 +984,26 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (rows_out) *rows_out = gx;
     if (dry) { used = true; return RVIP_OK; }
     if (stats) {
-        if constexpr (TAPS == 9) hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, true, TAPS>), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3(512), lds, s, b);
+        if constexpr (TAPS == 9) hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, true, TAPS, NCW>), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
         else return RVIP_EUNSUPPORTED;
-    } else hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, false, TAPS>), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3(512), lds, s, b);
+    } else hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, false, TAPS, NCW>), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
     used = true;
     return check_launch();
 }
 
 template <typename T>
-static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float* stats = nullptr, int* rows_out = nullptr, bool dry = false) {
+static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float* stats = nullptr, int* rows_out = nullptr, bool dry = false,
+                             bool wide = false) {
     const bool two = a.cout > 32;
     if (a.subpix) {                     // a.h, a.w = the low-resolution grid
         if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry);
         if (a.w > 16) return two ? launch_igemm_ws<T, 32, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 256, 4>(a, s, used, stats, rows_out, dry);
         return two ? launch_igemm_ws<T, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry);
     }
-    if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, 32, 2, 512>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512>(a, s, used, stats, rows_out, dry);
+    if (a.w > 16 && a.h >= 16) {
+        if (wide) return two ? launch_igemm_ws<T, 32, 2, 512, 9, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512, 9, 8>(a, s, used, stats, rows_out, dry);
+        return two ? launch_igemm_ws<T, 32, 2, 512>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512>(a, s, used, stats, rows_out, dry);
+    }
     if (a.w > 16) return two ? launch_igemm_ws<T, 32, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 256>(a, s, used, stats, rows_out, dry);
     return two ? launch_igemm_ws<T, 16, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 16, 1, 256>(a, s, used, stats, rows_out, dry);
 }
@@ -1324,17 +1332,16 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     }
 }
 
-// Kernel generation per launch.  RVIP_IGEMM=v1|v2|v3 forces one (A/B measurements).  Default: measured per layer on
-// MI355X (profiles/r01_igemm_v2_v3.txt) - the wave-specialised v3 wins wherever a tile carries many K chunks (-6..-16 %
-// at Cin >= 256, and on the up-sampling reads), v2 (all 8 waves share the epilogue stores) wins on the store-bound
-// layers with few chunks per tile (+8..+15 % for v3 at Cin <= 64 and at Cin = 128 on 128x128 maps).
+// Kernel generation per launch.  RVIP_IGEMM=v1|v2|v3|v4 forces one (A/B measurements).  Default v4 - four loader waves plus
+// EIGHT compute waves on the 512-pixel tiling (smaller maps: v3's four) - which is within 1 % of the best of v2 / v3 / v4
+// on every layer of config 2 (profiles/r01_igemm_v2_v3_v4.txt: family total 2.18 / 2.06 / 1.98 ms per step): the loaders
+// take the DMA issue out of the MFMA waves like v3, and the epilogue stores are spread over 8 waves like v2.
 static int igemm_generation(const ConvArgs& a, bool stats = false) {
-    static const int forced = [] { const char* e = getenv("RVIP_IGEMM"); return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '3') ? e[1] - '0' : 0; }();
+    static const int forced = [] { const char* e = getenv("RVIP_IGEMM"); return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4') ? e[1] - '0' : 0; }();
+    (void)stats;
     if (a.subpix) return 3;                            // only the wave-specialised kernel has the 4-tap phase form
     if (forced) return forced;
-    if (a.cin >= 256) return 3;
-    if (stats) return 2;
-    return (a.up0 == 1 || (a.cin >= 128 && a.h <= 64)) ? 3 : 2;
+    return 4;
 }
 
 }  // namespace rvip
@@ -1385,7 +1392,8 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
     if (gen >= 2) {
         bool used = false;
         int rc;
-        if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used) : dispatch_igemm_ws<float>(a, s, used);
+        if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used, nullptr, nullptr, false, gen >= 4)
+                                                 : dispatch_igemm_ws<float>(a, s, used, nullptr, nullptr, false, gen >= 4);
         else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
         if (rc || used) return rc;
     }
@@ -1403,8 +1411,8 @@ extern "C" int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d) {
     if (gen < 2) return 0;
     bool used = false; int rows = 0;
     int rc;
-    if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, nullptr, used, nullptr, &rows, true)
-                                             : dispatch_igemm_ws<float>(a, nullptr, used, nullptr, &rows, true);
+    if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, nullptr, used, nullptr, &rows, true, gen >= 4)
+                                             : dispatch_igemm_ws<float>(a, nullptr, used, nullptr, &rows, true, gen >= 4);
     else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, nullptr, used, nullptr, &rows, true)
                                     : dispatch_igemm_dma<float>(a, nullptr, used, nullptr, &rows, true);
     return (rc == RVIP_OK && used) ? rows : 0;
@@ -1421,7 +1429,9 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
     if (stats_ws_bytes < (size_t)rows * 2 * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
     bool used = false;
     hipStream_t s = (hipStream_t)stream;
-    if (igemm_generation(a, true) >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used, stats_ws) : dispatch_igemm_ws<float>(a, s, used, stats_ws);
+    const int sgen = igemm_generation(a, true);
+    if (sgen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used, stats_ws, nullptr, false, sgen >= 4)
+                                              : dispatch_igemm_ws<float>(a, s, used, stats_ws, nullptr, false, sgen >= 4);
     else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used, stats_ws) : dispatch_igemm_dma<float>(a, s, used, stats_ws);
     if (rc) return rc;
     return used ? RVIP_OK : RVIP_EUNSUPPORTED;
