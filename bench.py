@@ -182,7 +182,7 @@ def main():
         import ctypes as C
         s = torch.cuda.current_stream()
         L = rvip._native.lib()
-        conv_fn, wgrad_fn = L.rvip_conv3x3_fwd, L.rvip_conv3x3_wgrad
+        conv_fn, conv_stats_fn, wgrad_fn = L.rvip_conv3x3_fwd, L.rvip_conv3x3_fwd_stats, L.rvip_conv3x3_wgrad
         reps = 3
         agg = {}
         detail = []
@@ -198,7 +198,7 @@ def main():
                     e1.record(s)
                     assert rc == 0
                     flops = 0.0
-                    if fn is conv_fn:
+                    if fn is conv_fn or fn is conv_stats_fn:      # the same igemm kernels; the second adds the BN partial sums
                         d = a[0]._obj
                         flops = 2.0 * d.n * d.h * d.w * 9 * max(d.kd, 1) * (d.c0 + d.c1) * d.cout
                     elif fn is wgrad_fn:
@@ -224,7 +224,7 @@ def main():
             fl = sum(f for _, _, f in evs)
             per_kernel[name] = dict(launches_per_step=len(evs) // reps, ms_per_step=round(ms / reps, 4),
                                     tflops=round(fl / (ms * 1e-3) / 1e12, 2) if (fl > 0 and ms > 0) else None)
-        cv = agg['rvip_conv3x3_fwd']
+        cv = agg['rvip_conv3x3_fwd'] + agg.get('rvip_conv3x3_fwd_stats', [])
         ms = sum(a.elapsed_time(b) for a, b, _ in cv)
         fl = sum(f for _, _, f in cv)
         achieved = fl / (ms * 1e-3) / 1e12
@@ -235,7 +235,7 @@ def main():
             traffic = round(sum(f['hbm_bytes_per_launch'] * f['launches_sampled'] for f in fam) / sum(f['launches_sampled'] for f in fam))
         except Exception:
             pass
-        roof = dict(bound='mfma', kernel='conv3x3_igemm (fwd + dgrad launches)', achieved=round(achieved, 2),
+        roof = dict(bound='mfma', kernel='conv3x3_igemm (forward incl. fused BN statistics + data-gradient launches)', achieved=round(achieved, 2),
                     peak=PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3, unit='TFLOP/s',
                     frac=round(achieved / (PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3), 4),
                     traffic=traffic, traffic_source='profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)' if traffic else None,

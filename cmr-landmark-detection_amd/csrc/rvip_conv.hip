@@ -645,6 +645,27 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
 // NCW = number of compute waves: 4 (one per SIMD, 128 pixels each at NPIX = 512) or 8 (two per SIMD, 64 pixels each: the
 // epilogue stores are spread over twice as many waves, which is what the store-bound layers with one or two K chunks per
 // tile need); the four loader waves are the same in both.
+// Sum over the 32 lanes of a half-wave of a[r], for 16 values r per lane, leaving in lane j the total of r = (j >> 1) & 15
+// (lanes j and j ^ 1 hold the same one): a butterfly that halves the number of live values at every step - lane pairs
+// 16, 8, 4, 2 apart each keep one half of the values and hand over the other - 16 ds_swizzle and 16 adds instead of the
+// 80 + 80 of sixteen separate 32-lane reductions.
+template <int M>
+__device__ __forceinline__ float swz(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (M << 10) | 0x1f));
+}
+__device__ __forceinline__ float lane_channel_sum(const float (&a)[16], int j) {
+    float b[8], c[4], d[2];
+    const bool b4 = j & 16, b3 = j & 8, b2 = j & 4, b1 = j & 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = (b4 ? a[8 + i] : a[i]) + swz<16>(b4 ? a[i] : a[8 + i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = (b3 ? b[4 + i] : b[i]) + swz<8>(b3 ? b[i] : b[4 + i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) d[i] = (b2 ? c[2 + i] : c[i]) + swz<4>(b2 ? c[i] : c[2 + i]);
+    const float e = (b1 ? d[1] : d[0]) + swz<2>(b1 ? d[0] : d[1]);
+    return e + swz<1>(e);
+}
+
 template <typename T, int TW, int NCT, int NPIX, bool STATS, int TAPS = 9, int NCW = 4>
 __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     static_assert(TAPS == 9 || TAPS == 4, "taps");
@@ -800,12 +821,12 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
         for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
-    constexpr int SN = STATS ? NCT : 1, SR = STATS ? 16 : 1;
-    float ssum[SN][SR], ssq[SN][SR];
+    // fused BatchNormalization statistics: two registers per channel tile - lane (j, hf) accumulates the sum and the sum
+    // of squares of channel r = (j >> 1) & 15 of its accumulator quad set, over the 32 pixels of the half-wave and every
+    // tile of the workgroup (lane_channel_sum below); works for NCT = 2 inside the 168 / 256 register budgets
+    float st_sum[NCT], st_sq[NCT];
 #pragma unroll
-    for (int ct = 0; ct < SN; ++ct)
-#pragma unroll
-        for (int r = 0; r < SR; ++r) ssum[ct][r] = ssq[ct][r] = 0.f;
+    for (int ct = 0; ct < NCT; ++ct) st_sum[ct] = st_sq[ct] = 0.f;
 
     int it = 0;
     for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
@@ -842,62 +863,89 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
             }
         }
         // epilogue of this tile; compute waves never wait on their stores (they issue no DMA)
-        auto epilogue = [&](auto actf) {
+        // store one (channel tile, pixel tile) of activated values: bf16 pairs are merged with v_permlane32_swap so that every
+        // lane stores 16 contiguous bytes (8 channels of one pixel)
+        auto store_tile = [&](int ct, const float (&v)[16], unsigned pix, bool pix_ok) __attribute__((always_inline)) {
+            const int cbase = co0 + ct * 32;                                   // wave-uniform
+            const bool second = a.y1 && cbase >= a.csplit;                     // csplit % 32 == 0 (host)
+            const int cstride = a.y1 ? (second ? a.cout - a.csplit : a.csplit) : a.cout;
+            const int cshift = second ? a.csplit : 0;
+            if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) {
-            const int P = wv * (NPT * 32) + pt * 32 + j;
-            const int gy = ty0 + P / TW, gx = tx0 + P % TW;
-            const bool pix_ok = gy < a.h && gx < a.w;
-            const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gy + pa) * 2 * a.w + 2 * gx + pb)
-                                           : (unsigned)((n * a.h + gy) * a.w + gx);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int cbase = co0 + ct * 32;                                   // wave-uniform
-                const bool second = a.y1 && cbase >= a.csplit;                     // csplit % 32 == 0 (host)
-                const int cstride = a.y1 ? (second ? a.cout - a.csplit : a.csplit) : a.cout;
-                const int cshift = second ? a.csplit : 0;
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float t = acc[ct][pt][r] + lbias[ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
-                    acc[ct][pt][r] = 0.f;
-                    v[r] = actf(t);
-                    if constexpr (STATS) {
-                        if (pix_ok) {
-                            const float q = Vec<T>::round(v[r]);
-                            ssum[ct][r] += q;
-                            ssq[ct][r] = fmaf(q, q, ssq[ct][r]);
-                        }
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const int co = cbase + 8 * q + 4 * hf;
+                    const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 4u : OOB;
+                    const u32x4v dta = {__builtin_bit_cast(unsigned, v[4 * q]), __builtin_bit_cast(unsigned, v[4 * q + 1]),
+                                        __builtin_bit_cast(unsigned, v[4 * q + 2]), __builtin_bit_cast(unsigned, v[4 * q + 3])};
+                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
                 }
-                if constexpr (sizeof(T) == 4) {
+            } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int co = cbase + 8 * q + 4 * hf;
-                        const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 4u : OOB;
-                        const u32x4v dta = {__builtin_bit_cast(unsigned, v[4 * q]), __builtin_bit_cast(unsigned, v[4 * q + 1]),
-                                            __builtin_bit_cast(unsigned, v[4 * q + 2]), __builtin_bit_cast(unsigned, v[4 * q + 3])};
-                        if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
+                for (int qq = 0; qq < 2; ++qq) {
+                    unsigned ax = (uint32_t)f32_to_bf16(v[8 * qq + 0]) | ((uint32_t)f32_to_bf16(v[8 * qq + 1]) << 16);
+                    unsigned ay = (uint32_t)f32_to_bf16(v[8 * qq + 2]) | ((uint32_t)f32_to_bf16(v[8 * qq + 3]) << 16);
+                    unsigned bxx = (uint32_t)f32_to_bf16(v[8 * qq + 4]) | ((uint32_t)f32_to_bf16(v[8 * qq + 5]) << 16);
+                    unsigned byy = (uint32_t)f32_to_bf16(v[8 * qq + 6]) | ((uint32_t)f32_to_bf16(v[8 * qq + 7]) << 16);
+                    auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
+                    auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
+                    const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
+                    const int co = cbase + 16 * qq + 8 * hf;
+                    const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
+                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
+                }
+            }
+        };
+        auto epilogue = [&](auto actf) {
+            if constexpr (STATS) {                   // channel tile outermost: one set of 2 x 16 temporaries at a time
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    float qs[16], qq[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) qs[r] = qq[r] = 0.f;
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) {
+                        const int P = wv * (NPT * 32) + pt * 32 + j;
+                        const int gy = ty0 + P / TW, gx = tx0 + P % TW;
+                        const bool pix_ok = gy < a.h && gx < a.w;
+                        const unsigned pix = (unsigned)((n * a.h + gy) * a.w + gx);
+                        float v[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float t = acc[ct][pt][r] + lbias[ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
+                            acc[ct][pt][r] = 0.f;
+                            v[r] = actf(t);
+                            const float q = pix_ok ? Vec<T>::round(v[r]) : 0.f;     // statistics of what is stored
+                            qs[r] += q;
+                            qq[r] = fmaf(q, q, qq[r]);
+                        }
+                        store_tile(ct, v, pix, pix_ok);
                     }
-                } else {
+                    st_sum[ct] += lane_channel_sum(qs, j);
+                    st_sq[ct] += lane_channel_sum(qq, j);
+                }
+            } else {
 #pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        unsigned ax = (uint32_t)f32_to_bf16(v[8 * qq + 0]) | ((uint32_t)f32_to_bf16(v[8 * qq + 1]) << 16);
-                        unsigned ay = (uint32_t)f32_to_bf16(v[8 * qq + 2]) | ((uint32_t)f32_to_bf16(v[8 * qq + 3]) << 16);
-                        unsigned bxx = (uint32_t)f32_to_bf16(v[8 * qq + 4]) | ((uint32_t)f32_to_bf16(v[8 * qq + 5]) << 16);
-                        unsigned byy = (uint32_t)f32_to_bf16(v[8 * qq + 6]) | ((uint32_t)f32_to_bf16(v[8 * qq + 7]) << 16);
-                        auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
-                        auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
-                        const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
-                        const int co = cbase + 16 * qq + 8 * hf;
-                        const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
-                        if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
+                for (int pt = 0; pt < NPT; ++pt) {
+                    const int P = wv * (NPT * 32) + pt * 32 + j;
+                    const int gy = ty0 + P / TW, gx = tx0 + P % TW;
+                    const bool pix_ok = gy < a.h && gx < a.w;
+                    const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gy + pa) * 2 * a.w + 2 * gx + pb)
+                                                   : (unsigned)((n * a.h + gy) * a.w + gx);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        float v[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float t = acc[ct][pt][r] + lbias[ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
+                            acc[ct][pt][r] = 0.f;
+                            v[r] = actf(t);
+                        }
+                        store_tile(ct, v, pix, pix_ok);
                     }
                 }
             }
-        }
         };
         if (a.down2) epilogue_down2<T, TW, NCT, NPT>(acc, wv * (NPT * 32), j, hf, n, ty0, tx0, co0, a, ry);
         else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
@@ -907,19 +955,15 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
     if constexpr (STATS) {
         asm volatile("s_barrier" ::: "memory");                            // every stage has been consumed
         float* lst = reinterpret_cast<float*>(smem);                       // [NCW compute waves][2][BN]
+        if (!(j & 1)) {                                                    // lanes j and j ^ 1 hold the same channel
+            const int r = (j >> 1) & 15;
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s1 = ssum[ct][r], s2 = ssq[ct][r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-                if (j == 0) {
-                    const int c = ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
-                    lst[(wv * 2 + 0) * BN + c] = s1;
-                    lst[(wv * 2 + 1) * BN + c] = s2;
-                }
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int c = ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
+                lst[(wv * 2 + 0) * BN + c] = st_sum[ct];
+                lst[(wv * 2 + 1) * BN + c] = st_sq[ct];
             }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid < 2 * BN) {
             const int k = tid / BN, c = tid % BN;
@@ -1406,9 +1450,9 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
 extern "C" int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d) {
     ConvArgs a;
     if (conv_args_from_desc(d, a) != RVIP_OK || d->y1) return 0;
-    if (d->cout > 32) return 0;      // the 64-channel tile variant would exceed 256 VGPRs with the per-lane accumulators
     const int gen = igemm_generation(a, true);
     if (gen < 2) return 0;
+    if (gen == 2 && d->cout > 32) return 0;      // v2's per-lane accumulators exceed 256 VGPRs at the 64-channel tile
     bool used = false; int rows = 0;
     int rc;
     if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, nullptr, used, nullptr, &rows, true, gen >= 4)

@@ -214,7 +214,8 @@ def test_conv3d_first_layer(dtype):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-@pytest.mark.parametrize('shape', [(2, 40, 72, 32, 32), (3, 16, 16, 32, 24), (2, 24, 40, 8, 8)])
+@pytest.mark.parametrize('shape', [(2, 40, 72, 32, 32), (3, 16, 16, 32, 24), (2, 24, 40, 8, 8),
+                                   (2, 40, 72, 32, 64), (1, 16, 16, 64, 72), (2, 8, 40, 16, 128), (1, 32, 32, 256, 96)])   # two channel tiles per workgroup
 def test_conv3x3_fused_batchnorm_statistics(shape, dtype):
     """conv + bias + ReLU with the BatchNormalization statistics of the STORED output folded into the epilogue, then
     rvip_bn_stats_finalize: same mean / invstd / moving statistics as the two-pass kernels and the oracle."""
