@@ -15,7 +15,7 @@ from collections import defaultdict
 
 FAMILIES = [  # (family key, regex on the demangled kernel name)
     ('conv3x3_igemm_ws', r'conv3x3_igemm_ws<'), ('conv3x3_igemm_dma', r'conv3x3_igemm_dma<'), ('conv3x3_igemm_v1', r'conv3x3_igemm<'),
-    ('wgrad3x3_dma', r'wgrad3x3_dma<'), ('wgrad_fold', r'wgrad_fold_kernel'), ('pack_all', r'pack_all_kernel'),
+    ('wgrad3x3_ws', r'wgrad3x3_ws<'), ('wgrad3x3_dma', r'wgrad3x3_dma<'), ('wgrad_fold', r'wgrad_fold_kernel'), ('fold_batch', r'fold_batch_'), ('pack_all', r'pack_all_kernel'),
     ('conv3x3_c1', r'conv3x3_c1|conv3d_c1'), ('c1_wgrad', r'c1_wgrad'), ('bn_stats', r'bn_stats_kernel'), ('bn_apply', r'bn_apply_kernel'),
     ('bn_bwd_reduce', r'bn_bwd_reduce_kernel'), ('bn_bwd_apply', r'bn_bwd_apply_kernel'), ('maxpool_bwd', r'maxpool_bwd_kernel'),
     ('upsample', r'upsample_kernel'), ('head_fwd', r'head_fwd'), ('head_bwd', r'head_bwd_kernel'), ('adam', r'adam_kernel'),
