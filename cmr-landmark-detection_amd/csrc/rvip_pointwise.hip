@@ -1031,7 +1031,8 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     const long long ngroups = cdiv(units, rpi);
     const int unr = d->pooled ? 2 : 4;
     long long nb = cdiv(ngroups, unr);
-    if (nb > 4096) nb = 4096;
+    static const long long nb_cap = [] { const char* e = getenv("RVIP_APPLY_BLOCKS"); return e ? atoll(e) : 1024LL; }();     // one resident round of workgroups: 7-10 % faster than 4096 (tools/probe_apply.py)
+    if (nb > nb_cap) nb = nb_cap;
     dim3 grid((unsigned)nb);
     if (d->pooled) {
         if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
