@@ -813,6 +813,201 @@ struct PostHeadBwd {                   // ws columns: [2*MAXK][cin]: rows 0..MAX
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Last stage fused with the 1x1 sigmoid head (Unets.py:128): the stage's BN output y is consumed by nothing else, so
+//   forward : pred = sigmoid(W_h^T y + b_h) with y = act(scale*z + shift) built in registers   (no y tensor)
+//   backward: the gradient reaching y is g[p][c] = sum_k W_h[c][k] * dlogit[p][k], rebuilt in both BN-backward stages
+//             (no gy tensor); dW_h[c][k] = sum_p y[p][c] * dlogit[p][k] and db_h ride along in the reduce stage.
+// Thread = (channel vector cgi, pixel slot prow); the cg = C / VE lanes of a pixel are adjacent (cg a power of two).
+// ------------------------------------------------------------------------------------------------
+struct HeadFuse { const float* w; const float* b; const float* dlogit; int k; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFuse hd, float* __restrict__ pred, const float* __restrict__ yt,
+                                                            long long rows, long long chunk, int reduce, float* __restrict__ ws) {
+    constexpr int VE = Vec<T>::VE, U = 2;
+    __shared__ float red[4][16];
+    const int tid = threadIdx.x, k = hd.k;
+    const int cg = a.c / VE, rpi = 256 / cg, cgi = tid % cg, prow = tid / cg;
+    const long long r0 = blockIdx.x * chunk, r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
+    float sc[VE], sh[VE], wr[VE][RVIP_MAXK], bias[RVIP_MAXK];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        sc[e] = a.scale ? a.scale[cgi * VE + e] : 1.f; sh[e] = a.shift ? a.shift[cgi * VE + e] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < RVIP_MAXK; ++kk) wr[e][kk] = kk < k ? hd.w[(cgi * VE + e) * k + kk] : 0.f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < RVIP_MAXK; ++kk) bias[kk] = (kk < k && hd.b) ? hd.b[kk] : 0.f;
+    float s[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) s[i] = 0.f;
+    for (long long rb = r0 + prow; rb < r1; rb += (long long)U * rpi) {
+        float v[U][VE];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = rb + (long long)u * rpi;
+            if (r < r1) Vec<T>::load(a.z + ((size_t)r * a.c + cgi * VE) * sizeof(T), v[u]);
+            else {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) v[u][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = rb + (long long)u * rpi;
+            float lg[RVIP_MAXK];
+#pragma unroll
+            for (int kk = 0; kk < RVIP_MAXK; ++kk) lg[kk] = 0.f;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float y = Vec<T>::round(act_fwd(fmaf(v[u][e], sc[e], sh[e]), a.act));   // what rvip_bn_apply would have stored
+#pragma unroll
+                for (int kk = 0; kk < RVIP_MAXK; ++kk) lg[kk] = fmaf(y, wr[e][kk], lg[kk]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < RVIP_MAXK; ++kk) {
+                for (int o = cg >> 1; o > 0; o >>= 1) lg[kk] += __shfl_xor(lg[kk], o);
+                lg[kk] += bias[kk];
+            }
+            if (r >= r1) continue;
+            for (int kk = cgi; kk < k; kk += cg) {
+                float zl = lg[0];
+#pragma unroll
+                for (int q = 1; q < RVIP_MAXK; ++q) zl = (kk == q) ? lg[q] : zl;
+                const float e_ = __expf(-fabsf(zl));
+                const float inv = __frcp_rn(1.f + e_);
+                const float pv = (zl >= 0.f ? 1.f : e_) * inv;
+                pred[(size_t)r * k + kk] = pv;
+                if (yt) {
+                    const float t = yt[(size_t)r * k + kk];
+                    const float d = pv - t;
+                    s[0] = fmaf(d, d, s[0]);
+                    s[1] += fmaxf(zl, 0.f) - zl * t + __logf(1.f + e_);
+                    s[2] = fmaf(t, pv, s[2]); s[3] += t; s[4] += pv;
+                    if (kk == k - 2) { s[5] = fmaf(t, pv, s[5]); s[6] += t; s[7] += pv; }
+                    if (kk == k - 1) { s[8] = fmaf(t, pv, s[8]); s[9] += t; s[10] += pv; }
+                }
+            }
+        }
+    }
+    if (!reduce) return;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) s[i] = wave_sum(s[i]);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) red[wv][i] = s[i];
+    }
+    __syncthreads();
+    if (tid < 16) ws[(size_t)blockIdx.x * 16 + tid] = tid < 11 ? red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] : 0.f;
+}
+
+// incoming gradient of pixel r for this thread's channels, from the head's logit gradient
+template <typename T, int VE>
+__device__ __forceinline__ void head_grad_vec(const HeadFuse& hd, long long r, const float (&wr)[VE][RVIP_MAXK], float (&d)[RVIP_MAXK], float (&g)[VE]) {
+#pragma unroll
+    for (int kk = 0; kk < RVIP_MAXK; ++kk) d[kk] = kk < hd.k ? hd.dlogit[(size_t)r * hd.k + kk] : 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        float acc = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < RVIP_MAXK; ++kk) acc = fmaf(d[kk], wr[e][kk], acc);
+        g[e] = Vec<T>::round(acc);                                // the gy tensor the unfused path stores in the activation dtype
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(BnBwdArgs a, HeadFuse hd, RedGeom gm, float* __restrict__ ws_bn, float* __restrict__ ws_hd) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float lds[256 * VE];
+    const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
+    const bool active = prow < gm.rpi;
+    const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
+    float part[2][VE], hpart[2 * RVIP_MAXK][VE], mu[VE], is[VE], sc[VE], sh[VE], wr[VE][RVIP_MAXK];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        part[0][e] = part[1][e] = 0.f;
+        const int ch = cgi * VE + e;
+        mu[e] = active ? a.mean[ch] : 0.f; is[e] = active ? a.invstd[ch] : 0.f;
+        sc[e] = (active && a.scale) ? a.scale[ch] : 1.f; sh[e] = (active && a.shift) ? a.shift[ch] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < RVIP_MAXK; ++kk) wr[e][kk] = (active && kk < hd.k) ? hd.w[ch * hd.k + kk] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 2 * RVIP_MAXK; ++q) hpart[q][e] = 0.f;
+    }
+    if (active) {
+        for (long long r = r0 + prow; r < r1; r += gm.rpi) {
+            float z[VE], g[VE], d[RVIP_MAXK];
+            const size_t e0 = (size_t)r * a.c + cgi * VE;
+            Vec<T>::load(a.z + e0 * sizeof(T), z);
+            head_grad_vec<T, VE>(hd, r, wr, d, g);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float y = Vec<T>::round(act_fwd(fmaf(z[e], sc[e], sh[e]), a.act_after_bn ? a.act : RVIP_ACT_NONE));
+#pragma unroll
+                for (int kk = 0; kk < RVIP_MAXK; ++kk) hpart[kk][e] = fmaf(y, d[kk], hpart[kk][e]);     // dW_h
+            }
+            if (cgi == 0) {
+#pragma unroll
+                for (int kk = 0; kk < RVIP_MAXK; ++kk) hpart[RVIP_MAXK + kk][0] += d[kk];               // db_h
+            }
+            xform_g<T, VE>(a, e0, cgi * VE, 0u, z, g);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { part[0][e] += g[e]; part[1][e] = fmaf(g[e], (z[e] - mu[e]) * is[e], part[1][e]); }
+        }
+    }
+    block_fold<2, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws_bn + (size_t)blockIdx.x * 2 * a.c);
+    block_fold<2 * RVIP_MAXK, VE>(hpart, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws_hd + (size_t)blockIdx.x * 2 * RVIP_MAXK * a.c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(BnBwdArgs a, HeadFuse hd, RedGeom gm, float* __restrict__ ws) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float lds[256 * VE];
+    const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
+    const bool active = prow < gm.rpi;
+    const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
+    float part[1][VE], c1[VE], c2[VE], c3[VE], wr[VE][RVIP_MAXK];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        part[0][e] = 0.f;
+        const int ch = cgi * VE + e;
+        c1[e] = (a.has_bn && active) ? a.coef[ch] : 1.f;
+        c2[e] = (a.has_bn && active) ? a.coef[a.c + ch] : 0.f;
+        c3[e] = (a.has_bn && active) ? a.coef[2 * a.c + ch] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < RVIP_MAXK; ++kk) wr[e][kk] = (active && kk < hd.k) ? hd.w[ch * hd.k + kk] : 0.f;
+    }
+    if (active) {
+        for (long long r = r0 + prow; r < r1; r += 2 * gm.rpi) {
+            float z[2][VE], g[2][VE], d[RVIP_MAXK]; size_t e0[2]; bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long long rr = r + u * gm.rpi;
+                ok[u] = rr < r1;
+                e0[u] = (size_t)rr * a.c + cgi * VE;
+                if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); head_grad_vec<T, VE>(hd, rr, wr, d, g[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!ok[u]) continue;
+                xform_g<T, VE>(a, e0[u], cgi * VE, 0u, z[u], g[u]);
+                float dd[VE];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    float t = fmaf(c1[e], g[u][e], fmaf(c2[e], z[u][e], c3[e]));
+                    if (!a.act_after_bn) t *= act_bwd(z[u][e], a.act);
+                    dd[e] = t;
+                    part[0][e] += Vec<T>::round(t);
+                }
+                Vec<T>::store(a.dz + e0[u] * sizeof(T), dd);
+            }
+        }
+    }
+    block_fold<1, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws + (size_t)blockIdx.x * a.c);
+}
+
 // first layer (Cin = 1) weight gradient: dw[t][co] = sum_p x[p + off(t)] * dy[p][co]
 template <typename T>
 __global__ __launch_bounds__(256) void c1_wgrad_kernel(const T* __restrict__ x, const unsigned char* __restrict__ dy,
@@ -1195,6 +1390,95 @@ extern "C" int rvip_head_fwd(const void* x, const float* w, const float* b, floa
     if (rc || !y_true) return rc;
     PostHeadSums p{sums};
     return launch_fold<1, PostHeadSums>(ws, (int)nb, 16, p, s);
+}
+
+// Last stage + head, forward (see bn_apply_head_kernel).  d->y / d->pooled are ignored; no dropout on this stage.
+extern "C" int rvip_bn_apply_head(const rvip_apply_desc* d, const float* head_w, const float* head_b, int k, float* pred,
+                                  const float* y_true, float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!d || !d->z || !head_w || !pred || !RVIP_DT_OK(d->dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
+    const int ve = RVIP_VE(d->dtype);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->c % ve || d->drop_rate > 0.f) return RVIP_EINVAL;
+    const int cg = d->c / ve;
+    if (cg > 64 || (cg & (cg - 1))) return RVIP_EUNSUPPORTED;
+    if (y_true && (!sums || !workspace)) return RVIP_EINVAL;
+    ApplyArgs a;
+    a.z = (const unsigned char*)d->z; a.y = nullptr; a.pooled = nullptr;
+    a.scale = d->scale; a.shift = d->shift; a.act = d->act;
+    a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;
+    a.n = d->n; a.h = d->h; a.w = d->w; a.c = d->c;
+    const long long rows = (long long)d->n * d->h * d->w;
+    long long nb = cdiv(rows, 256 * 4);
+    if (nb > 1024) nb = 1024;
+    const long long chunk = cdiv(rows, nb);
+    nb = cdiv(rows, chunk);
+    if (y_true && workspace_bytes < (size_t)nb * 16 * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = y_true ? (float*)workspace : nullptr;
+    HeadFuse hd{head_w, head_b, nullptr, k};
+    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_apply_head_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
+    else hipLaunchKernelGGL(bn_apply_head_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
+    int rc = check_launch();
+    if (rc || !y_true) return rc;
+    PostHeadSums p{sums};
+    return launch_fold<1, PostHeadSums>(ws, (int)nb, 16, p, s);
+}
+
+// Last stage + head, backward stage 1 and 2 (d->dy is ignored: the incoming gradient is rebuilt from dlogit).
+// Stage 1 also writes the head's weight / bias gradients.  workspace: rvip_reduce_workspace(rows, 16 * c) bytes.
+extern "C" int rvip_bn_bwd_reduce_head(const rvip_bnbwd_desc* d, const float* head_w, const float* dlogit, int k,
+                                       float* head_dw, float* head_db, void* stream) {
+    (void)hipGetLastError();
+    if (!d || !d->z || !head_w || !dlogit || !head_dw || !head_db || !RVIP_DT_OK(d->dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
+    if (!d->gamma || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->coef || !d->workspace || d->drop_rate > 0.f) return RVIP_EINVAL;
+    RedGeom g;
+    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g)) return RVIP_EINVAL;
+    const size_t need = (size_t)g.nblk * (2 + 2 * RVIP_MAXK) * d->c * sizeof(float);
+    if (d->workspace_bytes < need) return RVIP_EWORKSPACE;
+    BnBwdArgs a;
+    a.dy = nullptr; a.z = (const unsigned char*)d->z; a.dz = (unsigned char*)d->dz;
+    a.mean = d->mean; a.invstd = d->invstd; a.scale = d->scale; a.shift = d->shift; a.coef = d->coef;
+    a.act = d->act; a.act_after_bn = d->act_after_bn; a.has_bn = 1;
+    a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;
+    a.rows = d->rows; a.c = d->c; a.pool_dp = nullptr; a.pool_add = nullptr; a.ph = a.pw = 0;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws_bn = (float*)d->workspace;
+    float* ws_hd = ws_bn + (size_t)g.nblk * 2 * d->c;
+    HeadFuse hd{head_w, nullptr, dlogit, k};
+    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_bwd_reduce_head_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
+    else hipLaunchKernelGGL(bn_bwd_reduce_head_kernel<float>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
+    int rc = check_launch();
+    if (rc) return rc;
+    PostBnBwd p{d->gamma, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef, (double)d->rows, d->c};
+    rc = launch_fold<2, PostBnBwd>(ws_bn, g.nblk, d->c, p, s);
+    if (rc) return rc;
+    PostHeadBwd ph{head_dw, head_db, d->c, k};
+    return launch_fold_k<PostHeadBwd>(ws_hd, g.nblk, d->c, 2 * RVIP_MAXK, ph, s);
+}
+
+extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* head_w, const float* dlogit, int k, void* stream) {
+    (void)hipGetLastError();
+    if (!d || !d->z || !d->dz || !head_w || !dlogit || !RVIP_DT_OK(d->dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
+    if ((!d->dbias && !d->bias_rows) || (d->gamma && !d->coef) || d->drop_rate > 0.f) return RVIP_EINVAL;
+    RedGeom g;
+    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g)) return RVIP_EINVAL;
+    const bool defer = d->bias_rows != nullptr;
+    if ((defer ? d->bias_rows_bytes : d->workspace_bytes) < (size_t)g.nblk * d->c * sizeof(float) || (!defer && !d->workspace)) return RVIP_EWORKSPACE;
+    BnBwdArgs a;
+    a.dy = nullptr; a.z = (const unsigned char*)d->z; a.dz = (unsigned char*)d->dz;
+    a.mean = d->mean; a.invstd = d->invstd; a.scale = d->scale; a.shift = d->shift; a.coef = d->coef;
+    a.act = d->act; a.act_after_bn = d->act_after_bn; a.has_bn = d->gamma != nullptr;
+    a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;
+    a.rows = d->rows; a.c = d->c; a.pool_dp = nullptr; a.pool_add = nullptr; a.ph = a.pw = 0;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = defer ? d->bias_rows : (float*)d->workspace;
+    HeadFuse hd{head_w, nullptr, dlogit, k};
+    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_bwd_apply_head_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
+    else hipLaunchKernelGGL(bn_bwd_apply_head_kernel<float>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
+    int rc = check_launch();
+    if (rc || defer) return rc;
+    PostSum p{d->dbias};
+    return launch_fold<1, PostSum>(ws, g.nblk, d->c, p, s);
 }
 
 extern "C" int rvip_head_grad(const float* pred, const float* y_true, const float* sums, float* dlogit, float* loss_out,

@@ -320,6 +320,14 @@ class Engine:
         esz = 2 if dt == N.BF16 else 4
         unbiased = 1 if self.kd == 1 else 0     # TF 2.3: fused 4-D BN feeds the unbiased variance to the moving average, 5-D does not
 
+        # The last conv stage's BN output feeds only the 1x1 head: in training it is never materialised (rvip_bn_apply_head,
+        # rvip_bn_bwd_*_head rebuild it / its gradient in registers).  Inference keeps the separate launches.
+        last = plan.stages[-1]
+        ve_ = 8 if dt == N.BF16 else 4
+        cg_ = last.cout // ve_
+        self.fuse_head = bool(last.bn and not last.pool and not (last.drop and last.drop[1] > 0) and last.y == plan.head['src']
+                              and cg_ <= 64 and (cg_ & (cg_ - 1)) == 0 and os.environ.get('RVIP_FUSE_HEAD', '1') != '0')
+        last_apply = None
         for st in plan.stages:
             rows = n * st.h * st.w
             z, y = self.act[st.z], self.act[st.y]
@@ -387,15 +395,22 @@ class Engine:
                             a.mask = self.masks[st.drop[0]].data_ptr()
                     a.n, a.h, a.w, a.c, a.dtype = n, st.h, st.w, st.cout, dt
                     self._keep.append(a)
-                    (fwd_t if training else fwd_i).append((L.rvip_bn_apply, (C.byref(a),)))
+                    if training and st is last and self.fuse_head:
+                        last_apply = a                      # consumed by rvip_bn_apply_head below
+                    else:
+                        (fwd_t if training else fwd_i).append((L.rvip_bn_apply, (C.byref(a),)))
 
         hd = plan.head
         fwd_t.label = fwd_i.label = bwd.label = 'head'
         hrows = C.c_longlong(n * hd['h'] * hd['w'])
         hx = self.act[hd['src']]
         hw_, hb_ = P.p(hd['conv'], 'kernel'), P.p(hd['conv'], 'bias')
-        fwd_t.append((L.rvip_head_fwd, (_ptr(hx), hw_, hb_, _ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), hrows,
-                                        hd['cin'], hd['k'], dt, ws, wsb)))
+        if self.fuse_head:
+            fwd_t.append((L.rvip_bn_apply_head, (C.byref(last_apply), hw_, hb_, hd['k'], _ptr(self.pred), _ptr(self.y_true),
+                                                 _ptr(self.sums), ws, wsb)))
+        else:
+            fwd_t.append((L.rvip_head_fwd, (_ptr(hx), hw_, hb_, _ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), hrows,
+                                            hd['cin'], hd['k'], dt, ws, wsb)))
         fwd_i.append((L.rvip_head_fwd, (_ptr(hx), hw_, hb_, _ptr(self.pred), None, None, hrows, hd['cin'], hd['k'], dt,
                                         None, C.c_size_t(0))))
         self.fwd_eval = list(fwd_i[:-1]) + [fwd_t[-1]]          # inference-mode network + loss sums (validation)
@@ -406,8 +421,9 @@ class Engine:
         bwd.append((L.rvip_head_grad, (_ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), _ptr(self.dlogit), _ptr(self.loss),
                                        hrows, hd['k'], self.loss_kind, C.c_float(self._inv_count), C.c_float(1.0 / self.world),
                                        C.c_float(self.w_bce), C.c_float(self.w_dice))))
-        bwd.append((L.rvip_head_bwd, (_ptr(hx), hw_, _ptr(self.dlogit), _ptr(self.grd[hd['src']]), P.g(hd['conv'], 'kernel'),
-                                      P.g(hd['conv'], 'bias'), hrows, hd['cin'], hd['k'], dt, ws, wsb)))
+        if not self.fuse_head:
+            bwd.append((L.rvip_head_bwd, (_ptr(hx), hw_, _ptr(self.dlogit), _ptr(self.grd[hd['src']]), P.g(hd['conv'], 'kernel'),
+                                          P.g(hd['conv'], 'bias'), hrows, hd['cin'], hd['k'], dt, ws, wsb)))
         # Gradient buckets for the data-parallel all-reduce: the backward pass finishes head, decoder and bottleneck
         # first; their gradients are the tail of the flat block (creation order) and can travel while the encoder's
         # backward still runs.  bwd[:bwd_split] produces grad[grad_split:], bwd[bwd_split:] produces grad[:grad_split].
@@ -480,9 +496,15 @@ class Engine:
                 b.bias_rows, b.bias_rows_bytes = rbuf.data_ptr(), rbuf.numel() * 4
                 narrow.append((rbuf, P.g(st.conv, 'bias'), nr, st.cout))
             self._keep.append(b)
-            if st.bn:
-                bwd.append((L.rvip_bn_bwd_reduce, (C.byref(b),)))
-            bwd.append((L.rvip_bn_bwd_apply, (C.byref(b),)))
+            if st is last and self.fuse_head:
+                b.dy = None
+                bwd.append((L.rvip_bn_bwd_reduce_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'], P.g(hd['conv'], 'kernel'),
+                                                        P.g(hd['conv'], 'bias'))))
+                bwd.append((L.rvip_bn_bwd_apply_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'])))
+            else:
+                if st.bn:
+                    bwd.append((L.rvip_bn_bwd_reduce, (C.byref(b),)))
+                bwd.append((L.rvip_bn_bwd_apply, (C.byref(b),)))
             if first and self.kd == 3:
                 bwd.append((L.rvip_conv3d_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, self.depth,
                                                      st.h, st.w, st.cout, dt, _ptr(self.ws_wg), C.c_size_t(self.ws_wg_bytes))))

@@ -284,6 +284,20 @@ int rvip_head_bwd(const void* x, const float* w, const float* dlogit, void* dx, 
                   long long rows, int cin, int k, int dtype,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The LAST conv stage fused with the 1x1 sigmoid head (Unets.py:128): nothing but the head reads that stage's BN output
+ * y = act(scale*z + shift), so it is built in registers instead of being stored and read back three times.
+ *   rvip_bn_apply_head      = rvip_bn_apply (no dropout, no pool; d->y ignored) + rvip_head_fwd in one pass over z
+ *   rvip_bn_bwd_reduce_head = rvip_head_bwd's weight / bias gradients + rvip_bn_bwd_reduce, the gradient reaching y being
+ *                             rebuilt per pixel as sum_k head_w[c][k] * dlogit[p][k] (d->dy ignored);
+ *                             workspace: rvip_reduce_workspace(rows, 16 * c) bytes
+ *   rvip_bn_bwd_apply_head  = rvip_bn_bwd_apply on the same rebuilt gradient (d->dy ignored).
+ * C / VE must be a power of two <= 64 (RVIP_EUNSUPPORTED otherwise: use the separate entry points). */
+int rvip_bn_apply_head(const rvip_apply_desc* d, const float* head_w, const float* head_b, int k, float* pred,
+                       const float* y_true, float* sums, void* workspace, size_t workspace_bytes, void* stream);
+int rvip_bn_bwd_reduce_head(const rvip_bnbwd_desc* d, const float* head_w, const float* dlogit, int k,
+                            float* head_dw, float* head_db, void* stream);
+int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* head_w, const float* dlogit, int k, void* stream);
+
 /* Per-(slice, class) argmax of the heat-map, row-major first-max (north_star landmark index), and the
  * >0.5 label mask of predict_model.py:149-156.  idx_out[n][k] int64; mask_out uint8 [rows][K] or NULL. */
 int rvip_landmarks(const float* pred, long long* idx_out, uint8_t* mask_out, int n, int hw, int k, float thr,

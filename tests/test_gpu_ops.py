@@ -707,3 +707,82 @@ def test_postprocess_flat_labels_cc_filter_and_points(cc):
     assert np.array_equal(np.isnan(got), np.isnan(rp)) and np.isnan(rp[2, 1]).all() and np.isnan(rp[4, 0]).all()
     np.testing.assert_allclose(got[~np.isnan(rp)], rp[~np.isnan(rp)], rtol=1e-6)
     np.testing.assert_array_equal(sizes.cpu().numpy(), np.stack([(ref == v + 1).sum((1, 2)) for v in range(k)], 1))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('act_after', [0, 1])
+def test_last_stage_fused_with_head_matches_the_separate_kernels(dtype, act_after):
+    """rvip_bn_apply_head / rvip_bn_bwd_reduce_head / rvip_bn_bwd_apply_head (the stage's BN output and its gradient
+    live in registers only) against rvip_bn_apply + rvip_head_fwd and rvip_head_bwd + rvip_bn_bwd_reduce/apply."""
+    n, h, w, c, k = 3, 12, 20, 16, 2
+    rows = n * h * w
+    rng = np.random.default_rng(11)
+    pre = rng.standard_normal((n, h, w, c)) * 1.5 + 0.2
+    z = rnd(pre if act_after else np.maximum(pre, 0), dtype)
+    gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    hw = (rng.standard_normal((c, k)) * 0.3).astype(np.float32)
+    hb = (rng.standard_normal(k) * 0.1).astype(np.float32)
+    _, yt = O.synthetic_batch(n, (h, w), k, seed=3)
+    L = N.lib()
+    wsb = L.rvip_reduce_workspace(rows, 16 * c)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    zd, gd, bd, hwd, hbd, ytd = up(z, dtype), f32(gamma), f32(beta), f32(hw), f32(hb), f32(yt)
+    mm, mv = f32(np.zeros(c)), f32(np.ones(c))
+    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(4))
+    N.call('rvip_bn_train_stats', P(zd), C.c_longlong(rows), c, ndt(dtype), P(gd), P(bd), P(mm), P(mv), 0.99, 1e-3, 1,
+           P(mean), P(invstd), P(scale), P(shift), P(ws), C.c_size_t(wsb), stream())
+    state = torch.zeros(8, dtype=torch.int32, device=dev())
+    y = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
+    a = N.ApplyDesc()
+    a.z, a.y, a.pooled = zd.data_ptr(), y.data_ptr(), None
+    a.scale, a.shift, a.act = scale.data_ptr(), shift.data_ptr(), (N.ACT['relu'] if act_after else 0)
+    a.drop_rate, a.mask, a.state, a.layer_id = 0.0, None, state.data_ptr(), 0
+    a.n, a.h, a.w, a.c, a.dtype = n, h, w, c, ndt(dtype)
+    # separate kernels
+    N.call('rvip_bn_apply', C.byref(a), stream())
+    pred0 = torch.empty((n, h, w, k), dtype=torch.float32, device=dev())
+    sums0 = torch.zeros(16, dtype=torch.float32, device=dev())
+    N.call('rvip_head_fwd', P(y), P(hwd), P(hbd), P(pred0), P(ytd), P(sums0), C.c_longlong(rows), c, k, ndt(dtype), P(ws), C.c_size_t(wsb), stream())
+    dl = (rng.standard_normal((n, h, w, k)) * 1e-3).astype(np.float32)
+    dld = f32(dl)
+    gy = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
+    hdw0, hdb0 = torch.empty((c, k), dtype=torch.float32, device=dev()), torch.empty(k, dtype=torch.float32, device=dev())
+    N.call('rvip_head_bwd', P(y), P(hwd), P(dld), P(gy), P(hdw0), P(hdb0), C.c_longlong(rows), c, k, ndt(dtype), P(ws), C.c_size_t(wsb), stream())
+
+    def bwd_desc(dz, dgamma, dbeta, dbias, coef, dy):
+        b = N.BnBwdDesc()
+        b.dy, b.z, b.dz = (dy.data_ptr() if dy is not None else None), zd.data_ptr(), dz.data_ptr()
+        b.gamma, b.mean, b.invstd = gd.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+        b.scale, b.shift = scale.data_ptr(), shift.data_ptr()
+        b.dgamma, b.dbeta, b.dbias, b.coef = dgamma.data_ptr(), dbeta.data_ptr(), dbias.data_ptr(), coef.data_ptr()
+        b.act, b.act_after_bn = N.ACT['relu'], act_after
+        b.drop_rate, b.mask, b.state, b.layer_id = 0.0, None, state.data_ptr(), 0
+        b.rows, b.c, b.dtype = rows, c, ndt(dtype)
+        b.workspace, b.workspace_bytes = ws.data_ptr(), wsb
+        return b
+    out0 = [torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())] + [torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(3)] + \
+           [torch.empty(3 * c, dtype=torch.float32, device=dev())]
+    b0 = bwd_desc(*out0, gy)
+    N.call('rvip_bn_bwd_reduce', C.byref(b0), stream())
+    N.call('rvip_bn_bwd_apply', C.byref(b0), stream())
+    # fused
+    pred1 = torch.empty_like(pred0)
+    sums1 = torch.zeros(16, dtype=torch.float32, device=dev())
+    a.y = None
+    N.call('rvip_bn_apply_head', C.byref(a), P(hwd), P(hbd), k, P(pred1), P(ytd), P(sums1), P(ws), C.c_size_t(wsb), stream())
+    out1 = [torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())] + [torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(3)] + \
+           [torch.empty(3 * c, dtype=torch.float32, device=dev())]
+    hdw1, hdb1 = torch.empty_like(hdw0), torch.empty_like(hdb0)
+    b1 = bwd_desc(*out1, None)
+    N.call('rvip_bn_bwd_reduce_head', C.byref(b1), P(hwd), P(dld), k, P(hdw1), P(hdb1), stream())
+    N.call('rvip_bn_bwd_apply_head', C.byref(b1), P(hwd), P(dld), k, stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(down(pred1), down(pred0), atol=2e-6)
+    np.testing.assert_allclose(down(sums1)[:11], down(sums0)[:11], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(down(hdw1), down(hdw0), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(down(hdb1), down(hdb0), rtol=1e-4, atol=1e-7)
+    for t1, t0, nm in zip(out1[1:], out0[1:], ('dgamma', 'dbeta', 'dbias', 'coef')):
+        sc_ = float(np.abs(down(t0)).max())
+        np.testing.assert_allclose(down(t1), down(t0), atol=(2e-3 if dtype == 'bf16' else 1e-5) * sc_ + 1e-9, err_msg=nm)
+    close(down(out1[0]), down(out0[0]).astype(np.float64), dtype, 'dz fused vs separate')
