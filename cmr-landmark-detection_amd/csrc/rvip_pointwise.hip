@@ -388,6 +388,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
 // ------------------------------------------------------------------------------------------------
 // backward of conv -> [act] -> BN -> [act] -> dropout
 // ------------------------------------------------------------------------------------------------
+#ifndef RVIP_BWD_U
+#define RVIP_BWD_U 2             // rows in flight per thread in the BN-backward passes
+#endif
 struct BnBwdArgs {
     const unsigned char* dy; const unsigned char* z; unsigned char* dz;
     const float* mean; const float* invstd; const float* scale; const float* shift; const float* coef;
@@ -484,17 +487,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom
             }
         }
     } else if (active) {
-        for (long long r = r0 + prow; r < r1; r += 2 * gm.rpi) {
-            float z[2][VE], g[2][VE]; size_t e0[2]; bool ok[2];
+        for (long long r = r0 + prow; r < r1; r += RVIP_BWD_U * gm.rpi) {
+            float z[RVIP_BWD_U][VE], g[RVIP_BWD_U][VE]; size_t e0[RVIP_BWD_U]; bool ok[RVIP_BWD_U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < RVIP_BWD_U; ++u) {
                 const long long rr = r + u * gm.rpi;
                 ok[u] = rr < r1;
                 e0[u] = (size_t)rr * a.c + cgi * VE;
                 if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); Vec<T>::load(a.dy + e0[u] * sizeof(T), g[u]); }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < RVIP_BWD_U; ++u) {
                 if (!ok[u]) continue;
                 xform_g<T, VE>(a, e0[u], cgi * VE, key, z[u], g[u]);
 #pragma unroll
@@ -559,17 +562,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
             }
         }
     } else if (active) {
-        for (long long r = r0 + prow; r < r1; r += 2 * gm.rpi) {
-            float z[2][VE], g[2][VE]; size_t e0[2]; bool ok[2];
+        for (long long r = r0 + prow; r < r1; r += RVIP_BWD_U * gm.rpi) {
+            float z[RVIP_BWD_U][VE], g[RVIP_BWD_U][VE]; size_t e0[RVIP_BWD_U]; bool ok[RVIP_BWD_U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < RVIP_BWD_U; ++u) {
                 const long long rr = r + u * gm.rpi;
                 ok[u] = rr < r1;
                 e0[u] = (size_t)rr * a.c + cgi * VE;
                 if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); Vec<T>::load(a.dy + e0[u] * sizeof(T), g[u]); }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < RVIP_BWD_U; ++u) {
                 if (!ok[u]) continue;
                 xform_g<T, VE>(a, e0[u], cgi * VE, key, z[u], g[u]);
                 float d[VE];
