@@ -7,9 +7,10 @@ Contract kept: ``__len__`` = floor(N / BATCHSIZE) (:142); ``__getit
 (predict_model.py:136-139).  With ``GAUS`` the targets are per-channel Gaussian-filtered one-hot masks, min-max
 normalised over all channels together (:385-391) -- the heat-map regression targets of the RVIP model.
 
-The reference's NRRD loading / resampling / albumentations body (:283-375) is CPU, I/O-bound pre-processing
-outside the hot path; ``SyntheticSAXGenerator`` produces slices of the same contract
-from a seed (no ACDC data is available to this build), ``ArrayGenerator`` wraps arrays already in memory.
+``SyntheticSAXGenerator`` produces slices of the same contract from a seed (no ACDC data is available to this
+build), ``ArrayGenerator`` wraps arrays already in memory, ``DataGenerator`` is the file-based generator
+(:234-398) on the NumPy / SciPy restatement of the reference's pre-processing in ``Preprocess.py`` (SURVEY 8(f)
+row 4: CPU, I/O-bound, outside the hot path).
 """
 from __future__ import annotations
 
@@ -139,3 +140,73 @@ class ArrayGenerator(BaseGenerator):
     def __data_generation__(self, idxs):
         idxs = np.asarray(idxs)
         return self._x[idxs], (None if self._y is None else self._y[idxs])
+
+
+class DataGenerator(BaseGenerator):
+    """File-based generator of the reference (Generators.py:234-398) on the NumPy / SciPy restatement of its
+    pre-processing (``Preprocess.py`` of this package): ``x`` / ``y`` are lists of image / label files (.nrrd, .nii(.gz),
+    .npy), one 2-D slice (or one 3-D volume when ``DIM`` has three entries) per file.
+
+    ``__fix_preprocessing__`` (:283-337): read, resample to ``SPACING`` (linear for the image, nearest for the labels)
+    when ``RESAMPLE``, clip to the 0.999 quantile, normalise.  ``__preprocess_one_image__`` (:339-398): augmentation
+    (``AUGMENT``), centre pad / crop to ``DIM``, normalise again, labels -> one channel per ``MASK_VALUES`` entry and,
+    with ``GAUS``, Gaussian heat-maps min-max normalised over all channels.  Not built: ``MASKING_IMAGE``,
+    ``HIST_MATCHING`` (both off in the reference's template config)."""
+
+    def __init__(self, x=None, y=None, config=None, in_memory=False):
+        config = dict(config or {})
+        if config.get('MASKING_IMAGE', False) or config.get('HIST_MATCHING', False):
+            raise NotImplementedError('MASKING_IMAGE / HIST_MATCHING are not built')
+        self.IMAGES = list(x or [])
+        self.LABELS = list(y) if y is not None else None
+        if self.LABELS is not None and len(self.LABELS) != len(self.IMAGES):
+            raise ValueError('x and y must list the same number of files')
+        self.MASKS = self.LABELS is not None
+        self.RESAMPLE = config.get('RESAMPLE', False)
+        self.SPACING = list(config.get('SPACING', [1.25, 1.25]))
+        self.AUGMENT = config.get('AUGMENT', False)
+        self.AUGMENT_PROB = config.get('AUGMENT_PROB', 0.8)
+        self.IN_MEMORY = in_memory
+        self._rng = np.random.default_rng(config.get('SEED', 42))
+        super().__init__(len(self.IMAGES), config)
+        if not self.MASKS:
+            self.N_CLASSES = 1                                   # the image is yielded twice (Generators.py:393-395)
+        self._processed = {}
+        if self.IN_MEMORY:
+            for i in range(len(self.IMAGES)):
+                self._processed[i] = self.__fix_preprocessing__(i)
+
+    def __fix_preprocessing__(self, ID):
+        from . import Preprocess as pp
+        img, sp = pp.read_image(self.IMAGES[ID])
+        if self.MASKS:
+            msk, _ = pp.read_image(self.LABELS[ID])
+        else:
+            msk = img
+        nd = len(self.DIM)
+        if img.ndim != nd or msk.ndim != nd:
+            raise ValueError('%s: %d-D file for a %d-D DIM' % (self.IMAGES[ID], img.ndim, nd))
+        if self.RESAMPLE:
+            if sp is None:
+                raise ValueError('%s carries no spacing: cannot RESAMPLE' % self.IMAGES[ID])
+            size = pp.calc_resampled_size(img.shape, sp, self.SPACING[-nd:])
+            img = pp.resample(img, sp, self.SPACING[-nd:], size, order=1)
+            msk = pp.resample(msk, sp, self.SPACING[-nd:], size, order=0 if self.MASKS else 1)
+        img = normalise_image(pp.clip_quantile(img.astype(np.float64), .999), self.SCALER)
+        if not self.MASKS:
+            msk = normalise_image(pp.clip_quantile(msk.astype(np.float64), .999), self.SCALER)
+        return img, msk
+
+    def __preprocess_one_image__(self, i, ID):
+        from . import Preprocess as pp
+        img, msk = self._processed[ID] if ID in self._processed else self.__fix_preprocessing__(ID)
+        if self.AUGMENT:
+            img, msk = pp.augment(img, msk, self.config, self._rng, self.AUGMENT_PROB)
+        img = normalise_image(pp.pad_and_crop(img, self.DIM), self.SCALER)
+        msk = pp.pad_and_crop(msk, self.DIM)
+        if self.MASKS:
+            msk = transform_to_binary_mask(msk, self.MASK_VALUES)
+            msk = gaussian_heatmaps(msk, self.SIGMA) if self.GAUS else msk
+        else:
+            msk = normalise_image(msk, self.SCALER)[..., None]
+        return img[..., None].astype(np.float32), np.asarray(msk, np.float32)

@@ -11,8 +11,8 @@ The directory name carries a hyphen (it is the reference's name + ``_amd``); imp
 from .Unets import create_unet, get_model, UnetPlan            # noqa: F401
 from .keras_model import Model                                  # noqa: F401
 from .ModelUtils import get_optimizer, Adam                     # noqa: F401
-from . import Loss_and_metrics, Generators, KerasCallbacks      # noqa: F401
+from . import Loss_and_metrics, Generators, KerasCallbacks, Preprocess      # noqa: F401
 from . import _native                                           # noqa: F401
 
 __all__ = ['create_unet', 'get_model', 'UnetPlan', 'Model', 'get_optimizer', 'Adam', 'Loss_and_metrics', 'Generators',
-           'KerasCallbacks']
+           'KerasCallbacks', 'Preprocess']

@@ -3,6 +3,7 @@ library load/exports, weights I/O, generator and callback protocols, dropout str
 and the 2-rank data-parallel path over gloo."""
 import io
 import json
+import importlib
 import os
 import re
 import sys
@@ -269,3 +270,95 @@ def test_two_rank_data_parallel_gloo():
         p.join(60)
     assert [r for r, _ in res] == [0, 1]
     assert all(err < 1e-12 for _, err in res), res
+
+
+# ----------------------------------------------------------------------------------------------
+# file generator / pre-processing restatement (src/data/Preprocess.py, Generators.py:234-398)
+# ----------------------------------------------------------------------------------------------
+def test_preprocess_restatement(tmp_path):
+    pp = importlib.import_module('cmr-landmark-detection_amd.Preprocess')
+    # pad_and_crop: centre; odd differences: pad (floor, floor+1), crop (floor+1, floor)  (Preprocess.py:494-541)
+    a = np.arange(1, 6, dtype=float)                                         # length 5
+    np.testing.assert_array_equal(pp.pad_and_crop(a, (8,)), [0, 1, 2, 3, 4, 5, 0, 0])     # pad 3 -> 1 in front, 2 behind
+    np.testing.assert_array_equal(pp.pad_and_crop(a, (2,)), [3, 4])                      # crop 3 -> 2 in front, 1 behind
+    np.testing.assert_array_equal(pp.pad_and_crop(a, (3,)), [2, 3, 4])
+    b = np.arange(12, dtype=float).reshape(3, 4)
+    out = pp.pad_and_crop(b, (5, 2))
+    assert out.shape == (5, 2) and np.array_equal(out[1:4], b[:, 1:3]) and not out[0].any() and not out[4].any()
+    # resampled size and linear / nearest resampling on the input's grid origin (Preprocess.py:123-134, 182-227)
+    assert pp.calc_resampled_size((10, 20), (2.0, 1.0), (1.0, 2.0)) == [20, 10]
+    ramp = np.add.outer(np.arange(8.0) * 3, np.arange(10.0))
+    up = pp.resample(ramp, (2.0, 2.0), (1.0, 1.0), order=1)
+    assert up.shape == (16, 20)
+    np.testing.assert_allclose(up[:15:2, :19:2], ramp, atol=1e-5)             # samples on the input grid are exact
+    np.testing.assert_allclose(up[1, 1], ramp[:2, :2].mean(), atol=1e-5)      # midpoints are linear
+    assert up[15].max() == 0 and up[:, 19].max() == 0                         # beyond the last input index: default pixel 0
+    lab = (np.arange(64).reshape(8, 8) % 3).astype(np.int16)
+    nn = pp.resample(lab, (1.0, 1.0), (0.5, 0.5), order=0)
+    assert nn.dtype == lab.dtype and set(np.unique(nn)) <= {0, 1, 2}
+    # quantile clip
+    v = np.concatenate([np.linspace(-1, 1, 999), [1e6]])
+    c = pp.clip_quantile(v, .999)
+    assert c.min() == 0 and c.max() < 1e6 and c.max() >= 1
+    # NRRD / NIfTI round trips (z,y,x order, spacing in the same order)
+    vol = (np.random.default_rng(0).random((3, 5, 7)) * 1000).astype(np.int16)
+    for gz in (True, False):
+        f = str(tmp_path / ('v%d.nrrd' % gz))
+        pp.write_nrrd(f, vol, spacing=(8.0, 1.5, 1.25), gz=gz)
+        got, sp = pp.read_nrrd(f)
+        assert np.array_equal(got, vol) and sp == (8.0, 1.5, 1.25)
+    import gzip, struct
+    hdr = bytearray(352)
+    struct.pack_into('<i', hdr, 0, 348)
+    struct.pack_into('<8h', hdr, 40, 3, 7, 5, 3, 1, 1, 1, 1)
+    struct.pack_into('<h', hdr, 70, 4); struct.pack_into('<h', hdr, 72, 16)
+    struct.pack_into('<8f', hdr, 76, 1.0, 1.25, 1.5, 8.0, 0, 0, 0, 0)
+    struct.pack_into('<f', hdr, 108, 352.0)
+    hdr[344:348] = b'n+1\0'
+    nf = str(tmp_path / 'v.nii.gz')
+    with gzip.open(nf, 'wb') as fh:
+        fh.write(bytes(hdr) + vol.astype('<i2').tobytes())
+    got, sp = pp.read_nifti(nf)
+    assert np.array_equal(got, vol) and sp == (8.0, 1.5, 1.25)
+    # augmentation: image and mask move together, labels stay labels, shapes kept
+    rng = np.random.default_rng(3)
+    img = np.zeros((40, 48)); img[10:20, 12:30] = 1.0
+    msk = (img > 0).astype(np.int16) * 2
+    cfg = dict(AUGMENT_PROB=1.0, RANDOMROTATE=True, SHIFTSCALEROTATE=True, GRIDDISTORTION=True)
+    for _ in range(5):
+        ai, am = pp.augment(img, msk, cfg, rng, 1.0)
+        assert ai.shape == img.shape and am.shape == msk.shape and set(np.unique(am)) <= {0, 2}
+        inter = ((ai > 0.5) & (am == 2)).sum() / max(1, ((ai > 0.5) | (am == 2)).sum())
+        assert inter > 0.8
+
+
+def test_file_generator_contract(tmp_path):
+    pp = importlib.import_module('cmr-landmark-detection_amd.Preprocess')
+    rng = np.random.default_rng(1)
+    xs, ys = [], []
+    for i in range(5):
+        h, w = 90 + 7 * i, 100 - 5 * i
+        img = (rng.random((h, w)) * 800 + 20).astype(np.int16)
+        lab = np.zeros((h, w), np.uint8)
+        lab[h // 3, w // 3], lab[h // 2, w // 2 + 4] = 1, 2
+        fx, fy = str(tmp_path / ('p%d_img.nrrd' % i)), str(tmp_path / ('p%d_msk.nrrd' % i))
+        pp.write_nrrd(fx, img, spacing=(1.5, 1.5)); pp.write_nrrd(fy, lab, spacing=(1.5, 1.5))
+        xs.append(fx); ys.append(fy)
+    cfg = dict(DIM=[64, 64], BATCHSIZE=2, SPACING=[1.5, 1.5], RESAMPLE=True, MASK_VALUES=[1, 2], GAUS=True, SIGMA=2, SHUFFLE=False,
+               AUGMENT=True, SHIFTSCALEROTATE=True, AUGMENT_PROB=0.5, SEED=7)
+    gen = rvip.Generators.DataGenerator(xs, ys, cfg)
+    assert len(gen) == 2                                                     # floor(5 / 2), Generators.py:142
+    x, y = gen[0]
+    assert x.shape == (2, 64, 64, 1) and y.shape == (2, 64, 64, 2) and x.dtype == y.dtype == np.float32
+    assert x.min() >= 0 and x.max() <= 1 and abs(float(x.max()) - 1) < 1e-6 and abs(float(y.max()) - 1) < 1e-6 and y.min() >= 0
+    mem = rvip.Generators.DataGenerator(xs, ys, dict(cfg, AUGMENT=False), in_memory=True)
+    x2, y2 = mem[1]
+    x3, y3 = rvip.Generators.DataGenerator(xs, ys, dict(cfg, AUGMENT=False))[1]
+    assert np.array_equal(x2, x3) and np.array_equal(y2, y3)
+    # the landmark survives the pipeline: heat-map peak = centre-cropped landmark position of the (spacing-preserving) input
+    h, w = 90 + 7 * 2, 100 - 5 * 2
+    py, px = h // 3 - ((h - 64) // 2 + (h - 64) % 2), w // 3 - ((w - 64) // 2 + (w - 64) % 2)
+    assert np.unravel_index(int(y2[0, ..., 0].argmax()), (64, 64)) == (py, px)
+    inf = rvip.Generators.DataGenerator(xs, None, dict(cfg, AUGMENT=False))
+    xi, yi = inf[0]
+    assert yi.shape == (2, 64, 64, 1) and np.allclose(xi, yi)
