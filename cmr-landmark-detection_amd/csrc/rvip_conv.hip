@@ -1392,7 +1392,7 @@ static int igemm_generation(const ConvArgs& a, bool stats = false) {
 
 using namespace rvip;
 
-extern "C" int rvip_abi_version(void) { return 1; }
+extern "C" int rvip_abi_version(void) { return 2; }     // 2: descriptors grew (depth taps, down2, subpix, deferred folds, pool fusion)
 extern "C" const char* rvip_build_info(void) { return "rvip_hip gfx950 wave64 mfma"; }
 extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
 
