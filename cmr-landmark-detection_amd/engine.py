@@ -616,34 +616,57 @@ class Engine:
         self._run(self.fwd_eval, self.stream())
 
     def backward(self):
-        """Backward launch list.  With RVIP_SIDE_STREAM=1 the weight gradients (needed only by the optimizer) go to a side
-        stream, forked after the kernel that produced their dz and joined at the end (eagerly or under stream capture,
-        where the fork / join events become graph edges).  Off by default: measured on MI355X (cfg 2) the two chains
-        fight for the same CUs and LDS - 6.97 ms per step against 6.67 ms on one stream."""
+        """Backward launch list.  With RVIP_SIDE_STREAM=1 the weight gradient of a stage (MFMA-bound, needed only by the
+        optimizer) is launched on a side stream right AFTER that stage's data gradient has been queued on the main one, so
+        that it runs next to the HBM-bound BN-backward passes of the stage below instead of next to another LDS-filling
+        conv; the side stream is joined before the batched folds.  Works eagerly and under stream capture (the fork /
+        join events become graph edges).  Off by default: measured slower on MI355X in both schedules tried (weight
+        gradient next to the data gradient: 6.97 vs 6.67 ms; next to the BN-backward passes: 6.39 vs 6.11 ms)."""
         torch = _torch()
         main = torch.cuda.current_stream()
         if self.side is None:
             return self._run(self.bwd, main.cuda_stream)
         L = N.lib()
-        on_side = (L.rvip_conv3x3_wgrad, L.rvip_conv3x3_c1_wgrad)
         s_main, s_side = C.c_void_p(main.cuda_stream), C.c_void_p(self.side.cuda_stream)
-        forked = False
+        state = {'pending': None, 'forked': False}
+
+        def to_side(th):
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.side.wait_event(ev)
+            state['forked'] = True
+            rc = th[0](*th[1], s_side)
+            if rc:
+                N.check(rc, th[0].__name__)
+
+        def join():
+            if state['pending'] is not None:
+                to_side(state['pending'])
+                state['pending'] = None
+            if state['forked']:
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                main.wait_event(ev)
+                state['forked'] = False
         for th in self.bwd:
             fn, args = th[0], th[1]
-            if any(fn is f for f in on_side):
-                ev = torch.cuda.Event()
-                ev.record(main)
-                self.side.wait_event(ev)
-                forked = True
-                rc = fn(*args, s_side)
-            else:
-                rc = fn(*args, s_main)
+            if fn is L.rvip_conv3x3_wgrad:
+                if state['pending'] is not None:
+                    to_side(state['pending'])
+                state['pending'] = th                      # goes out after the data gradient that follows it in the list
+                continue
+            if fn is L.rvip_conv3x3_c1_wgrad or fn is L.rvip_conv3d_c1_wgrad:
+                to_side(th)
+                continue
+            if fn is L.rvip_fold_rows_batch:
+                join()
+            rc = fn(*args, s_main)
             if rc:
                 N.check(rc, fn.__name__)
-        if forked:
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-            main.wait_event(ev)
+            if fn is L.rvip_conv3x3_fwd and state['pending'] is not None:
+                to_side(state['pending'])
+                state['pending'] = None
+        join()
 
     def optimizer_step(self):
         self._run(self.opt, self.stream())
