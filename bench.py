@@ -175,6 +175,19 @@ def main():
     loss = float(eng.loss.item())
     assert np.isfinite(loss), 'training diverged in the benchmark'
 
+    # ---- the same step fed from HOST buffers (what Model.fit hands over): H2D of x and y every step, then the replay.  Reported
+    # beside `value`, never as it (the contract times resident inputs).
+    host_rate = None
+    if rank == 0 and world == 1:
+        hs = max(3, min(args.steps, 10))
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for _ in range(hs):
+            eng.load_input(x, y)               # pageable NumPy -> device (x 8.4 MB + y 16.8 MB at config 2), includes the fp32 -> bf16 staging
+            run()
+        torch.cuda.synchronize()
+        host_rate = round(B * hs / (time.perf_counter() - th0), 2)
+
     # ---- roofline pass: HIP events around every launch, eager, on the launch stream -------------------------
     roof = None
     per_kernel = {}
@@ -257,6 +270,7 @@ def main():
                 args.depth, args.filters, args.dim, args.dim, B, ' + RCCL grad all-reduce' if world > 1 else ''),
                 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch, 'collective': ('%s all-reduce of %d fp32 gradients' % (backend, model._params.count)) if world > 1 else None,
                 'gflop_per_slice_fwd_bwd': round(step_flops / 1e9, 3)},
+            'host_input_slices_per_s': host_rate,
             'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),
             'loss': loss,
             'roofline': roof,
