@@ -395,7 +395,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
 // wgrad v3: the same kernel with the producer / consumer split of igemm v3.  A workgroup is 8 waves: waves 0..3 contract
 // (exactly the four waves of v2), waves 4..7 only issue the LDS-DMA pieces of the next pixel tile; one s_barrier per tile
 // joins them.  In v2 every wave issues ~19 DMA instructions (~150 issue cycles each) in front of its 144 MFMAs per tile.
-template <typename T, int TW, int CIB, int COB>
+// NST = LDS stages: 3 where they fit (the 32 x 32 block variant, 38 KiB per stage - the full-resolution layers, which are bound
+// by the latency of the input stream: a second tile in flight per CU), else 2.
+template <typename T, int TW, int CIB, int COB, int NST = 2>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     constexpr int TH = 256 / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
     constexpr int NHROWS = (NHALO + 15) / 16 * 16;
@@ -490,12 +492,26 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
 
     if (loader) {
         if (split < a.ntiles) issue(split, 0);
+        if constexpr (NST == 3) { if (split + a.nsplit < a.ntiles) issue(split + a.nsplit, 1); }
+        // DMA instructions this wave issues per tile (the pieces are dealt round-robin to the four loader waves)
+        const int mine = ((NQX - wv + 3) >> 2) + ((NQG - wv + 3) >> 2);
         int it = 0;
         for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
             // my pieces of this tile have landed; after the barrier everybody's have, and the compute waves are done
             // with the previous tile, whose stage the next one may overwrite
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (tile + a.nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + a.nsplit, (it + 1) & 1);
+            if constexpr (NST == 3) {
+                // the tile after this one may stay in flight: wait until at most its `mine` instructions are outstanding
+                if (tile + a.nsplit < a.ntiles && !(a.dbg & 1)) {
+                    if (mine == QX + QG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG) : "memory");
+                    else if (mine == QX + QG - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG - 1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG >= 2 ? QX + QG - 2 : 0) : "memory");
+                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                if (tile + 2 * a.nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + 2 * a.nsplit, (it + 2) % 3);
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (tile + a.nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + a.nsplit, (it + 1) & 1);
+            }
         }
         asm volatile("s_barrier" ::: "memory");                       // matches the compute waves' barrier before the fold
         if constexpr (PSPLIT > 1) {
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
         asm volatile("s_barrier" ::: "memory");                       // the tile is in LDS (the loaders waited for their DMAs)
         if (a.dbg & 2) continue;
-        const unsigned char* lx = smem + (it & 1) * ST_BYTES;
+        const unsigned char* lx = smem + (NST == 3 ? it % 3 : (it & 1)) * ST_BYTES;
         const unsigned char* lg = lx + X_BYTES;
         if constexpr (ESZ == 2) {
             // Every transposed read of the tile = one of 6 (X) / 2 (G) per-lane base addresses + a compile-time offset:
@@ -696,18 +712,23 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int ESZ = (int)sizeof(T);
     constexpr int ST = NHROWS * CIB * ESZ + 256 * COB * ESZ;
-    constexpr int lds = 2 * ST;
+#ifdef RVIP_WG_TWO_STAGES
+    constexpr int NST = 2;
+#else
+    constexpr int NST = (WS && 3 * ST <= 160 * 1024) ? 3 : 2;
+#endif
+    constexpr int lds = NST * ST;
     static_assert(lds <= 160 * 1024, "LDS");
     static_assert(2 * ST >= 4 * 9 * 32 * 32 * 4 || true, "fold buffer");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = WS ? hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+        hipError_t e = WS ? hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                           : hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma<T, TW, CIB, COB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
         attr_done = true;
     }
     dim3 grid((unsigned)a.nsplit, (unsigned)cdiv(a.cin, CIB), (unsigned)cdiv(a.cout, COB));
-    if constexpr (WS) hipLaunchKernelGGL((wgrad3x3_ws<T, TW, CIB, COB>), grid, dim3(512), lds, s, a);
+    if constexpr (WS) hipLaunchKernelGGL((wgrad3x3_ws<T, TW, CIB, COB, NST>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((wgrad3x3_dma<T, TW, CIB, COB>), grid, dim3(256), lds, s, a);
     return check_launch();
 }
