@@ -365,3 +365,28 @@ def test_two_rank_data_parallel_step_matches_single_rank(overlap):
     for rank, losses, _, _ in res:                       # the logged loss is the global one (loss sums are all-reduced)
         for step in range(2):
             assert abs(losses[step] - ref_losses[step]) <= 2e-5 * max(1.0, abs(ref_losses[step])), (rank, step)
+
+
+@pytest.mark.parametrize('variant', [dict(DIM=[4, 64, 64], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32),
+                                     dict(USE_UPSAMPLE=False, FILTERS=16, DIM=[64, 64])],
+                         ids=['cine-3d', 'conv2d-transpose'])
+def test_bf16_variants_are_deterministic_and_learn(variant):
+    """bf16 path of the 3-D cine graph (cfg 5's layer types) and of the Conv2DTranspose decoder: two identical steps
+    from identical state are bit-identical, and a few Adam steps on one batch lower the loss."""
+    cfg = _cfg(RVIP_PRECISION='bf16', LEARNING_RATE=2e-3, **variant)
+    model = rvip.get_model(cfg, metrics=[])
+    x, y = O.synthetic_batch(4, cfg['DIM'], 2, seed=6)
+    eng = model._engine(4)
+    outs = []
+    for _ in range(2):
+        eng.load_input(x, y)
+        eng.forward(training=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        outs.append((eng.loss.clone(), eng.pred.clone(), model._params.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.isfinite(outs[0][2]).all()
+    losses = [model.train_on_batch(x, y)[0] for _ in range(12)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    p = model.predict(x)
+    assert p.shape == (4,) + tuple(cfg['DIM']) + (2,) and np.isfinite(p).all()
