@@ -16,9 +16,14 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __builtin_bit_
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }   // RNE, NaN kept
 
 // 16-byte channel vector: VE elements of T
+typedef unsigned rvip_u32x4 __attribute__((ext_vector_type(4)));
+typedef float rvip_f32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Vec;
 template <> struct Vec<float> {
     static constexpr int VE = 4;
+    // last use of a streamed tensor: do not keep the lines (nt = non-temporal)
+    __device__ static __forceinline__ void load_nt(const void* p, float (&v)[4]) {
+        const rvip_f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const rvip_f32x4*>(p)); v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
     __device__ static __forceinline__ void load(const void* p, float (&v)[4]) {
         float4 r = *reinterpret_cast<const float4*>(p); v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
     __device__ static __forceinline__ void store(void* p, const float (&v)[4]) {
@@ -27,6 +32,11 @@ template <> struct Vec<float> {
 };
 template <> struct Vec<bf16_t> {
     static constexpr int VE = 8;
+    __device__ static __forceinline__ void load_nt(const void* p, float (&v)[8]) {
+        const rvip_u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const rvip_u32x4*>(p));
+        uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __builtin_bit_cast(float, w[i] << 16); v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); } }
     __device__ static __forceinline__ void load(const void* p, float (&v)[8]) {
         uint4 r = *reinterpret_cast<const uint4*>(p);
         uint32_t w[4] = {r.x, r.y, r.z, r.w};
