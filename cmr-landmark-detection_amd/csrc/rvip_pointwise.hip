@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
                 const long long r = (g + u * G) * rpi + prow;
                 ok[u] = (g + u * G) < ngroups && r < rows;
                 e0[u] = (size_t)r * a.c + cv * VE;
-                if (ok[u]) Vec<T>::load(a.z + e0[u] * sizeof(T), v[u]);
+                if (ok[u]) Vec<T>::load_nt(a.z + e0[u] * sizeof(T), v[u]);     // z is not read again before the backward pass
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     e0[u][k] = (((size_t)img * a.h + 2 * oy + (k >> 1)) * a.w + 2 * ox + (k & 1)) * a.c + cv * VE;
-                    if (ok[u]) Vec<T>::load(a.z + e0[u][k] * sizeof(T), v[u][k]);
+                    if (ok[u]) Vec<T>::load_nt(a.z + e0[u][k] * sizeof(T), v[u][k]);
                 }
             }
 #pragma unroll
