@@ -33,7 +33,7 @@ class Conv3x3Desc(C.Structure):
                 ('y', vp), ('y1', vp), ('csplit', C.c_int32),
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('act', C.c_int32), ('dtype', C.c_int32),
-                ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32), ('subpix', C.c_int32)]
+                ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32), ('subpix', C.c_int32), ('stream_in', C.c_int32)]
 
 
 class PackEntry(C.Structure):

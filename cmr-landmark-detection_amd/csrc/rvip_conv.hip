@@ -47,6 +47,7 @@ struct ConvArgs {
     int depth, kd;                            // Conv3D: images per volume and depth taps (3); a plain 2-D conv has 1, 1
     int down2;                                // store the 2x2 block sums of the result at half resolution (gradient of UpSampling2D)
     int subpix;                               // UpSampling2D -> conv as four 2x2-tap phase convolutions on the low-resolution input
+    int nt_in;                                // non-temporal input reads (last reader of x0)
 };
 
 template <typename T, int TW, int NCT>
@@ -257,6 +258,12 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned lds_of
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
 }
+// the same with the non-temporal hint: a streamed tensor that nothing reads again soon should not displace the others
+__device__ __forceinline__ void dma16_nt(i32x4 rsrc, unsigned voff, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
+}
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(lds_void_t*)p; }
 
 struct ConvArgs2 {
@@ -272,6 +279,7 @@ struct ConvArgs2 {
     int depth, kd;                           // Conv3D as a K loop over depth taps: chunk kc reads image n + kc / nch - kd / 2
     int down2;                               // epilogue_down2 instead of the plain epilogue
     int subpix;                              // TAPS == 4 kernels: blockIdx.z = output phase (a, b); y is [N, 2h, 2w, Cout]
+    int nt_in;                               // input pieces with the non-temporal hint
     int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
 };
@@ -763,7 +771,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                     int rel = irel0[i];
                     if (!from0) rel = ((ihy[i] * a.w + ihx[i]) * a.c1 + ich[i]) * (int)sizeof(T);
                     const unsigned off = ok ? (unsigned)(base + rel) : OOB;
-                    dma16(rs, off, lds_base + stage * IN_BYTES + q * 1024);
+                    if (a.nt_in) dma16_nt(rs, off, lds_base + stage * IN_BYTES + q * 1024);
+                    else dma16(rs, off, lds_base + stage * IN_BYTES + q * 1024);
                 }
             }
         };
@@ -998,7 +1007,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = a0.subpix;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = a0.subpix; b.nt_in = a0.nt_in;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -1075,7 +1084,7 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float
     ConvArgs2 b;
     b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = 0;
+    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = 0; b.nt_in = 0;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -1418,6 +1427,7 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     if ((a.kd != 1 && a.kd != 3) || d->n % a.depth) return RVIP_EINVAL;
     a.down2 = d->down2 ? 1 : 0;
     if (a.down2 && (d->y1 || d->bias || d->act != RVIP_ACT_NONE || ((d->h | d->w) & 1))) return RVIP_EINVAL;
+    a.nt_in = d->stream_in ? 1 : 0;
     a.subpix = d->subpix ? 1 : 0;
     if (a.subpix) {                      // UpSampling2D -> conv as four phase convolutions on the low-resolution grid
         if (d->up0 != 1 || d->c1 || d->y1 || a.kd != 1 || a.down2) return RVIP_EINVAL;

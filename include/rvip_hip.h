@@ -95,6 +95,9 @@ typedef struct rvip_conv3x3_desc {
      * convolutions on the low-resolution x0, 16 instead of 36 multiply-adds per low-resolution pixel; same result up to
      * the summation order of the taps.  w_packed is then the [4][4][Cout][C0] block of rvip_pack_subpixel_weights. */
     int32_t      subpix;
+    /* stream_in != 0: hint that this launch is the last reader of x0 for a while (e.g. the data gradient reading dz):
+     * its input is fetched with the non-temporal cache policy. */
+    int32_t      stream_in;
 } rvip_conv3x3_desc;
 
 int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
