@@ -645,6 +645,11 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
 // (each owns NPIX/4 pixels x BN channels, so a weight fragment is reused by up to 4 pixel fragments: 0.75 KiB of LDS
 // reads per MFMA instead of 1 KiB).  One s_barrier per work item joins the two roles.
 // ---------------------------------------------------------------------------------------------
+// cache policy of the second output (the skip-connection gradient of a concat conv's data gradient: written at the start of
+// the backward pass, read by the encoder's max-pool backward at its end): 2 = non-temporal
+#ifndef RVIP_Y1_POLICY
+#define RVIP_Y1_POLICY 0
+#endif
 // TAPS = 4: sub-pixel form of UpSampling2D(2) -> conv3x3 (KerasLayers.py:756-758).  Output pixel (2i+a, 2j+b) only sees the
 // low-resolution pixels (i+a-1 .. i+a) x (j+b-1 .. j+b), each through a SUM of the 3x3 taps that fall on it, so the layer
 // is four 2x2-tap convolutions on the low-resolution image (16 instead of 36 multiply-adds per low-resolution pixel and
@@ -886,7 +891,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                     const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 4u : OOB;
                     const u32x4v dta = {__builtin_bit_cast(unsigned, v[4 * q]), __builtin_bit_cast(unsigned, v[4 * q + 1]),
                                         __builtin_bit_cast(unsigned, v[4 * q + 2]), __builtin_bit_cast(unsigned, v[4 * q + 3])};
-                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
+                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, RVIP_Y1_POLICY);
                     else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
                 }
             } else {
@@ -901,7 +906,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                     const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
                     const int co = cbase + 16 * qq + 8 * hf;
                     const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
-                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
+                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, RVIP_Y1_POLICY);
                     else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
                 }
             }

@@ -599,7 +599,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + ci_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf, co = co0 + co_t * 32 + j;
-                if (ci < a.cin && co < a.cout) out[((size_t)t * a.cin + ci) * a.cout + co] = acc[t][r];
+                // the slab is read back by the batched fold at the end of the gradient bucket, milliseconds later: non-temporal
+                // stores keep its 37.7 MB per layer from displacing the activations (measured: -0.07 ms per step)
+                if (ci < a.cin && co < a.cout) __builtin_nontemporal_store(acc[t][r], &out[((size_t)t * a.cin + ci) * a.cout + co]);
             }
     } else {
         float* red = reinterpret_cast<float*>(smem) + pair * 9 * 32 * 32;   // [PAIRS][9][32][32]
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
         for (int e = tid; e < PAIRS * 9 * 32 * 32; e += 256) {
             const int pr = e / (9 * 32 * 32), rem = e % (9 * 32 * 32);
             const int t = rem >> 10, ci = ci0 + (pr % NCI) * 32 + ((rem >> 5) & 31), co = co0 + (pr / NCI) * 32 + (rem & 31);
-            if (ci < a.cin && co < a.cout) out[((size_t)t * a.cin + ci) * a.cout + co] = redall[e];
+            if (ci < a.cin && co < a.cout) __builtin_nontemporal_store(redall[e], &out[((size_t)t * a.cin + ci) * a.cout + co]);
         }
     }
 }
