@@ -1033,6 +1033,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
         attr_lds = LDS_MAX;
     }
     const int cot = (int)cdiv(a0.cout, NCT * 32);
+    if (cot > 1) b.nt_in = 0;       // several workgroup columns re-read the same input tile: keep it cached (measured)
     constexpr int NZ = TAPS == 4 ? 4 : 1;
     int gx = 256 / (cot * NZ);
     if (gx < 1) gx = 1;

@@ -362,6 +362,7 @@ class Engine:
                 d.y, d.y1, d.csplit = z.data_ptr(), None, 0
                 d.n, d.h, d.w, d.cout, d.act, d.dtype = n, st.h, st.w, st.cout, act_conv, dt
                 d.depth, d.kd = self.depth, self.kd
+                d.stream_in = 1 if os.environ.get('RVIP_NT_FWD', '0') == '1' else 0
                 if st.conv in P.subpix:
                     d.w_packed, d.subpix = P.subpix[st.conv].data_ptr(), 1
                 self._keep.append(d)
