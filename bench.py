@@ -38,7 +38,7 @@ def main():
     ap.add_argument('--filters', type=int, default=32, help='base filters (BASELINE.json headline: 32; cfg 4: 64)')
     ap.add_argument('--depth', type=int, default=4, help='U-Net levels (headline: 4; cfg 4: 5)')
     ap.add_argument('--frames', type=int, default=0, help='> 0: 3-D cine graph on [frames, dim, dim] volumes (cfg 5: 16), Conv3D 3x3x3, pool (1,2,2)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'], help='fp16: BASELINE.json configs[3] (static loss scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--cpu-batch', type=int, default=8)
@@ -249,10 +249,10 @@ def main():
         except Exception:
             pass
         roof = dict(bound='mfma', kernel='conv3x3_igemm (forward incl. fused BN statistics + data-gradient launches)', achieved=round(achieved, 2),
-                    peak=PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3, unit='TFLOP/s',
-                    frac=round(achieved / (PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3), 4),
+                    peak=PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3, unit='TFLOP/s',
+                    frac=round(achieved / (PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3), 4),
                     traffic=traffic, traffic_source='profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)' if traffic else None,
-                    algorithmic_bytes_per_launch=round(plan.ideal_bytes_per_slice(2 if args.precision == 'bf16' else 4) * 2.0 / 3.0 * B / max(len(cv) // reps, 1)),
+                    algorithmic_bytes_per_launch=round(plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * 2.0 / 3.0 * B / max(len(cv) // reps, 1)),
                     launches_per_step=len(cv) // reps, avg_launch_ms=round(ms / len(cv), 4),
                     flops_per_launch=fl / len(cv))
 
@@ -265,7 +265,7 @@ def main():
             'metric': 'SAX slices/sec (fwd+bwd), 256x256 U-Net 2-heatmap' if args.frames <= 0 else 'cine volumes/sec (fwd+bwd), %dx%dx%d 3-D U-Net' % (args.frames, args.dim, args.dim),
             'value': round(value, 2), 'unit': 'slices/s' if args.frames <= 0 else 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'fp16': 'f16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
             'config': {'workload': '%d-level 2D U-Net F=%d, %dx%d, batch %d per GPU, fwd+loss(MSE)+bwd+Adam%s' % (
                 args.depth, args.filters, args.dim, args.dim, B, ' + RCCL grad all-reduce' if world > 1 else ''),
                 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch, 'collective': ('%s all-reduce of %d fp32 gradients' % (backend, model._params.count)) if world > 1 else None,

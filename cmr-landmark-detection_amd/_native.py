@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RVIP_LIB') or os.path.join(_HERE, 'librvip_hip.so')     # RVIP_LIB: A/B another build of the same ABI
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'elu': 2, 'sigmoid': 3}
 LOSS_MSE, LOSS_BCE_DICE = 0, 1
 STATE_STEP, STATE_LR, STATE_SEED, STATE_WORDS = 0, 1, 2, 8
@@ -131,6 +131,7 @@ SIGNATURES = {
     'rvip_postprocess': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, C.c_size_t, vp]),
     'rvip_adam_step': (C.c_int, [vp, vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]),
     'rvip_state_tick': (C.c_int, [vp, vp]),
+    'rvip_scale_f32': (C.c_int, [vp, C.c_longlong, C.c_float, vp]),
     'rvip_convert': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, vp]),
 }
 

@@ -10,10 +10,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 struct bf16_t { uint16_t bits; };
+struct f16_t { uint16_t bits; };      // IEEE binary16 storage (RVIP_F16): same kernels, v_mfma_f32_32x32x16_f16, fp32 accumulate
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }   // RNE, NaN kept
+
+__device__ __forceinline__ float f16_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // RNE, overflow -> inf
 
 // 16-byte channel vector: VE elements of T
 typedef unsigned rvip_u32x4 __attribute__((ext_vector_type(4)));
@@ -48,7 +53,37 @@ template <> struct Vec<bf16_t> {
         for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]); }
     __device__ static __forceinline__ float round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
+    __device__ static __forceinline__ uint16_t enc(float x) { return f32_to_bf16(x); }
+    __device__ static __forceinline__ float dec(uint16_t b) { return bf16_to_f32(b); }
 };
+template <> struct Vec<f16_t> {
+    static constexpr int VE = 8;
+    __device__ static __forceinline__ void unpack(const uint32_t (&w)[4], float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = f16_to_f32((uint16_t)(w[i] & 0xffffu)); v[2 * i + 1] = f16_to_f32((uint16_t)(w[i] >> 16)); } }
+    __device__ static __forceinline__ void load_nt(const void* p, float (&v)[8]) {
+        const rvip_u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const rvip_u32x4*>(p));
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        unpack(w, v); }
+    __device__ static __forceinline__ void load(const void* p, float (&v)[8]) {
+        const uint4 r = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        unpack(w, v); }
+    __device__ static __forceinline__ void store(void* p, const float (&v)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_f16(v[2 * i]) | ((uint32_t)f32_to_f16(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]); }
+    __device__ static __forceinline__ float round(float x) { return f16_to_f32(f32_to_f16(x)); }
+    __device__ static __forceinline__ uint16_t enc(float x) { return f32_to_f16(x); }
+    __device__ static __forceinline__ float dec(uint16_t b) { return f16_to_f32(b); }
+};
+// MFMA on eight 16-bit K elements per lane (one uint4 fragment of each operand)
+template <typename T> __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& acc);
+template <> __device__ __forceinline__ f32x16 mfma16<bf16_t>(const uint4& a, const uint4& b, const f32x16& acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0); }
+template <> __device__ __forceinline__ f32x16 mfma16<f16_t>(const uint4& a, const uint4& b, const f32x16& acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0); }
 
 __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
@@ -106,5 +141,15 @@ inline int check_launch() {
 }
 
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+// dtype tags of the ABI -> storage types
+#define RVIP_DT_OK(dt) ((dt) == RVIP_BF16 || (dt) == RVIP_F16 || (dt) == RVIP_F32)
+#define RVIP_VE(dt) ((dt) == RVIP_F32 ? 4 : 8)
+#define RVIP_ESZ(dt) ((dt) == RVIP_F32 ? 4 : 2)
+template <typename F> static inline int by_dtype(int dt, F&& f) {
+    if (dt == RVIP_BF16) return f(bf16_t{});
+    if (dt == RVIP_F16) return f(f16_t{});
+    return f(float{});
+}
 
 }  // namespace rvip

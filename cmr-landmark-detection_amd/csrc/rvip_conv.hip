@@ -23,9 +23,10 @@ int g_last_hip_error = 0;
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    }
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) { acc = mfma16<bf16_t>(a, b, acc); }
+};
+template <> struct Mma<f16_t> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) { acc = mfma16<f16_t>(a, b, acc); }
 };
 template <> struct Mma<float> {
     __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) {
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(ConvArgs a) {
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     uint2 o;
-                    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    o.x = (uint32_t)Vec<T>::enc(v[0]) | ((uint32_t)Vec<T>::enc(v[1]) << 16);
+                    o.y = (uint32_t)Vec<T>::enc(v[2]) | ((uint32_t)Vec<T>::enc(v[3]) << 16);
                     *reinterpret_cast<uint2*>(dst) = o;
                 }
             }
@@ -325,10 +326,10 @@ __device__ __forceinline__ void epilogue_down2(f32x16 (&acc)[NCT][NPT], int pbas
             } else {
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
-                    unsigned ax = (uint32_t)f32_to_bf16(v[8 * qq + 0]) | ((uint32_t)f32_to_bf16(v[8 * qq + 1]) << 16);
-                    unsigned ay = (uint32_t)f32_to_bf16(v[8 * qq + 2]) | ((uint32_t)f32_to_bf16(v[8 * qq + 3]) << 16);
-                    unsigned bxx = (uint32_t)f32_to_bf16(v[8 * qq + 4]) | ((uint32_t)f32_to_bf16(v[8 * qq + 5]) << 16);
-                    unsigned byy = (uint32_t)f32_to_bf16(v[8 * qq + 6]) | ((uint32_t)f32_to_bf16(v[8 * qq + 7]) << 16);
+                    unsigned ax = (uint32_t)Vec<T>::enc(v[8 * qq + 0]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 1]) << 16);
+                    unsigned ay = (uint32_t)Vec<T>::enc(v[8 * qq + 2]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 3]) << 16);
+                    unsigned bxx = (uint32_t)Vec<T>::enc(v[8 * qq + 4]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 5]) << 16);
+                    unsigned byy = (uint32_t)Vec<T>::enc(v[8 * qq + 6]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 7]) << 16);
                     auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
                     auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
                     const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
@@ -584,10 +585,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
                 } else {
 #pragma unroll
                     for (int qq = 0; qq < 2; ++qq) {
-                        unsigned ax = (uint32_t)f32_to_bf16(v[8 * qq + 0]) | ((uint32_t)f32_to_bf16(v[8 * qq + 1]) << 16);
-                        unsigned ay = (uint32_t)f32_to_bf16(v[8 * qq + 2]) | ((uint32_t)f32_to_bf16(v[8 * qq + 3]) << 16);
-                        unsigned bxx = (uint32_t)f32_to_bf16(v[8 * qq + 4]) | ((uint32_t)f32_to_bf16(v[8 * qq + 5]) << 16);
-                        unsigned byy = (uint32_t)f32_to_bf16(v[8 * qq + 6]) | ((uint32_t)f32_to_bf16(v[8 * qq + 7]) << 16);
+                        unsigned ax = (uint32_t)Vec<T>::enc(v[8 * qq + 0]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 1]) << 16);
+                        unsigned ay = (uint32_t)Vec<T>::enc(v[8 * qq + 2]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 3]) << 16);
+                        unsigned bxx = (uint32_t)Vec<T>::enc(v[8 * qq + 4]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 5]) << 16);
+                        unsigned byy = (uint32_t)Vec<T>::enc(v[8 * qq + 6]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 7]) << 16);
                         // lanes 0-31 keep quad 2qq and receive the upper half's quad 2qq (channels +4..7);
                         // lanes 32-63 receive the lower half's quad 2qq+1 and keep their own (channels +8..15)
                         auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
@@ -897,10 +898,10 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
             } else {
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
-                    unsigned ax = (uint32_t)f32_to_bf16(v[8 * qq + 0]) | ((uint32_t)f32_to_bf16(v[8 * qq + 1]) << 16);
-                    unsigned ay = (uint32_t)f32_to_bf16(v[8 * qq + 2]) | ((uint32_t)f32_to_bf16(v[8 * qq + 3]) << 16);
-                    unsigned bxx = (uint32_t)f32_to_bf16(v[8 * qq + 4]) | ((uint32_t)f32_to_bf16(v[8 * qq + 5]) << 16);
-                    unsigned byy = (uint32_t)f32_to_bf16(v[8 * qq + 6]) | ((uint32_t)f32_to_bf16(v[8 * qq + 7]) << 16);
+                    unsigned ax = (uint32_t)Vec<T>::enc(v[8 * qq + 0]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 1]) << 16);
+                    unsigned ay = (uint32_t)Vec<T>::enc(v[8 * qq + 2]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 3]) << 16);
+                    unsigned bxx = (uint32_t)Vec<T>::enc(v[8 * qq + 4]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 5]) << 16);
+                    unsigned byy = (uint32_t)Vec<T>::enc(v[8 * qq + 6]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 7]) << 16);
                     auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
                     auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
                     const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
@@ -1145,7 +1146,7 @@ __global__ void pack_w_kernel(const float* __restrict__ w, int cin, int cout, T*
             if (wf) wf[((size_t)t * cout + o) * cin + ci] = v;
             if (wd) wd[((size_t)(8 - t) * cin + ci) * cout + o] = v;
         } else {
-            const uint16_t b = f32_to_bf16(v);
+            const uint16_t b = Vec<T>::enc(v);
             if (wf) wf[((size_t)t * cout + o) * cin + ci].bits = b;
             if (wd) wd[((size_t)(8 - t) * cin + ci) * cout + o].bits = b;
         }
@@ -1158,6 +1159,7 @@ __global__ void pack_w_kernel(const float* __restrict__ w, int cin, int cout, T*
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_to_f32(p->bits); }
+template <> __device__ __forceinline__ float ld1<f16_t>(const f16_t* p) { return f16_to_f32(p->bits); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const T* __restrict__ x, const float* __restrict__ w,
@@ -1309,7 +1311,7 @@ __device__ __forceinline__ void pack_subpixel_range(const float* __restrict__ w,
         for (int kh = kh0; kh <= kh1; ++kh)
             for (int kw = kw0; kw <= kw1; ++kw) acc += w[((size_t)(kh * 3 + kw) * cin + ci) * cout + co];
         if constexpr (sizeof(T) == 4) wp[i] = acc;
-        else wp[i].bits = f32_to_bf16(acc);
+        else wp[i].bits = Vec<T>::enc(acc);
     }
 }
 
@@ -1357,8 +1359,8 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
                 if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = v;
                 else {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                    pk.x = (uint32_t)Vec<T>::enc(v.x) | ((uint32_t)Vec<T>::enc(v.y) << 16);
+                    pk.y = (uint32_t)Vec<T>::enc(v.z) | ((uint32_t)Vec<T>::enc(v.w) << 16);
                     *reinterpret_cast<uint2*>(dst) = pk;
                 }
             }
@@ -1374,17 +1376,17 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
             if (en.cin & 7) {                               // ragged channel count: element stores
                 for (int e = 0; e < 8 && ci0 + i8 + e < en.cin; ++e) {
                     if constexpr (sizeof(T) == 4) dst[e] = v[e];
-                    else dst[e].bits = f32_to_bf16(v[e]);
+                    else dst[e].bits = Vec<T>::enc(v[e]);
                 }
             } else if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<float4*>(dst) = float4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<float4*>(dst + 4) = float4{v[4], v[5], v[6], v[7]};
             } else {
                 uint4 pk;
-                pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                pk.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-                pk.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                pk.x = (uint32_t)Vec<T>::enc(v[0]) | ((uint32_t)Vec<T>::enc(v[1]) << 16);
+                pk.y = (uint32_t)Vec<T>::enc(v[2]) | ((uint32_t)Vec<T>::enc(v[3]) << 16);
+                pk.z = (uint32_t)Vec<T>::enc(v[4]) | ((uint32_t)Vec<T>::enc(v[5]) << 16);
+                pk.w = (uint32_t)Vec<T>::enc(v[6]) | ((uint32_t)Vec<T>::enc(v[7]) << 16);
                 *reinterpret_cast<uint4*>(dst) = pk;
             }
         }
@@ -1413,8 +1415,8 @@ extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
 
 static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     if (!d || !d->x0 || !d->w_packed || !d->y) return RVIP_EINVAL;
-    const int ve = d->dtype == RVIP_BF16 ? 8 : 4;
-    if (d->dtype != RVIP_BF16 && d->dtype != RVIP_F32) return RVIP_EINVAL;
+    const int ve = RVIP_VE(d->dtype);
+    if (!RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->c0 <= 0) return RVIP_EINVAL;
     if (d->c0 % ve || d->c1 % ve || d->cout % 4) return RVIP_EINVAL;
     if ((d->c1 > 0) != (d->x1 != nullptr)) return RVIP_EINVAL;
@@ -1452,13 +1454,13 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
     if (gen >= 2) {
         bool used = false;
         int rc;
-        if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used, nullptr, nullptr, false, gen >= 4)
-                                                 : dispatch_igemm_ws<float>(a, s, used, nullptr, nullptr, false, gen >= 4);
+        if (gen >= 3 || d->dtype == RVIP_F16)        // the A/B generation v2 is not built for f16
+            rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t)>(a, s, used, nullptr, nullptr, false, gen >= 4); });
         else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
         if (rc || used) return rc;
     }
     if (a.kd > 1 || a.down2 || a.subpix) return RVIP_EUNSUPPORTED;        // the register-staged fallback is 2-D only and has the plain epilogue
-    return d->dtype == RVIP_BF16 ? dispatch_igemm<bf16_t>(a, s) : dispatch_igemm<float>(a, s);
+    return by_dtype(d->dtype, [&](auto t) { return dispatch_igemm<decltype(t)>(a, s); });
 }
 
 // Number of partial-statistics rows rvip_conv3x3_fwd_stats will write for this shape (0 = this shape is served by the
@@ -1471,8 +1473,8 @@ extern "C" int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d) {
     if (gen == 2 && d->cout > 32) return 0;      // v2's per-lane accumulators exceed 256 VGPRs at the 64-channel tile
     bool used = false; int rows = 0;
     int rc;
-    if (gen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, nullptr, used, nullptr, &rows, true, gen >= 4)
-                                             : dispatch_igemm_ws<float>(a, nullptr, used, nullptr, &rows, true, gen >= 4);
+    if (gen >= 3 || d->dtype == RVIP_F16)
+        rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t)>(a, nullptr, used, nullptr, &rows, true, gen >= 4); });
     else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, nullptr, used, nullptr, &rows, true)
                                     : dispatch_igemm_dma<float>(a, nullptr, used, nullptr, &rows, true);
     return (rc == RVIP_OK && used) ? rows : 0;
@@ -1490,8 +1492,8 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
     bool used = false;
     hipStream_t s = (hipStream_t)stream;
     const int sgen = igemm_generation(a, true);
-    if (sgen >= 3) rc = d->dtype == RVIP_BF16 ? dispatch_igemm_ws<bf16_t>(a, s, used, stats_ws, nullptr, false, sgen >= 4)
-                                              : dispatch_igemm_ws<float>(a, s, used, stats_ws, nullptr, false, sgen >= 4);
+    if (sgen >= 3 || d->dtype == RVIP_F16)
+        rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t)>(a, s, used, stats_ws, nullptr, false, sgen >= 4); });
     else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used, stats_ws) : dispatch_igemm_dma<float>(a, s, used, stats_ws);
     if (rc) return rc;
     return used ? RVIP_OK : RVIP_EUNSUPPORTED;
@@ -1504,6 +1506,7 @@ extern "C" int rvip_pack_conv3x3_weights(const float* w, int cin, int cout, int 
     const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(pack_w_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (bf16_t*)wf, (bf16_t*)wd);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(pack_w_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (f16_t*)wf, (f16_t*)wd);
     else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_w_kernel<float>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (float*)wf, (float*)wd);
     else return RVIP_EINVAL;
     return check_launch();
@@ -1513,21 +1516,23 @@ extern "C" int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* b
                                    int act, int dtype, void* stream) {
     (void)hipGetLastError();
     if (!x || !w || !y || n <= 0 || h <= 0 || w_ <= 0) return RVIP_EINVAL;
-    const int ve = dtype == RVIP_BF16 ? 8 : 4;
+    const int ve = RVIP_VE(dtype);
     if (cout <= 0 || cout % ve) return RVIP_EINVAL;
     const long long total = (long long)n * h * w_ * (cout / ve);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype != RVIP_BF16 && dtype != RVIP_F32) return RVIP_EINVAL;
+    if (!RVIP_DT_OK(dtype)) return RVIP_EINVAL;
     if (256 % (cout / ve) == 0) {
         const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
         long long nt = (long long)n * tx * ty;
         dim3 g2((unsigned)(nt < 2048 ? nt : 2048));
         if (dtype == RVIP_BF16) hipLaunchKernelGGL(conv3x3_c1_tiled<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty);
+        else if (dtype == RVIP_F16) hipLaunchKernelGGL(conv3x3_c1_tiled<f16_t>, g2, dim3(256), 0, s, (const f16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty);
         else hipLaunchKernelGGL(conv3x3_c1_tiled<float>, g2, dim3(256), 0, s, (const float*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty);
         return check_launch();
     }
     dim3 grid((unsigned)cdiv(total, 256));
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(conv3x3_c1_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(conv3x3_c1_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act);
     else if (dtype == RVIP_F32) hipLaunchKernelGGL(conv3x3_c1_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act);
     else return RVIP_EINVAL;
     return check_launch();
@@ -1537,8 +1542,8 @@ extern "C" int rvip_conv3d_c1_fwd(const void* x, const float* w, const float* bi
                                   int cout, int act, int dtype, void* stream) {
     (void)hipGetLastError();
     if (!x || !w || !y || n <= 0 || depth <= 0 || n % depth || h <= 0 || w_ <= 0) return RVIP_EINVAL;
-    if (dtype != RVIP_BF16 && dtype != RVIP_F32) return RVIP_EINVAL;
-    const int ve = dtype == RVIP_BF16 ? 8 : 4;
+    if (!RVIP_DT_OK(dtype)) return RVIP_EINVAL;
+    const int ve = RVIP_VE(dtype);
     if (cout <= 0 || cout % ve || 256 % (cout / ve) || cout > 256) return RVIP_EINVAL;
     const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
     long long nt = (long long)n * tx * ty;
@@ -1546,6 +1551,7 @@ extern "C" int rvip_conv3d_c1_fwd(const void* x, const float* w, const float* bi
     const size_t lds = (size_t)27 * cout * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(conv3d_c1_tiled<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(conv3d_c1_tiled<f16_t>, grid, dim3(256), lds, s, (const f16_t*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
     else hipLaunchKernelGGL(conv3d_c1_tiled<float>, grid, dim3(256), lds, s, (const float*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
     return check_launch();
 }
@@ -1557,6 +1563,7 @@ extern "C" int rvip_pack_subpixel_weights(const float* w, int cin, int cout, int
     const int blocks = (int)(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(pack_subpixel_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (bf16_t*)w_phase);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(pack_subpixel_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (f16_t*)w_phase);
     else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_subpixel_kernel<float>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (float*)w_phase);
     else return RVIP_EINVAL;
     return check_launch();
@@ -1572,6 +1579,7 @@ extern "C" int rvip_pack_all_conv3x3_weights(const float* theta, const void* tab
     dim3 grid((unsigned)nb, (unsigned)entries);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(pack_all_kernel<bf16_t>, grid, dim3(256), 0, s, theta, (const PackEntry*)table, (bf16_t*)wf_base, (bf16_t*)wd_base);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(pack_all_kernel<f16_t>, grid, dim3(256), 0, s, theta, (const PackEntry*)table, (f16_t*)wf_base, (f16_t*)wd_base);
     else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_all_kernel<float>, grid, dim3(256), 0, s, theta, (const PackEntry*)table, (float*)wf_base, (float*)wd_base);
     else return RVIP_EINVAL;
     return check_launch();

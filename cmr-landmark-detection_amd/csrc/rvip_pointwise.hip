@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const T* __restrict__ x, 
                 float xv = 0.f;
                 if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
                     if constexpr (sizeof(T) == 4) xv = x[(img * h + yy) * w + xx];
-                    else xv = bf16_to_f32(x[(img * h + yy) * w + xx].bits);
+                    else xv = Vec<T>::dec(x[(img * h + yy) * w + xx].bits);
                 }
 #pragma unroll
                 for (int e = 0; e < VE; ++e) part[t][e] = fmaf(xv, g[e], part[t][e]);
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, c
             float xv = 0.f;
             if (dok && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) {
                 if constexpr (sizeof(T) == 4) xv = x[(ximg * h + gy) * w + gx];
-                else xv = bf16_to_f32(x[(ximg * h + gy) * w + gx].bits);
+                else xv = Vec<T>::dec(x[(ximg * h + gy) * w + gx].bits);
             }
             xs[i] = xv;
         }
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void c1_stage_kernel(C1Conv cv_, ApplyArgs ap,
             float xv = 0.f;
             if ((unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) {
                 if constexpr (sizeof(T) == 4) xv = x[(img * h + gy) * w + gx];
-                else xv = bf16_to_f32(x[(img * h + gy) * w + gx].bits);
+                else xv = Vec<T>::dec(x[(img * h + gy) * w + gx].bits);
             }
             xs[i] = xv;
         }
@@ -1262,14 +1262,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ th, const
     }
 }
 
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long long count, float scale) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < count; i += (long long)gridDim.x * 256) x[i] *= scale;
+}
 __global__ void state_tick_kernel(uint32_t* state) { if (threadIdx.x == 0 && blockIdx.x == 0) state[RVIP_STATE_STEP] += 1u; }
 
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ s, D* __restrict__ d, long long count) {
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
         float v;
-        if constexpr (sizeof(S) == 4) v = s[i]; else v = bf16_to_f32(s[i].bits);
-        if constexpr (sizeof(D) == 4) d[i] = v; else d[i].bits = f32_to_bf16(v);
+        if constexpr (sizeof(S) == 4) v = s[i]; else v = Vec<S>::dec(s[i].bits);
+        if constexpr (sizeof(D) == 4) d[i] = v; else d[i].bits = Vec<D>::enc(v);
     }
 }
 
@@ -1277,8 +1280,6 @@ __global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ s, D
 
 using namespace rvip;
 
-#define RVIP_VE(dt) ((dt) == RVIP_BF16 ? 8 : 4)
-#define RVIP_DT_OK(dt) ((dt) == RVIP_BF16 || (dt) == RVIP_F32)
 
 extern "C" size_t rvip_reduce_workspace(long long rows, int width) {
     (void)rows;
@@ -1297,6 +1298,7 @@ extern "C" int rvip_bn_train_stats(const void* z, long long rows, int c, int dty
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)z, rows, c, g, ws);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(bn_stats_kernel<f16_t>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)z, rows, c, g, ws);
     else hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)z, rows, c, g, ws);
     int rc = check_launch();
     if (rc) return rc;
@@ -1351,9 +1353,11 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     dim3 grid((unsigned)nb);
     if (d->pooled) {
         if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+        else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_apply_kernel<f16_t, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
         else hipLaunchKernelGGL((bn_apply_kernel<float, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
     } else {
         if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+        else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_apply_kernel<f16_t, false>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
         else hipLaunchKernelGGL((bn_apply_kernel<float, false>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
     }
     return check_launch();
@@ -1392,8 +1396,10 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     float* ws = (float*)d->workspace;
     if (a.pool_dp) {
         if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16_t, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     } else if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16_t, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     rc = check_launch();
     if (rc) return rc;
@@ -1414,8 +1420,10 @@ extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
     float* ws = defer ? d->bias_rows : (float*)d->workspace;
     if (a.pool_dp) {
         if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16_t, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     } else if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16_t, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     rc = check_launch();
     if (rc || defer) return rc;
@@ -1452,6 +1460,7 @@ extern "C" int rvip_maxpool2x2_bwd(const void* y, const void* dpooled, const voi
     dim3 grid((unsigned)cdiv(total, 256));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const unsigned char*)y, (const unsigned char*)dpooled, (const unsigned char*)add, (unsigned char*)dx, n, h, w, c);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16_t>, grid, dim3(256), 0, s, (const unsigned char*)y, (const unsigned char*)dpooled, (const unsigned char*)add, (unsigned char*)dx, n, h, w, c);
     else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, s, (const unsigned char*)y, (const unsigned char*)dpooled, (const unsigned char*)add, (unsigned char*)dx, n, h, w, c);
     return check_launch();
 }
@@ -1463,6 +1472,7 @@ static int launch_upsample(const void* src, void* dst, int n, int h, int w, int 
     dim3 grid((unsigned)cdiv(total, 256));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL((upsample_kernel<bf16_t, BWD>), grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL((upsample_kernel<f16_t, BWD>), grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
     else hipLaunchKernelGGL((upsample_kernel<float, BWD>), grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
     return check_launch();
 }
@@ -1483,6 +1493,7 @@ extern "C" int rvip_subsample_odd(const void* src, void* dst, int n, int h, int 
     dim3 grid((unsigned)cdiv(total, 256));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(subsample_odd_kernel<bf16_t>, grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(subsample_odd_kernel<f16_t>, grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
     else hipLaunchKernelGGL(subsample_odd_kernel<float>, grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, n, h, w, c);
     return check_launch();
 }
@@ -1505,6 +1516,7 @@ extern "C" int rvip_head_fwd(const void* x, const float* w, const float* b, floa
     hipStream_t s = (hipStream_t)stream;
     float* ws = y_true ? (float*)workspace : nullptr;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const unsigned char*)x, w, b, pred, y_true, rows, cin, k, chunk, ws);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(head_fwd_kernel<f16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const unsigned char*)x, w, b, pred, y_true, rows, cin, k, chunk, ws);
     else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const unsigned char*)x, w, b, pred, y_true, rows, cin, k, chunk, ws);
     int rc = check_launch();
     if (rc || !y_true) return rc;
@@ -1537,6 +1549,7 @@ extern "C" int rvip_bn_apply_head(const rvip_apply_desc* d, const float* head_w,
     float* ws = y_true ? (float*)workspace : nullptr;
     HeadFuse hd{head_w, head_b, nullptr, k};
     if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_apply_head_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
+    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL(bn_apply_head_kernel<f16_t>, dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
     else hipLaunchKernelGGL(bn_apply_head_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
     int rc = check_launch();
     if (rc || !y_true) return rc;
@@ -1566,6 +1579,7 @@ extern "C" int rvip_bn_bwd_reduce_head(const rvip_bnbwd_desc* d, const float* he
     float* ws_hd = ws_bn + (size_t)g.nblk * 2 * d->c;
     HeadFuse hd{head_w, nullptr, dlogit, k};
     if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_bwd_reduce_head_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
+    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL(bn_bwd_reduce_head_kernel<f16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
     else hipLaunchKernelGGL(bn_bwd_reduce_head_kernel<float>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
     int rc = check_launch();
     if (rc) return rc;
@@ -1594,6 +1608,7 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     float* ws = defer ? d->bias_rows : (float*)d->workspace;
     HeadFuse hd{head_w, nullptr, dlogit, k};
     if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_bwd_apply_head_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
+    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL(bn_bwd_apply_head_kernel<f16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
     else hipLaunchKernelGGL(bn_bwd_apply_head_kernel<float>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
     int rc = check_launch();
     if (rc || defer) return rc;
@@ -1622,6 +1637,7 @@ extern "C" int rvip_head_bwd(const void* x, const float* w, const float* dlogit,
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)x, w, dlogit, (unsigned char*)dx, rows, cin, k, g, ws);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(head_bwd_kernel<f16_t>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)x, w, dlogit, (unsigned char*)dx, rows, cin, k, g, ws);
     else hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)x, w, dlogit, (unsigned char*)dx, rows, cin, k, g, ws);
     int rc = check_launch();
     if (rc) return rc;
@@ -1644,6 +1660,7 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
         const int nb = (int)(nt < 1024 ? nt : 1024);
         if (workspace_bytes < (size_t)nb * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
         if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0);
+        else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_tiled<f16_t>, dim3(nb), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0);
         else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0);
         int rc2 = check_launch();
         if (rc2) return rc2;
@@ -1651,6 +1668,7 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
         return launch_fold_k<PostC1Wgrad>(ws, nb, cout, 9, p2, s);
     }
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_kernel<f16_t>, dim3(g.nblk), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     else hipLaunchKernelGGL(c1_wgrad_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     int rc = check_launch();
     if (rc) return rc;
@@ -1673,6 +1691,7 @@ extern "C" int rvip_conv3d_c1_wgrad(const void* x, const void* dy, float* dw, in
     float* ws = (float*)workspace;
     for (int kdi = 0; kdi < 3; ++kdi) {
         if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1);
+        else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_tiled<f16_t>, dim3(nb), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1);
         else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1);
         int rc = check_launch();
         if (rc) return rc;
@@ -1698,6 +1717,7 @@ static int c1_geom(const rvip_c1_desc* c, C1Conv& cv, int& nb) {
 template <int MODE>
 static int c1_launch(const rvip_c1_desc* c, const C1Conv& cv, const ApplyArgs& ap, const BnBwdArgs& bw, int nb, float* ws, hipStream_t s) {
     if (c->dtype == RVIP_BF16) hipLaunchKernelGGL((c1_stage_kernel<bf16_t, MODE>), dim3(nb), dim3(256), 0, s, cv, ap, bw, ws);
+    else if (c->dtype == RVIP_F16) hipLaunchKernelGGL((c1_stage_kernel<f16_t, MODE>), dim3(nb), dim3(256), 0, s, cv, ap, bw, ws);
     else hipLaunchKernelGGL((c1_stage_kernel<float, MODE>), dim3(nb), dim3(256), 0, s, cv, ap, bw, ws);
     return check_launch();
 }
@@ -1802,6 +1822,15 @@ extern "C" int rvip_adam_step(float* theta, const float* grad, float* m, float* 
     return check_launch();
 }
 
+extern "C" int rvip_scale_f32(float* x, long long count, float scale, void* stream) {
+    (void)hipGetLastError();
+    if (!x || count <= 0) return RVIP_EINVAL;
+    long long nb = cdiv(count, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, count, scale);
+    return check_launch();
+}
+
 extern "C" int rvip_state_tick(uint32_t* state, void* stream) {
     (void)hipGetLastError();
     if (!state) return RVIP_EINVAL;
@@ -1816,9 +1845,12 @@ extern "C" int rvip_convert(const void* src, int sdt, void* dst, int ddt, long l
     if (nb > 4096) nb = 4096;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)nb), blk(256);
-    if (sdt == RVIP_F32 && ddt == RVIP_BF16) hipLaunchKernelGGL((convert_kernel<float, bf16_t>), grid, blk, 0, s, (const float*)src, (bf16_t*)dst, count);
-    else if (sdt == RVIP_BF16 && ddt == RVIP_F32) hipLaunchKernelGGL((convert_kernel<bf16_t, float>), grid, blk, 0, s, (const bf16_t*)src, (float*)dst, count);
-    else if (sdt == RVIP_F32) hipLaunchKernelGGL((convert_kernel<float, float>), grid, blk, 0, s, (const float*)src, (float*)dst, count);
-    else hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)src, (bf16_t*)dst, count);
+    by_dtype(sdt, [&](auto ts) {
+        return by_dtype(ddt, [&](auto td) {
+            using S = decltype(ts); using D = decltype(td);
+            hipLaunchKernelGGL((convert_kernel<S, D>), grid, blk, 0, s, (const S*)src, (D*)dst, count);
+            return 0;
+        });
+    });
     return check_launch();
 }

@@ -113,14 +113,14 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(WgArgs a) {
                 }
                 const s16x4 g0 = tr_read(lg + gaddr[0]);
                 const s16x4 g1 = tr_read(lg + gaddr[1]);
-                const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const uint4 fb = __builtin_bit_cast(uint4, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int toff = ((t / 3) * HWD + (t % 3)) * ROWB;
                     const s16x4 x0 = tr_read(lx + xaddr[0] + toff);
                     const s16x4 x1 = tr_read(lx + xaddr[1] + toff);
-                    const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                    const uint4 fa = __builtin_bit_cast(uint4, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[t] = mfma16<T>(fa, fb, acc[t]);
                 }
             }
         } else {
@@ -328,14 +328,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
                 const int srow = (s * 16) / TW, scol = (s * 16) % TW;     // compile-time after unrolling
                 const s16x4 g0 = tr_read(gp[0] + s * 16 * RBG);
                 const s16x4 g1 = tr_read(gp[1] + s * 16 * RBG);
-                const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const uint4 fb = __builtin_bit_cast(uint4, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int off = ((srow + t / 3) * HWD + scol) * RBX;
                     const s16x4 x0 = tr_read(xp[t % 3][0] + off);
                     const s16x4 x1 = tr_read(xp[t % 3][1] + off);
-                    const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                    const uint4 fa = __builtin_bit_cast(uint4, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[t] = mfma16<T>(fa, fb, acc[t]);
                 }
             }
         } else {
@@ -560,14 +560,14 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
                 const int srow = (s * 16) / TW, scol = (s * 16) % TW;     // compile-time after unrolling
                 const s16x4 g0 = tr_read(gp[0] + s * 16 * RBG);
                 const s16x4 g1 = tr_read(gp[1] + s * 16 * RBG);
-                const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const uint4 fb = __builtin_bit_cast(uint4, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int off = ((srow + t / 3) * HWD + scol) * RBX;
                     const s16x4 x0 = tr_read(xp[t % 3][0] + off);
                     const s16x4 x1 = tr_read(xp[t % 3][1] + off);
-                    const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                    const uint4 fa = __builtin_bit_cast(uint4, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[t] = mfma16<T>(fa, fb, acc[t]);
                 }
             }
         } else {
@@ -687,13 +687,13 @@ struct Wg2Geom { int tw, cib, cob, tiles_x, tiles_y, ntiles, nsplit; bool ok; };
 static Wg2Geom wgrad2_geometry(int n, int h, int w, int c0, int c1, int cout, int dtype) {
     Wg2Geom g;
     const int cin = c0 + c1;
-    const int esz = dtype == RVIP_BF16 ? 2 : 4;
+    const int esz = RVIP_ESZ(dtype);
     const int wide = 128 / esz, narrow = 64 / esz;             // channels in a 128-byte / 64-byte row
     g.tw = w > 16 ? 32 : 16;
     const int th = 256 / g.tw;
     g.tiles_x = (int)cdiv(w, g.tw); g.tiles_y = (int)cdiv(h, th);
     g.ntiles = n * g.tiles_x * g.tiles_y;
-    if (dtype == RVIP_BF16) {
+    if (dtype != RVIP_F32) {
         g.cib = (cin >= wide && (c1 == 0 || c0 % wide == 0)) ? wide : narrow;
         g.cob = cout >= wide ? wide : narrow;
     } else {
@@ -779,8 +779,8 @@ extern "C" size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int
 extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     (void)hipGetLastError();
     if (!d || !d->x0 || !d->dy || !d->dw || !d->workspace) return RVIP_EINVAL;
-    if (d->dtype != RVIP_BF16 && d->dtype != RVIP_F32) return RVIP_EINVAL;
-    const int ve = d->dtype == RVIP_BF16 ? 8 : 4;
+    if (!RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
+    const int ve = RVIP_VE(d->dtype);
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->c0 <= 0) return RVIP_EINVAL;
     if (d->c0 % ve || d->c1 % ve || d->cout % ve) return RVIP_EINVAL;
     if ((d->c1 > 0) != (d->x1 != nullptr)) return RVIP_EINVAL;
@@ -796,7 +796,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     const int depth = d->depth > 0 ? d->depth : 1, kd = d->kd > 0 ? d->kd : 1;
     if ((kd != 1 && kd != 3) || d->n % depth) return RVIP_EINVAL;
     static const bool force_v1 = [] { const char* e = getenv("RVIP_WGRAD"); return e && e[0] == 'v' && e[1] == '1'; }();
-    const long long esz = d->dtype == RVIP_BF16 ? 2 : 4;
+    const long long esz = RVIP_ESZ(d->dtype);
     const long long x0b = (long long)a.n * (a.h >> a.up0) * (a.w >> a.up0) * a.c0 * esz, x1b = (long long)a.n * a.h * a.w * a.c1 * esz;
     const long long dyb = (long long)a.n * a.h * a.w * a.cout * esz;
     const Wg2Geom g2 = wgrad2_geometry(a.n, a.h, a.w, a.c0, a.c1, a.cout, d->dtype);
@@ -812,21 +812,22 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
         const long long count2 = 9LL * a.cin * a.cout;
         for (int kdi = 0; kdi < kd; ++kdi) {
             b.depth = depth; b.dshift = kdi - (kd >> 1);
-            if (d->dtype == RVIP_BF16) {
-                if (g2.tw == 32) {
-                    if (g2.cib == 64 && g2.cob == 64) rc = launch_wgrad2<bf16_t, 32, 64, 64>(b, s);
-                    else if (g2.cib == 64) rc = launch_wgrad2<bf16_t, 32, 64, 32>(b, s);
-                    else if (g2.cob == 64) rc = launch_wgrad2<bf16_t, 32, 32, 64>(b, s);
-                    else rc = launch_wgrad2<bf16_t, 32, 32, 32>(b, s);
+            rc = by_dtype(d->dtype, [&](auto t) {
+                using T = decltype(t);
+                if constexpr (sizeof(T) == 4) {
+                    return g2.tw == 32 ? launch_wgrad2<float, 32, 32, 32>(b, s) : launch_wgrad2<float, 16, 32, 32>(b, s);
+                } else if (g2.tw == 32) {
+                    if (g2.cib == 64 && g2.cob == 64) return launch_wgrad2<T, 32, 64, 64>(b, s);
+                    if (g2.cib == 64) return launch_wgrad2<T, 32, 64, 32>(b, s);
+                    if (g2.cob == 64) return launch_wgrad2<T, 32, 32, 64>(b, s);
+                    return launch_wgrad2<T, 32, 32, 32>(b, s);
                 } else {
-                    if (g2.cib == 64 && g2.cob == 64) rc = launch_wgrad2<bf16_t, 16, 64, 64>(b, s);
-                    else if (g2.cib == 64) rc = launch_wgrad2<bf16_t, 16, 64, 32>(b, s);
-                    else if (g2.cob == 64) rc = launch_wgrad2<bf16_t, 16, 32, 64>(b, s);
-                    else rc = launch_wgrad2<bf16_t, 16, 32, 32>(b, s);
+                    if (g2.cib == 64 && g2.cob == 64) return launch_wgrad2<T, 16, 64, 64>(b, s);
+                    if (g2.cib == 64) return launch_wgrad2<T, 16, 64, 32>(b, s);
+                    if (g2.cob == 64) return launch_wgrad2<T, 16, 32, 64>(b, s);
+                    return launch_wgrad2<T, 16, 32, 32>(b, s);
                 }
-            } else {
-                rc = g2.tw == 32 ? launch_wgrad2<float, 32, 32, 32>(b, s) : launch_wgrad2<float, 16, 32, 32>(b, s);
-            }
+            });
             if (rc) return rc;
             if (d->defer_fold && kd == 1) return RVIP_OK;      // slabs stay in the caller's workspace for rvip_fold_rows_batch
             rc = launch_wgrad_fold(a.slab, b.nsplit, count2, d->dw + (size_t)kdi * count2, s);
@@ -839,8 +840,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     wgrad_geometry(a.n, a.h, a.w, a.cin, a.cout, tw, a.tiles_x, a.tiles_y, a.ntiles, a.nsplit);
     const size_t need = (size_t)a.nsplit * 9 * a.cin * a.cout * sizeof(float);
     if (d->workspace_bytes < need) return RVIP_EWORKSPACE;
-    if (d->dtype == RVIP_BF16) rc = tw == 32 ? launch_wgrad<bf16_t, 32>(a, s) : launch_wgrad<bf16_t, 16>(a, s);
-    else rc = tw == 32 ? launch_wgrad<float, 32>(a, s) : launch_wgrad<float, 16>(a, s);
+    rc = by_dtype(d->dtype, [&](auto t) { return tw == 32 ? launch_wgrad<decltype(t), 32>(a, s) : launch_wgrad<decltype(t), 16>(a, s); });
     if (rc || d->defer_fold) return rc;
     const long long count = 9LL * a.cin * a.cout;
     return launch_wgrad_fold(a.slab, a.nsplit, count, d->dw, s);
@@ -848,10 +848,10 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
 
 // number of split-K slabs rvip_conv3x3_wgrad writes for this shape (rows of the deferred fold; 0 = invalid descriptor)
 extern "C" int rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d) {
-    if (!d || (d->dtype != RVIP_BF16 && d->dtype != RVIP_F32) || d->n <= 0 || d->h <= 0 || d->w <= 0) return 0;
+    if (!d || !RVIP_DT_OK(d->dtype) || d->n <= 0 || d->h <= 0 || d->w <= 0) return 0;
     static const bool force_v1 = [] { const char* e = getenv("RVIP_WGRAD"); return e && e[0] == 'v' && e[1] == '1'; }();
     const int up = d->up0 ? 1 : 0;
-    const long long esz = d->dtype == RVIP_BF16 ? 2 : 4;
+    const long long esz = RVIP_ESZ(d->dtype);
     const long long x0b = (long long)d->n * (d->h >> up) * (d->w >> up) * d->c0 * esz, x1b = (long long)d->n * d->h * d->w * d->c1 * esz;
     const long long dyb = (long long)d->n * d->h * d->w * d->cout * esz;
     const int kd = d->kd > 0 ? d->kd : 1;

@@ -52,8 +52,9 @@ class ParamStore:
     def __init__(self, plan, host_weights, dtype, device, seed=42, lr=1e-3):
         torch = require_gpu()
         self.plan, self.device = plan, device
-        self.dt = N.BF16 if dtype == 'bf16' else N.F32
-        self.tdtype = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self.dt = {'bf16': N.BF16, 'f16': N.F16, 'f32': N.F32}[dtype]
+        self.tdtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dtype]
+        self.grad_unscale = 1.0                   # 1 / loss scale of the engine that last wrote self.grad (f16 only)
         self.off, self.moff = OrderedDict(), OrderedDict()
         n_tr = n_mv = 0
         for (lname, wname, shape, trainable, _), arr in zip(plan.weight_specs(), host_weights):
@@ -153,7 +154,7 @@ class ParamStore:
         return flat.reshape(shape).copy()
 
     def grads_host(self):
-        g = self.grad.detach().cpu().numpy()
+        g = self.grad.detach().cpu().numpy() * np.float32(self.grad_unscale)
         return OrderedDict(((ln, wn), self._from_device(ln, wn, g[o:o + int(np.prod(s))], s)) for (ln, wn), (o, s) in self.off.items())
 
     def p(self, lname, wname):
@@ -210,11 +211,11 @@ class Engine:
         elif tuple(plan.f_size) != (3, 3) or tuple(plan.m_pool) != (2, 2):
             raise NotImplementedError('2-D graphs: F_SIZE (3,3) and M_POOL (2,2) are built')
         self.n = n = self.batch * self.depth
-        ve = 8 if P.dt == N.BF16 else 4
+        ve = 4 if P.dt == N.F32 else 8
         for st in plan.stages:
             if st.cout % ve or (st.src0 != 'input_1' and (st.c0 % ve or st.c1 % ve)):
                 raise ValueError('channel counts must be multiples of %d for %s activations (layer %s: %d -> %d)'
-                                 % (ve, 'bf16' if ve == 8 else 'f32', st.conv, st.cin, st.cout))
+                                 % (ve, '16-bit' if ve == 8 else 'f32', st.conv, st.cin, st.cout))
         if plan.img_channels != 1:
             raise NotImplementedError('IMG_CHANNELS != 1: the first-layer kernel is the Cin = 1 specialisation')
         dev, T = P.device, P.tdtype
@@ -317,13 +318,13 @@ class Engine:
             def append(self, item):
                 list.append(self, (item[0], item[1], self.label))
         fwd_t, fwd_i, bwd = _Labelled(), _Labelled(), _Labelled()
-        esz = 2 if dt == N.BF16 else 4
+        esz = 4 if dt == N.F32 else 2
         unbiased = 1 if self.kd == 1 else 0     # TF 2.3: fused 4-D BN feeds the unbiased variance to the moving average, 5-D does not
 
         # The last conv stage's BN output feeds only the 1x1 head: in training it is never materialised (rvip_bn_apply_head,
         # rvip_bn_bwd_*_head rebuild it / its gradient in registers).  Inference keeps the separate launches.
         last = plan.stages[-1]
-        ve_ = 8 if dt == N.BF16 else 4
+        ve_ = 4 if dt == N.F32 else 8
         cg_ = last.cout // ve_
         self.fuse_head = bool(last.bn and not last.pool and not (last.drop and last.drop[1] > 0) and last.y == plan.head['src']
                               and cg_ <= 64 and (cg_ & (cg_ - 1)) == 0 and os.environ.get('RVIP_FUSE_HEAD', '1') != '0')
@@ -439,9 +440,21 @@ class Engine:
         # ---------------- backward ----------------
         per_rank = float(n * hd['h'] * hd['w'] * hd['k'])
         self._inv_count = 1.0 / (per_rank * self.world)
+        # f16 activations: the loss gradient 2(p - y) p(1-p) / count is ~1e-7 at the benchmark shapes, below the f16 normal
+        # range.  Static loss scaling (the reference has no f16 path; this is the usual mixed-precision recipe): dlogit is
+        # multiplied by a power of two ~ count (so |dlogit| <= 0.5), every gradient of the step carries the factor, and the
+        # optimiser removes it exactly (rvip_adam_step grad_scale).  RVIP_LOSS_SCALE overrides.
+        if P.dt == N.F16:
+            env = os.environ.get('RVIP_LOSS_SCALE')
+            self.loss_scale = float(env) if env else float(2 ** int(np.floor(np.log2(per_rank * self.world))))
+        else:
+            self.loss_scale = 1.0
+        P.grad_unscale = 1.0 / self.loss_scale
         bwd.append((L.rvip_head_grad, (_ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), _ptr(self.dlogit), _ptr(self.loss),
                                        hrows, hd['k'], self.loss_kind, C.c_float(self._inv_count), C.c_float(1.0 / self.world),
                                        C.c_float(self.w_bce), C.c_float(self.w_dice))))
+        if self.loss_scale != 1.0:
+            bwd.append((L.rvip_scale_f32, (_ptr(self.dlogit), C.c_longlong(self.dlogit.numel()), C.c_float(self.loss_scale))))
         if not self.fuse_head:
             bwd.append((L.rvip_head_bwd, (_ptr(hx), hw_, _ptr(self.dlogit), _ptr(self.grd[hd['src']]), P.g(hd['conv'], 'kernel'),
                                           P.g(hd['conv'], 'bias'), hrows, hd['cin'], hd['k'], dt, ws, wsb)))
@@ -580,7 +593,7 @@ class Engine:
         flush_folds()
         self.fwd_train, self.fwd_infer, self.bwd = fwd_t, fwd_i, bwd
         self.opt = [(L.rvip_adam_step, (_ptr(P.theta), _ptr(P.grad), _ptr(P.adam_m), _ptr(P.adam_v), C.c_longlong(P.count),
-                                        C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0), _ptr(P.state)))]
+                                        C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0 / self.loss_scale), _ptr(P.state)))]
         if P.pack_entries:
             self.opt.append(P.pack_call())
         self.opt.append((L.rvip_state_tick, (_ptr(P.state),)))

@@ -62,7 +62,8 @@ class Model:
         self.metrics = []
         self.history = None
         cfg = plan.config
-        self.precision = {'bf16': 'bf16', 'bfloat16': 'bf16', 'fp32': 'f32', 'f32': 'f32', 'float32': 'f32'}[
+        self.precision = {'bf16': 'bf16', 'bfloat16': 'bf16', 'fp32': 'f32', 'f32': 'f32', 'float32': 'f32',
+                          'fp16': 'f16', 'f16': 'f16', 'float16': 'f16', 'half': 'f16'}[
             str(cfg.get('RVIP_PRECISION', 'bf16')).lower()]
         self.seed = int(cfg.get('SEED', 42))
         rng = np.random.default_rng(self.seed)

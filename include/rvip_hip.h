@@ -12,7 +12,7 @@
  *   - returns 0 (RVIP_OK) or a negative RVIP_E* code; never throws, never allocates, never syncs;
  *   - the CALLER owns every buffer (device memory) and passes the HIP stream (hipStream_t as void*);
  *     all work is enqueued on that stream; re-entrant across streams;
- *   - activations NHWC, dtype tag per call (RVIP_F32 / RVIP_BF16), accumulation always fp32;
+ *   - activations NHWC, dtype tag per call (RVIP_F32 / RVIP_BF16 / RVIP_F16), accumulation always fp32;
  *   - parameters (bias, BN gamma/beta/stats), gradients and optimiser state are fp32;
  *   - master conv kernels are Keras HWIO fp32 [kh][kw][Cin][Cout]; the MFMA kernels read "packed"
  *     copies in the activation dtype (rvip_pack_conv3x3_weights);
@@ -39,6 +39,7 @@ extern "C" {
 
 #define RVIP_F32  0
 #define RVIP_BF16 1
+#define RVIP_F16  2      /* IEEE binary16 storage, fp32 accumulate; the caller scales the loss gradient (rvip_adam_step grad_scale) */
 
 #define RVIP_ACT_NONE    0
 #define RVIP_ACT_RELU    1
@@ -344,6 +345,11 @@ int rvip_postprocess(const float* pred, uint8_t* flat, float* points, int* sizes
 int rvip_adam_step(float* theta, const float* grad, float* m, float* v, long long count,
                    float beta1, float beta2, float eps, float grad_scale, const uint32_t* state, void* stream);
 int rvip_state_tick(uint32_t* state, void* stream);
+
+/* x[i] *= scale over a flat fp32 buffer.  The RVIP_F16 path uses it for static loss scaling: dlogit (rvip_head_grad) is
+ * multiplied by a power of two before the backward pass and rvip_adam_step's grad_scale removes the factor again.  The
+ * reference has no half-precision path (TF 2.3 float32 throughout); this is the standard mixed-precision recipe. */
+int rvip_scale_f32(float* x, long long count, float scale, void* stream);
 
 /* dtype conversion of a flat buffer (host-side plumbing: generator batches are float32). */
 int rvip_convert(const void* src, int src_dtype, void* dst, int dst_dtype, long long count, void* stream);

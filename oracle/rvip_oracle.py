@@ -516,6 +516,14 @@ def bf16_round(a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy().astype(a.dtype)
 
 
+def f16_round(a, scale=1.0):
+    """Round-to-nearest-even to IEEE binary16 and back, at `scale` (storage emulation for the f16 device path; gradient
+    tensors are stored multiplied by the loss scale)."""
+    a = np.asarray(a)
+    with np.errstate(over='ignore'):
+        return ((a * scale).astype(np.float16).astype(a.dtype)) / a.dtype.type(scale)
+
+
 def knife_edges(layers, cache, rel=3e-6):
     """Elements at which a float32 evaluation may legitimately take the other branch of a non-smooth op: ReLU
     pre-activations within `rel` of zero (relative to the tensor scale) and 2x2 max-pool windows whose two largest
@@ -648,7 +656,7 @@ def gaussian_targets(mask_onehot, sigma):
 class OracleUNet:
     """Executes build_graph(config) with the primitives above."""
 
-    def __init__(self, config, params=None, seed=42, dtype=np.float32, quant=None):
+    def __init__(self, config, params=None, seed=42, dtype=np.float32, quant=None, quant_grad=None):
         """quant: optional storage-rounding emulation (e.g. ``bf16_round``).  It is applied exactly where the
         device path materialises a low-precision tensor: network input, packed 3x3 kernels (not the first
         Cin=1 layer, not the head: those read the fp32 masters), every conv output, the END of each fused
@@ -657,6 +665,7 @@ class OracleUNet:
         self.layers = build_graph(config)
         self.dtype = dtype
         self.quant = quant
+        self.quant_grad = quant_grad if quant_grad is not None else quant     # gradient tensors (f16: rounded at the loss scale)
         consumers = {}
         for l in self.layers:
             for i in l['inputs']:
@@ -760,7 +769,7 @@ class OracleUNet:
                 continue
             dy = dt.pop(name)
             ins = l['inputs']
-            q = self.quant
+            q = self.quant_grad
             if q is not None and (name in self._mat or ty in ('UpSampling2D', 'UpSampling3D', 'Concatenate')):
                 dy = q(dy)                                  # a materialised gradient tensor (sum rounded once)
             if ty == 'InputLayer':
@@ -768,7 +777,7 @@ class OracleUNet:
             if ty in ('Conv2D', 'Conv3D'):
                 w, _ = self.params[name]
                 if q is not None and name in self._qweights:
-                    w = q(w)
+                    w = self.quant(w)
                 dpre = dy if (name == 'unet' and d_is_logit_grad) else act_bwd(t[name], dy, l['activation'])
                 if q is not None and name != 'unet':
                     dpre = q(dpre)                          # dz: what wgrad / dgrad read

@@ -280,11 +280,11 @@ def test_full_size_step_is_deterministic_and_finite():
 
 
 def test_cfg4_shape_step_is_deterministic_and_finite():
-    """BASELINE.json configs[3] shape (512x512, F=64, depth 5; bf16 stands in for fp16, batch 8): parameter count of
-    SURVEY.md 8(d) (138 376 578), bit-identical repeat of fwd+bwd from identical state, finite loss after two
-    optimizer steps."""
+    """BASELINE.json configs[3] shape (512x512, F=64, depth 5, fp16 MFMA path with static loss scaling, batch 8):
+    parameter count of SURVEY.md 8(d) (138 376 578), bit-identical repeat of fwd+bwd from identical state, finite
+    gradients well inside the f16 range, finite and decreasing loss over optimizer steps."""
     cfg = dict(DIM=[512, 512], FILTERS=64, DEPTH=5, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2,
-               LEARNING_RATE=1e-4, RVIP_PRECISION='bf16', LOSS_FUNCTION=M.mse, SEED=1)
+               LEARNING_RATE=1e-4, RVIP_PRECISION='fp16', LOSS_FUNCTION=M.mse, SEED=1)
     model = rvip.get_model(cfg, metrics=[])
     assert model.count_params() == 138376578
     G = rvip.Generators.SyntheticSAXGenerator(8, dict(DIM=[512, 512], BATCHSIZE=8, GAUS=True, SIGMA=2, SHUFFLE=False))
@@ -299,9 +299,71 @@ def test_cfg4_shape_step_is_deterministic_and_finite():
         outs.append((eng.loss.clone(), eng.pred.clone(), model._params.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     assert torch.isfinite(outs[0][2]).all() and float(outs[0][2].abs().max()) > 0
-    l0 = model.train_on_batch(x, y)[0]
-    l1 = model.train_on_batch(x, y)[0]
-    assert np.isfinite(l0) and np.isfinite(l1)
+    # the scaled activation gradients the f16 tensors carry sit in the middle of the f16 range (tools/diag_f16_range.py)
+    gmax = max(float(t.float().abs().max()) for t in eng.grd.values() if t is not None and t.dtype == torch.float16)
+    assert eng.loss_scale == 2.0 ** 22 and 1e-2 < gmax < 1e3, gmax
+    ls = [model.train_on_batch(x, y)[0] for _ in range(4)]
+    assert np.all(np.isfinite(ls)) and ls[-1] < ls[0], ls
+
+
+def test_f16_path_matches_f16_storage_emulation():
+    """f16 device path (RVIP_PRECISION='fp16': IEEE half activations / packed weights, fp32 accumulation and master weights,
+    static loss scale) vs the oracle with binary16 rounding applied at every tensor the device materialises in f16 --
+    gradient tensors rounded at the loss scale.  Differences: summation order only (rare 1-ulp flips); against the exact
+    oracle every element carries 2^-12."""
+    cfg = _cfg(RVIP_PRECISION='fp16', FILTERS=16, DIM=[64, 64])
+    model = rvip.get_model(cfg, metrics=[])
+    _, layers = _oracle_from(model, cfg)
+    params = _oracle_from(model, cfg)[0].params
+    B = 4
+    eng = model._engine(B)
+    S = eng.loss_scale
+    assert S == 2.0 ** 15                               # 2^floor(log2(4*64*64*2))
+    emu = O.OracleUNet(cfg, params, dtype=np.float64, quant=O.f16_round, quant_grad=lambda a: O.f16_round(a, S))
+    exact = O.OracleUNet(cfg, params, dtype=np.float64)
+    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=5)
+    eng.load_input(x, y)
+    eng.forward(training=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    masks = _masks(layers, B, model.seed, 0)
+    lv, egrads, epred, _ = emu.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', masks)
+    _, xgrads, xpred, _ = exact.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', masks)
+    pred = eng.pred.cpu().numpy()
+    err_emu, err_exact = np.abs(pred - epred), np.abs(pred - xpred)
+    assert abs(float(eng.loss.item()) - lv) < 1e-3 * lv
+    assert err_emu.mean() < 1e-3 and err_emu.max() < 0.05, (err_emu.mean(), err_emu.max())
+    assert err_emu.mean() < 0.7 * err_exact.mean(), (err_emu.mean(), err_exact.mean())
+    got = model._params.grads_host()                    # unscaled by ParamStore.grad_unscale
+    for lname in ('conv2d', 'conv2d_1', 'conv2d_3', 'conv2d_5', 'conv2d_8', 'unet'):
+        rel = np.linalg.norm(got[(lname, 'kernel')] - egrads[lname][0]) / np.linalg.norm(egrads[lname][0])
+        rel_x = np.linalg.norm(got[(lname, 'kernel')] - xgrads[lname][0]) / np.linalg.norm(xgrads[lname][0])
+        assert rel < 0.7 * rel_x + 0.01 and rel < 0.1, (lname, rel, rel_x)     # rel_x: rounding moves ReLU masks / max-pool winners
+    # one optimizer step: Adam sees the UNSCALED gradient.  First Keras-Adam step: dtheta = -lr * g / (|g| + eps / sqrt(1 - beta2))
+    # -- a gradient still carrying the loss scale would give -lr * sign(g) everywhere.
+    w0 = model.get_weights()[0].copy()
+    model.train_on_batch(x, y)
+    dw = model.get_weights()[0] - w0
+    g0 = got[('conv2d', 'kernel')].astype(np.float64)               # the device's own gradient of that step, unscaled
+    want = -cfg['LEARNING_RATE'] * g0 / (np.abs(g0) + 1e-7 / np.sqrt(1e-3))
+    assert (np.abs(want) < 0.9 * cfg['LEARNING_RATE']).sum() > 5     # some elements are not saturated at +-lr
+    np.testing.assert_allclose(dw, want, rtol=2e-3, atol=1e-7)
+
+
+def test_f16_loss_curve_tracks_the_float64_oracle():
+    """Fifteen Adam steps, f16 device path vs the float64 oracle (same start, same dropout masks): same loss curve."""
+    cfg = _cfg(RVIP_PRECISION='fp16', FILTERS=16, DIM=[64, 64], LEARNING_RATE=1e-3)
+    model = rvip.get_model(cfg, metrics=[])
+    ref, layers = _oracle_from(model, cfg)
+    B = 4
+    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=12)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    dev_losses, ref_losses = [], []
+    for step in range(15):
+        dev_losses.append(model.train_on_batch(x, y)[0])
+        lv, _ = ref.train_step(x64, y64, 'mse', _masks(layers, B, model.seed, step))
+        ref_losses.append(lv)
+    np.testing.assert_allclose(np.array(dev_losses), np.array(ref_losses), rtol=1e-2)
 
 
 def test_fit_with_generator_and_callbacks(tmp_path):

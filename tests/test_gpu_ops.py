@@ -29,17 +29,17 @@ def P(t):
 
 
 def tdt(dtype):
-    return torch.bfloat16 if dtype == 'bf16' else torch.float32
+    return {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dtype]
 
 
 def ndt(dtype):
-    return N.BF16 if dtype == 'bf16' else N.F32
+    return {'bf16': N.BF16, 'f16': N.F16, 'f32': N.F32}[dtype]
 
 
 def rnd(a, dtype):
-    """what the device will actually see: bf16-rounded (as float32) or unchanged"""
+    """what the device will actually see: rounded to the 16-bit storage type (as float32) or unchanged"""
     t = torch.from_numpy(np.ascontiguousarray(a, np.float32))
-    return t.to(torch.bfloat16).to(torch.float32).numpy() if dtype == 'bf16' else t.numpy()
+    return t.to(tdt(dtype)).to(torch.float32).numpy()
 
 
 def up(a, dtype):
@@ -57,7 +57,7 @@ def down(t):
 
 def close(got, ref, dtype, what=''):
     scale = max(float(np.abs(ref).max()), 1e-6)
-    tol = (2.0 ** -7 if dtype == 'bf16' else 2e-5) * scale
+    tol = {'bf16': 2.0 ** -7, 'f16': 2.0 ** -10, 'f32': 2e-5}[dtype] * scale      # one output rounding + accumulation order
     err = float(np.abs(got - ref).max())
     assert err <= tol, '%s: max err %.3e > tol %.3e (scale %.3e)' % (what, err, tol, scale)
 
@@ -90,7 +90,7 @@ SHAPES = [  # n, h, w, cin, cout
 ]
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', SHAPES)
 def test_conv3x3_fwd_dgrad_wgrad(shape, dtype):
     n, h, w, ci, co = shape
@@ -126,7 +126,7 @@ def test_conv3x3_fwd_dgrad_wgrad(shape, dtype):
     N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
     got = down(dw)
     scale = float(np.abs(rdw).max())
-    assert np.abs(got - rdw).max() <= (2e-3 if dtype == 'bf16' else 2e-5) * scale, np.abs(got - rdw).max() / scale
+    assert np.abs(got - rdw).max() <= (2e-3 if dtype != 'f32' else 2e-5) * scale, np.abs(got - rdw).max() / scale
     dw2 = torch.empty_like(dw)
     g.dw = dw2.data_ptr()
     N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
@@ -147,7 +147,7 @@ def pack_all(w, dtype):
     return wf, wd
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(2, 4, 24, 40, 8, 8), (1, 3, 16, 16, 16, 40), (2, 5, 40, 36, 72, 64), (1, 1, 16, 16, 8, 8)])
 def test_conv3d_fwd_dgrad_wgrad(shape, dtype):
     """Conv3D(3x3x3, 'same') (KerasLayers.py:679 with 3 DIM entries; cfg 5) = the 3x3 implicit GEMM with a K loop over
@@ -187,10 +187,10 @@ def test_conv3d_fwd_dgrad_wgrad(shape, dtype):
     N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
     got = down(dw)
     scale = float(np.abs(rdw).max())
-    assert np.abs(got - rdw).max() <= (2e-3 if dtype == 'bf16' else 2e-5) * scale, np.abs(got - rdw).max() / scale
+    assert np.abs(got - rdw).max() <= (2e-3 if dtype != 'f32' else 2e-5) * scale, np.abs(got - rdw).max() / scale
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_conv3d_first_layer(dtype):
     nb, dep, h, w, co = 2, 3, 20, 40, 16
     n = nb * dep
@@ -213,7 +213,7 @@ def test_conv3d_first_layer(dtype):
     assert np.abs(down(dw) - rdw).max() <= 2e-5 * float(np.abs(rdw).max())
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(2, 40, 72, 32, 32), (3, 16, 16, 32, 24), (2, 24, 40, 8, 8),
                                    (2, 40, 72, 32, 64), (1, 16, 16, 64, 72), (2, 8, 40, 16, 128), (1, 32, 32, 256, 96)])   # two channel tiles per workgroup
 def test_conv3x3_fused_batchnorm_statistics(shape, dtype):
@@ -251,7 +251,7 @@ def test_conv3x3_fused_batchnorm_statistics(shape, dtype):
     np.testing.assert_allclose(down(scale), gamma * cache[1], rtol=1e-5)
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_conv3x3_virtual_upsample_concat_and_split(dtype):
     """UpSampling2D + Conv2D and Concatenate + Conv2D as addressing modes; dgrad of the concat conv writes the
     two halves of the gradient to separate tensors."""
@@ -291,13 +291,13 @@ def test_conv3x3_virtual_upsample_concat_and_split(dtype):
     g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
     N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
     scale = float(np.abs(rdw).max())
-    assert np.abs(down(dw) - rdw).max() <= (2e-3 if dtype == 'bf16' else 2e-5) * scale
+    assert np.abs(down(dw) - rdw).max() <= (2e-3 if dtype != 'f32' else 2e-5) * scale
     ups = torch.empty((n, h, w, c0), dtype=tdt(dtype), device=dev())
     N.call('rvip_upsample2x_fwd', P(lod), P(ups), n, h // 2, w // 2, c0, ndt(dtype), stream())
     np.testing.assert_array_equal(down(ups), O.upsample_nearest_fwd(lo))
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(2, 24, 40, 32, 64), (1, 16, 16, 16, 40), (2, 8, 72, 8, 8),       # igemm v2: 512 px, TW=16, 256 px
                                    (1, 32, 64, 16, 256), (2, 16, 16, 8, 256), (1, 8, 40, 8, 264)])   # igemm v3 (K >= 256): same three tilings
 def test_conv3x3_dgrad_with_fused_2x2_sum(shape, dtype):
@@ -317,7 +317,7 @@ def test_conv3x3_dgrad_with_fused_2x2_sum(shape, dtype):
     close(down(glo), O.upsample_nearest_bwd(rdx), dtype, 'down2 dgrad')
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(2, 48, 80, 32, 32), (1, 32, 32, 16, 40), (2, 16, 72, 8, 8), (1, 64, 64, 72, 64)])
 def test_upsample_conv_subpixel_form(shape, dtype):
     """UpSampling2D(2) -> Conv2D(3x3, same) (KerasLayers.py:756-758) as four 2x2-tap phase convolutions on the
@@ -338,11 +338,11 @@ def test_upsample_conv_subpixel_form(shape, dtype):
     ref = O.act_fwd(O.conv2d_same_fwd(O.upsample_nearest_fwd(lo).astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), 'relu')
     got = down(y)
     scale = float(np.abs(ref).max())
-    tol = (2.0 ** -6 if dtype == 'bf16' else 2e-5) * scale      # bf16: + one rounding of the summed taps
+    tol = (2.0 ** -6 if dtype != 'f32' else 2e-5) * scale      # bf16: + one rounding of the summed taps
     assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max() / scale
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(2, 12, 20, 16, 8), (1, 8, 8, 8, 24)])
 def test_conv2d_transpose_as_zero_stuffed_conv(shape, dtype):
     """Conv2DTranspose(3, strides=2, 'same') = the 3x3 igemm over the zero-stuffed read (up0 = 2) with the kernel in its
@@ -382,10 +382,10 @@ def test_conv2d_transpose_as_zero_stuffed_conv(shape, dtype):
     g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
     N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
     dw_hwoi = down(dw).transpose(0, 1, 3, 2)[::-1, ::-1]                  # back to Keras' layout
-    assert np.abs(dw_hwoi - rdw).max() <= (2e-3 if dtype == 'bf16' else 2e-5) * np.abs(rdw).max()
+    assert np.abs(dw_hwoi - rdw).max() <= (2e-3 if dtype != 'f32' else 2e-5) * np.abs(rdw).max()
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_first_layer_c1(dtype):
     n, h, w, co = 2, 20, 36, 16
     rng = np.random.default_rng(4)
@@ -409,7 +409,7 @@ def test_first_layer_c1(dtype):
     assert np.abs(down(dw) - rdw).max() <= 2e-5 * np.abs(rdw).max()
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('act_after', [0, 1])
 def test_batchnorm_dropout_pool_forward_backward(dtype, act_after):
     n, h, w, c = 3, 12, 20, 16
@@ -487,7 +487,7 @@ def test_batchnorm_dropout_pool_forward_backward(dtype, act_after):
         g = g * (yact > 0)
     dxr, dgr, dbr = O.bn_train_bwd(g, gamma.astype(np.float64), cache)
     dconv = dxr if act_after else dxr * (z64 > 0)
-    tolr = 1e-2 if dtype == 'bf16' else 1e-4
+    tolr = 1e-2 if dtype != 'f32' else 1e-4
     np.testing.assert_allclose(down(dgamma), dgr, atol=tolr * np.abs(dgr).max())
     np.testing.assert_allclose(down(dbeta), dbr, atol=tolr * np.abs(dbr).max())
     close(down(dz), dconv, dtype, 'bn bwd dz')
@@ -505,7 +505,7 @@ def test_batchnorm_dropout_pool_forward_backward(dtype, act_after):
     assert z_act is not None
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('act_after', [0, 1])
 @pytest.mark.parametrize('with_skip', [0, 1])
 def test_bn_backward_with_fused_maxpool_backward(dtype, act_after, with_skip):
@@ -564,7 +564,7 @@ def test_bn_backward_with_fused_maxpool_backward(dtype, act_after, with_skip):
         g = g * (ybn > 0)
     dxr, dgr, dbr = O.bn_train_bwd(g, gamma.astype(np.float64), cache)
     dconv = dxr if act_after else dxr * (z64 > 0)
-    tolr = 1e-2 if dtype == 'bf16' else 1e-4
+    tolr = 1e-2 if dtype != 'f32' else 1e-4
     np.testing.assert_allclose(down(dgamma), dgr, atol=tolr * np.abs(dgr).max())
     np.testing.assert_allclose(down(dbeta), dbr, atol=tolr * np.abs(dbr).max())
     close(down(dz), dconv, dtype, 'bn bwd dz with fused pool bwd')
@@ -573,7 +573,7 @@ def test_bn_backward_with_fused_maxpool_backward(dtype, act_after, with_skip):
     assert L.rvip_bn_bwd_apply(C.byref(b), stream()) == N.EINVAL if hasattr(N, 'EINVAL') else L.rvip_bn_bwd_apply(C.byref(b), stream()) != 0
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('loss', ['mse', 'bce_dice'])
 def test_head_loss_and_backward(dtype, loss):
     n, h, w, cin, k = 3, 16, 24, 16, 2
@@ -709,7 +709,7 @@ def test_postprocess_flat_labels_cc_filter_and_points(cc):
     np.testing.assert_array_equal(sizes.cpu().numpy(), np.stack([(ref == v + 1).sum((1, 2)) for v in range(k)], 1))
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('act_after', [0, 1])
 def test_last_stage_fused_with_head_matches_the_separate_kernels(dtype, act_after):
     """rvip_bn_apply_head / rvip_bn_bwd_reduce_head / rvip_bn_bwd_apply_head (the stage's BN output and its gradient
@@ -784,5 +784,5 @@ def test_last_stage_fused_with_head_matches_the_separate_kernels(dtype, act_afte
     np.testing.assert_allclose(down(hdb1), down(hdb0), rtol=1e-4, atol=1e-7)
     for t1, t0, nm in zip(out1[1:], out0[1:], ('dgamma', 'dbeta', 'dbias', 'coef')):
         sc_ = float(np.abs(down(t0)).max())
-        np.testing.assert_allclose(down(t1), down(t0), atol=(2e-3 if dtype == 'bf16' else 1e-5) * sc_ + 1e-9, err_msg=nm)
+        np.testing.assert_allclose(down(t1), down(t0), atol=(2e-3 if dtype != 'f32' else 1e-5) * sc_ + 1e-9, err_msg=nm)
     close(down(out1[0]), down(out0[0]).astype(np.float64), dtype, 'dz fused vs separate')
