@@ -338,3 +338,21 @@ def test_post_threshold_restatement():
     assert np.isnan(pts[1, 0]).all() and np.isnan(pts[2]).all()
     raw = O.mean_rvip_points(flat)                                                  # without the filter: slice 1 has no zero
     assert np.isnan(raw[1, 0]).all() and not np.isnan(raw[1, 1]).any()
+
+
+def test_storage_rounding_emulations_match_torch_casts():
+    """bf16_round / f16_round (the storage emulations the GPU parity tests hand to OracleUNet) are round-to-nearest-even
+    casts; f16_round at a loss scale rounds the SCALED value (what the f16 gradient tensors hold)."""
+    import torch
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal(4096) * np.exp(rng.uniform(-12, 8, 4096))).astype(np.float64)
+    t = torch.from_numpy(a.astype(np.float32))
+    assert np.array_equal(O.bf16_round(a), t.to(torch.bfloat16).to(torch.float64).numpy())
+    assert np.array_equal(O.f16_round(a), t.to(torch.float16).to(torch.float64).numpy())
+    S = 2.0 ** 15
+    tiny = a * 1e-9                                      # below the f16 range unscaled ...
+    assert np.count_nonzero(O.f16_round(tiny)) < np.count_nonzero(tiny) // 2
+    got = O.f16_round(tiny, S)                           # ... representable at the scale
+    want = (torch.from_numpy((tiny * S).astype(np.float32)).to(torch.float16).to(torch.float64) / S).numpy()
+    assert np.array_equal(got, want)
+    assert np.isinf(O.f16_round(np.array([1e5]))).all()  # overflow is visible, not clipped
