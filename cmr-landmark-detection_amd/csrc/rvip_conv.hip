@@ -991,7 +991,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
 }
 
 template <typename T, int TW, int NCT, int NPIX, int TAPS = 9, int NCW = 4>
-static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry) {
+static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry, int wgpc = 1) {
     constexpr int TH = NPIX / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int IN_BYTES = NHROWS * 64, W_BYTES = TAPS * NCT * 32 * 64;
@@ -1036,7 +1036,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     const int cot = (int)cdiv(a0.cout, NCT * 32);
     if (cot > 1) b.nt_in = 0;       // several workgroup columns re-read the same input tile: keep it cached (measured)
     constexpr int NZ = TAPS == 4 ? 4 : 1;
-    int gx = 256 / (cot * NZ);
+    int gx = 256 * wgpc / (cot * NZ);              // wgpc workgroups per CU (LDS / VGPR budget checked by the caller)
     if (gx < 1) gx = 1;
     if (gx > b.ntiles) gx = b.ntiles;
     b.stats = stats;
@@ -1061,6 +1061,11 @@ static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float
         return two ? launch_igemm_ws<T, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry);
     }
     if (a.w > 16 && a.h >= 16) {
+        // HBM-bound shape (one K chunk, 32 output channels, e.g. 32 -> 32 at 256x256): two 8-wave workgroups per CU on
+        // 256-pixel tiles (63 KB of LDS, <= 128 VGPRs each) so that one's epilogue overlaps the other's loads
+        static const bool occ2 = [] { const char* e = getenv("RVIP_L0_OCC2"); return e && e[0] == '1'; }();
+        if (occ2 && wide && !two && a.kd == 1 && a.cin <= 64 / (int)sizeof(T) && (long long)a.n * a.h * a.w >= 512 * 1024)
+            return launch_igemm_ws<T, 32, 1, 256>(a, s, used, stats, rows_out, dry, 2);
         if (wide) return two ? launch_igemm_ws<T, 32, 2, 512, 9, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512, 9, 8>(a, s, used, stats, rows_out, dry);
         return two ? launch_igemm_ws<T, 32, 2, 512>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512>(a, s, used, stats, rows_out, dry);
     }
