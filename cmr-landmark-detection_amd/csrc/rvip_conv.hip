@@ -726,7 +726,15 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
             wch[i] = (co < a.cout && row < WROWS) ? (dslot ^ ((row >> 2) & 3)) * VE : 1 << 28;
             wrel[i] = (((tap * a.cout + co) * a.cin) + (dslot ^ ((row >> 2) & 3)) * VE) * (int)sizeof(T);
         }
-        int ihy[QI], ihx[QI], irel0[QI], ich[QI];
+        // The loaders' own instructions are the critical path of staging (profiles/r01_conv_ablation.txt: one K chunk in flight
+        // per workgroup, and every instruction of these waves is issued in the shadow of two MFMA-bound waves), so whatever does
+        // not depend on the K chunk is hoisted: per wave the tile-independent byte offsets of its pieces, per TILE the offsets
+        // with the image-border test folded in (t0 / t1: offset inside the tile's window of source 0 / 1, or OOB), computed in
+        // the idle window after the tile's predecessor has issued its last chunk.  A full chunk then costs one v_add per piece.
+        unsigned wfast[QW];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) wfast[i] = (wch[i] != (1 << 28)) ? (unsigned)wrel[i] : OOB;
+        int ihy[QI], ihx[QI], irel0[QI], irel1[QI], ich[QI];
 #pragma unroll
         for (int i = 0; i < QI; ++i) {
             const int row = (lwv + 4 * i) * 16 + drow;
@@ -735,56 +743,90 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
             ihy[i] = (row < NHALO) ? hy - 1 : -100000;
             ihx[i] = hx - 1;
             irel0[i] = ((((hy - 1) >> a.up0) * w0 + ((hx - 1) >> a.up0)) * a.c0 + ich[i]) * (int)sizeof(T);
+            irel1[i] = (((hy - 1) * a.w + (hx - 1)) * a.c1 + ich[i]) * (int)sizeof(T);
         }
+        unsigned t0[QI], t1[QI];                         // prepared tile: per-piece offsets (border test folded in)
+        int p_nmod = 0, p_tb0 = 0, p_tb1 = 0;
+        const int img0_bytes = h0 * w0 * a.c0 * (int)sizeof(T), img1_bytes = a.h * a.w * a.c1 * (int)sizeof(T);
+        auto prep_tile = [&](int tile) __attribute__((always_inline)) {
+            unsigned bx = (unsigned)tile;
+            const unsigned tx_i = bx % (unsigned)a.tiles_x; bx /= (unsigned)a.tiles_x;
+            const unsigned ty_i = bx % (unsigned)a.tiles_y;
+            const int n_out = (int)(bx / (unsigned)a.tiles_y);
+            const int ty0 = (int)ty_i * TH, tx0 = (int)tx_i * TW;
+            p_nmod = a.depth > 1 ? n_out % a.depth : 0;
+            p_tb0 = ((n_out * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 * (int)sizeof(T);
+            p_tb1 = ((n_out * a.h + ty0) * a.w + tx0) * a.c1 * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < QI; ++i) {
+                const int gy = ty0 + ihy[i], gx = tx0 + ihx[i];
+                const bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+                const bool ok0 = a.zs ? (ok && ((gy & gx) & 1)) : ok;
+                t0[i] = ok0 ? (unsigned)irel0[i] : OOB;
+                t1[i] = ok ? (unsigned)irel1[i] : OOB;
+            }
+        };
         auto issue_weights = [&](int kc, int wstage) __attribute__((always_inline)) {
-            const int kdi = kc / nch;
+            const int kdi = a.kd > 1 ? kc / nch : 0;
             const int cbase = (kc - kdi * nch) * KCE;
             const int tapbase = ((kdi + ph) * TAPS * a.cout * a.cin + cbase) * (int)sizeof(T);
+            const unsigned lw0 = lds_base + 2 * IN_BYTES + wstage * W_BYTES + lwv * 1024;      // + i * 4096 per piece
+            if (a.cin - cbase >= KCE) {                  // full chunk: valid rows carry all their channels
 #pragma unroll
-            for (int i = 0; i < QW; ++i) {
-                const int q = lwv + 4 * i;
-                if (q < NQW) {
-                    const unsigned off = (wch[i] < a.cin - cbase) ? (unsigned)(wrel[i] + tapbase) : OOB;
-                    dma16(rsw, off, lds_base + 2 * IN_BYTES + wstage * W_BYTES + q * 1024);
+                for (int i = 0; i < QW; ++i) {
+                    if (i < QW - 1 || lwv + 4 * i < NQW) dma16(rsw, wfast[i] + (unsigned)tapbase, lw0 + i * 4096);   // OOB + tapbase stays >= 2^31
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < QW; ++i) {
+                    if (i < QW - 1 || lwv + 4 * i < NQW) {
+                        const unsigned off = (wch[i] < a.cin - cbase) ? (unsigned)(wrel[i] + tapbase) : OOB;
+                        dma16(rsw, off, lw0 + i * 4096);
+                    }
                 }
             }
         };
-        auto issue_input = [&](int tile, int kc, int stage) __attribute__((always_inline)) {
-            int bx = tile;
-            const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
-            const int ty_i = bx % a.tiles_y;
-            const int n_out = bx / a.tiles_y;
-            const int ty0 = ty_i * TH, tx0 = tx_i * TW;
-            const int kdi = kc / nch;
+        // stages chunk kc of the PREPARED tile
+        auto issue_input = [&](int kc, int stage) __attribute__((always_inline)) {
+            const int kdi = a.kd > 1 ? kc / nch : 0;
             const int dsh = kdi - (a.kd >> 1);               // depth tap: the image dsh slices away, zeros outside the volume
-            const int n = n_out + dsh;
-            const bool dok = (unsigned)(n_out % a.depth + dsh) < (unsigned)a.depth;
+            const bool dok = (unsigned)(p_nmod + dsh) < (unsigned)a.depth;
             const int cbase = (kc - kdi * nch) * KCE;
             const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
             const int cb = from0 ? cbase : cbase - a.c0;
             const int crem = dok ? (from0 ? a.c0 : a.c1) - cb : 0;
-            const int base = from0 ? (((n * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 + cb) * (int)sizeof(T)
-                                   : (((n * a.h + ty0) * a.w + tx0) * a.c1 + cb) * (int)sizeof(T);
-            const bool zs = from0 && a.zs;
-            const i32x4 rs = from0 ? rs0 : rs1;
+            const unsigned li0 = lds_base + stage * IN_BYTES + lwv * 1024;                      // + i * 4096 per piece
+            const unsigned base = (unsigned)((from0 ? p_tb0 + dsh * img0_bytes : p_tb1 + dsh * img1_bytes) + cb * (int)sizeof(T));
+            if (crem >= KCE && !a.nt_in) {                   // full chunk inside the volume: offset = prepared + base
+                if (from0) {
 #pragma unroll
-            for (int i = 0; i < QI; ++i) {
-                const int q = lwv + 4 * i;
-                if (q < NQI) {
-                    const int gy = ty0 + ihy[i], gx = tx0 + ihx[i];
-                    bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && ich[i] < crem;
-                    if (zs) ok = ok && ((gy & gx) & 1);
-                    int rel = irel0[i];
-                    if (!from0) rel = ((ihy[i] * a.w + ihx[i]) * a.c1 + ich[i]) * (int)sizeof(T);
-                    const unsigned off = ok ? (unsigned)(base + rel) : OOB;
-                    if (a.nt_in) dma16_nt(rs, off, lds_base + stage * IN_BYTES + q * 1024);
-                    else dma16(rs, off, lds_base + stage * IN_BYTES + q * 1024);
+                    for (int i = 0; i < QI; ++i) {
+                        if (i < QI - 1 || lwv + 4 * i < NQI) dma16(rs0, t0[i] + base, li0 + i * 4096);   // OOB + base stays >= 2^31
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < QI; ++i) {
+                        if (i < QI - 1 || lwv + 4 * i < NQI) dma16(rs1, t1[i] + base, li0 + i * 4096);
+                    }
+                }
+            } else {                                         // partial chunk / depth tap outside the volume / streaming hint
+                const i32x4 rs = from0 ? rs0 : rs1;
+#pragma unroll
+                for (int i = 0; i < QI; ++i) {
+                    if (i < QI - 1 || lwv + 4 * i < NQI) {
+                        const unsigned t = from0 ? t0[i] : t1[i];
+                        const unsigned off = (t != OOB && ich[i] < crem) ? t + base : OOB;
+                        if (a.nt_in) dma16_nt(rs, off, li0 + i * 4096);
+                        else dma16(rs, off, li0 + i * 4096);
+                    }
                 }
             }
         };
         if (resident) for (int kc = 0; kc < nchunks; ++kc) issue_weights(kc, kc);
         else issue_weights(0, 0);
-        issue_input(first_tile, 0, 0);
+        prep_tile(first_tile);
+        issue_input(0, 0);
+        if (nchunks == 1 && first_tile + (int)gridDim.x < a.ntiles) prep_tile(first_tile + gridDim.x);
         int it = 0;
         for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
             for (int kc = 0; kc < nchunks; ++kc, ++it) {
@@ -794,8 +836,10 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                 int ntile = tile, nkc = kc + 1;
                 if (nkc == nchunks) { nkc = 0; ntile = tile + gridDim.x; }
                 if (ntile < a.ntiles && !(a.dbg & 1)) {
-                    issue_input(ntile, nkc, (it + 1) & 1);
+                    issue_input(nkc, (it + 1) & 1);          // the prepared tile is ntile (see below)
                     if (!resident) issue_weights(nkc, (it + 1) & 1);
+                    // ntile's last chunk is on its way: prepare its successor while the DMAs fly
+                    if (nkc == nchunks - 1 && ntile + (int)gridDim.x < a.ntiles) prep_tile(ntile + gridDim.x);
                 }
             }
         }
