@@ -205,6 +205,34 @@ def test_reference_default_config_224_fp32_forward():
     assert np.isfinite(loss)
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_reference_default_config_224_low_precision_training(precision):
+    """The template config's shape (224 -> 112 -> 56 -> 28 -> 14: ragged against the 32 x 16 / 16 x 16 pixel tiles at every
+    level) on the 16-bit paths: heat-maps within the storage precision of the fp32 path's, a repeated step is bit-identical,
+    and a few Adam steps on one batch lower the loss."""
+    cfg = dict(DIM=[224, 224], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
+               MASK_CLASSES=2, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-3, RVIP_PRECISION=precision,
+               LOSS_FUNCTION=M.mse, SEED=42)
+    model = rvip.get_model(cfg, metrics=[])
+    ref32 = rvip.get_model(dict(cfg, RVIP_PRECISION='fp32'), metrics=[])
+    ref32.set_weights(model.get_weights())
+    x, y = O.synthetic_batch(2, cfg['DIM'], 2, seed=42)
+    d = np.abs(model.predict(x) - ref32.predict(x))
+    assert d.max() < (0.08 if precision == 'bf16' else 0.02) and d.mean() < (8e-3 if precision == 'bf16' else 2e-3), (d.max(), d.mean())
+    eng = model._engine(2)
+    outs = []
+    for _ in range(2):
+        eng.load_input(x, y)
+        eng.forward(training=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        outs.append((eng.loss.clone(), eng.pred.clone(), model._params.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert torch.isfinite(outs[0][2]).all()
+    ls = [model.train_on_batch(x, y)[0] for _ in range(6)]
+    assert np.all(np.isfinite(ls)) and ls[-1] < ls[0], ls
+
+
 def _assert_landmarks_and_masks(pg, pr, eps=2e-5):
     """argmax indices and >0.5 masks must be IDENTICAL, except where the reference itself is within `eps` (fp32
     rounding of a different summation order) of a tie / of the threshold."""
