@@ -15,6 +15,7 @@
 //                  (exact fp32, k-ordered fma chain; the k <-> channel map only has to agree between
 //                  the two operands, and both read the same 16-byte channel group).
 #include "rvip_common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace rvip {
@@ -204,7 +205,7 @@ template <typename T, int TW, int NCT>
 static int launch_igemm(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 256 / TW;
     constexpr int lds = (TW + 2) * (TH + 2) * 80 + 9 * NCT * 32 * 80;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};      // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm<T, TW, NCT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1066,7 +1067,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     b.lds_bias_off = 2 * IN_BYTES + (res ? nchunks : 2) * W_BYTES;
     const int lds = b.lds_bias_off + 256;
     if (lds > LDS_MAX) return RVIP_OK;
-    static int attr_lds = 0;
+    static std::atomic<int> attr_lds{0};             // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!dry && lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, false, TAPS, NCW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
@@ -1149,7 +1150,7 @@ static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float
     b.lds_bias_off = 2 * IN_BYTES + (res ? nchunks : 2) * W_BYTES;
     const int lds = b.lds_bias_off + 256;
     if (lds > LDS_MAX) return RVIP_OK;
-    static int attr_lds = 0;
+    static std::atomic<int> attr_lds{0};             // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!dry && lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma<T, TW, NCT, NW, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);

@@ -12,6 +12,7 @@
 // The four waves' accumulators are folded through LDS in a fixed order, each workgroup writes one fp32
 // slab [9][Cin][Cout], and a second kernel sums the slabs in split order: bitwise reproducible.
 #include "rvip_common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace rvip {
@@ -722,7 +723,7 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
     constexpr int lds = NST * ST;
     static_assert(lds <= 160 * 1024, "LDS");
     static_assert(2 * ST >= 4 * 9 * 32 * 32 * 4 || true, "fold buffer");
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};      // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!attr_done) {
         hipError_t e = WS ? hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                           : hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma<T, TW, CIB, COB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -752,7 +753,7 @@ static int launch_wgrad(const WgArgs& a, hipStream_t s) {
     constexpr int rowb = 32 * (int)sizeof(T);
     constexpr int lds_tiles = (TW + 2) * (TH + 2) * rowb + 256 * rowb;
     constexpr int lds = lds_tiles > 9 * 32 * 32 * 4 ? lds_tiles : 9 * 32 * 32 * 4;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};      // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<T, TW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
