@@ -1246,12 +1246,20 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const T* __restrict__ x
 // first layer, tiled form: the 8x32-pixel tile's 10x34 halo of the single input channel sits in LDS, a thread owns
 // one channel vector for good (its 9 x VE weights stay in registers) and walks pixels/tiles; a wave stores 1 KiB
 // of contiguous NHWC output per instruction.
-template <typename T>
+// STATS: the BatchNormalization statistics of the stored output ride along -- every thread keeps the sum and the sum of squares
+// of its channel vector over the pixels it produced, the workgroup folds its pixel slots through LDS and writes one partial
+// row stats[blockIdx.x][2][cout] (finish with rvip_bn_stats_finalize): saves the 134 MB re-read of rvip_bn_train_stats.
+template <typename T, bool STATS = false>
 __global__ __launch_bounds__(256) void conv3x3_c1_tiled(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, unsigned char* y,
-                                                        int n, int h, int wd, int cout, int act, int tiles_x, int tiles_y) {
+                                                        int n, int h, int wd, int cout, int act, int tiles_x, int tiles_y,
+                                                        float* __restrict__ stats = nullptr) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float xs[10 * 34];
+    __shared__ float red[STATS ? 256 * VE : 1];
+    float ssum[VE], ssq[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) ssum[e] = ssq[e] = 0.f;
     const int tid = threadIdx.x, cg = cout / VE, cv = tid % cg, ps = tid / cg, pps = 256 / cg;
     float wr[9][VE], br[VE];
 #pragma unroll
@@ -1286,8 +1294,29 @@ __global__ __launch_bounds__(256) void conv3x3_c1_tiled(const T* __restrict__ x,
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc = fmaf(xin[t], wr[t][e], acc);
                 v[e] = act_fwd(acc, act);
+                if constexpr (STATS) {
+                    const float q = Vec<T>::round(v[e]);          // statistics of what is stored
+                    ssum[e] += q;
+                    ssq[e] = fmaf(q, q, ssq[e]);
+                }
             }
             Vec<T>::store(y + ((((size_t)img * h + gy) * wd + gx) * cout + cv * VE) * sizeof(T), v);
+        }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            __syncthreads();
+            if (ps < pps) {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) red[ps * cout + cv * VE + e] = k == 0 ? ssum[e] : ssq[e];
+            }
+            __syncthreads();
+            for (int col = tid; col < cout; col += 256) {
+                float t = 0.f;
+                for (int r = 0; r < pps; ++r) t += red[r * cout + col];
+                stats[((size_t)blockIdx.x * 2 + k) * cout + col] = t;
+            }
         }
     }
 }
@@ -1575,9 +1604,9 @@ extern "C" int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* b
         const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
         long long nt = (long long)n * tx * ty;
         dim3 g2((unsigned)(nt < 2048 ? nt : 2048));
-        if (dtype == RVIP_BF16) hipLaunchKernelGGL(conv3x3_c1_tiled<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty);
-        else if (dtype == RVIP_F16) hipLaunchKernelGGL(conv3x3_c1_tiled<f16_t>, g2, dim3(256), 0, s, (const f16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty);
-        else hipLaunchKernelGGL(conv3x3_c1_tiled<float>, g2, dim3(256), 0, s, (const float*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty);
+        if (dtype == RVIP_BF16) hipLaunchKernelGGL((conv3x3_c1_tiled<bf16_t, false>), g2, dim3(256), 0, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty, (float*)nullptr);
+        else if (dtype == RVIP_F16) hipLaunchKernelGGL((conv3x3_c1_tiled<f16_t, false>), g2, dim3(256), 0, s, (const f16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty, (float*)nullptr);
+        else hipLaunchKernelGGL((conv3x3_c1_tiled<float, false>), g2, dim3(256), 0, s, (const float*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty, (float*)nullptr);
         return check_launch();
     }
     dim3 grid((unsigned)cdiv(total, 256));
@@ -1585,6 +1614,36 @@ extern "C" int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* b
     else if (dtype == RVIP_F16) hipLaunchKernelGGL(conv3x3_c1_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act);
     else if (dtype == RVIP_F32) hipLaunchKernelGGL(conv3x3_c1_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act);
     else return RVIP_EINVAL;
+    return check_launch();
+}
+
+static int c1_tiled_blocks(int n, int h, int w_) {
+    const long long nt = (long long)n * cdiv(w_, 32) * cdiv(h, 8);
+    return (int)(nt < 2048 ? nt : 2048);
+}
+
+// rows of partial statistics rvip_conv3x3_c1_fwd_stats writes (0 = the shape runs on the untiled kernel: use rvip_bn_train_stats)
+extern "C" int rvip_conv3x3_c1_fwd_stats_rows(int n, int h, int w_, int cout, int dtype) {
+    if (!RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w_ <= 0 || cout <= 0) return 0;
+    const int ve = RVIP_VE(dtype);
+    if (cout % ve || 256 % (cout / ve)) return 0;
+    return c1_tiled_blocks(n, h, w_);
+}
+
+extern "C" int rvip_conv3x3_c1_fwd_stats(const void* x, const float* w, const float* bias, void* y, int n, int h, int w_, int cout,
+                                         int act, int dtype, float* stats_ws, size_t stats_ws_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !w || !y || !stats_ws) return RVIP_EINVAL;
+    const int rows = rvip_conv3x3_c1_fwd_stats_rows(n, h, w_, cout, dtype);
+    if (rows <= 0) return RVIP_EUNSUPPORTED;
+    if (stats_ws_bytes < (size_t)rows * 2 * cout * sizeof(float)) return RVIP_EWORKSPACE;
+    const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
+    hipStream_t s = (hipStream_t)stream;
+    by_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((conv3x3_c1_tiled<T, true>), dim3((unsigned)rows), dim3(256), 0, s, (const T*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty, stats_ws);
+        return 0;
+    });
     return check_launch();
 }
 

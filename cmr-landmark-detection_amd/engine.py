@@ -370,10 +370,17 @@ class Engine:
                 call = (L.rvip_conv3x3_fwd, (C.byref(d),))
             # ---- BN statistics / coefficients ----
             fused_rows = 0
-            if st.bn and not first and os.environ.get('RVIP_FUSE_STATS', '1') != '0':
+            fuse_stats = st.bn and os.environ.get('RVIP_FUSE_STATS', '1') != '0'
+            if fuse_stats and not first:
                 fused_rows = L.rvip_conv3x3_fwd_stats_rows(C.byref(d))     # > 0: the LDS-DMA igemm folds them in its epilogue
+            elif fuse_stats and self.kd == 1 and not self.fuse_first:
+                fused_rows = L.rvip_conv3x3_c1_fwd_stats_rows(n, st.h, st.w, st.cout, dt)       # first layer (Cin = 1), tiled kernel
             if fused_rows > 0:
-                fwd_t.append((L.rvip_conv3x3_fwd_stats, (C.byref(d), ws, wsb)))
+                if first:
+                    fwd_t.append((L.rvip_conv3x3_c1_fwd_stats, (_ptr(self.act['input_1']), P.p(st.conv, 'kernel'), bias, _ptr(z),
+                                                                n, st.h, st.w, st.cout, act_conv, dt, ws, wsb)))
+                else:
+                    fwd_t.append((L.rvip_conv3x3_fwd_stats, (C.byref(d), ws, wsb)))
                 fwd_t.append((L.rvip_bn_stats_finalize, (
                     ws, fused_rows, C.c_longlong(rows), st.cout, P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'),
                     P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), unbiased,

@@ -164,6 +164,13 @@ int rvip_fold_rows_batch(const void* table, int entries, long long max_width, in
  * workspace for wgrad: rvip_reduce_workspace(n*h*w, 16*cout) bytes. */
 int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* bias, void* y,
                         int n, int h, int w_, int cout, int act, int dtype, void* stream);
+
+/* The same first layer with the BatchNormalization statistics of its stored output fused in (as rvip_conv3x3_fwd_stats):
+ * writes rvip_conv3x3_c1_fwd_stats_rows(...) partial rows [rows][2][cout]; finish with rvip_bn_stats_finalize.
+ * rows == 0: Cout / VE does not divide 256 (untiled kernel) -- use rvip_conv3x3_c1_fwd + rvip_bn_train_stats. */
+int rvip_conv3x3_c1_fwd_stats_rows(int n, int h, int w, int cout, int dtype);
+int rvip_conv3x3_c1_fwd_stats(const void* x, const float* w, const float* bias, void* y, int n, int h, int w_, int cout,
+                              int act, int dtype, float* stats_ws, size_t stats_ws_bytes, void* stream);
 int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cout,
                           int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* The same first layer of the 3-D graph: Conv3D(3x3x3, 'same') with Cin = 1 on n = N*depth slices (volumes of `depth`

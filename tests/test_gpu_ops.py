@@ -386,6 +386,39 @@ def test_conv2d_transpose_as_zero_stuffed_conv(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(2, 20, 36, 16), (3, 256, 256, 32), (1, 9, 70, 64)])
+def test_first_layer_c1_fused_batchnorm_statistics(shape, dtype):
+    """rvip_conv3x3_c1_fwd_stats + rvip_bn_stats_finalize = rvip_conv3x3_c1_fwd + the statistics of the stored tensor
+    (ragged tiles, more tiles than workgroups at 256 x 256)."""
+    n, h, w, co = shape
+    rng = np.random.default_rng(41)
+    x = rnd(rng.random((n, h, w, 1)), dtype)
+    wt = (rng.standard_normal((3, 3, 1, co)) * 0.5).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    xd, wtd, bd = up(x, dtype), f32(wt), f32(b)
+    y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    y2 = torch.empty_like(y)
+    L = N.lib()
+    rows = L.rvip_conv3x3_c1_fwd_stats_rows(n, h, w, co, ndt(dtype))
+    assert rows > 0
+    ws = torch.full((rows * 2 * co + 16,), 123.0, dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_c1_fwd_stats', P(xd), P(wtd), P(bd), P(y), n, h, w, co, N.ACT['relu'], ndt(dtype), P(ws), C.c_size_t(rows * 2 * co * 4), stream())
+    N.call('rvip_conv3x3_c1_fwd', P(xd), P(wtd), P(bd), P(y2), n, h, w, co, N.ACT['relu'], ndt(dtype), stream())
+    assert torch.equal(y, y2)                                            # the stored tensor is the plain kernel's, bit for bit
+    gamma = (1 + 0.3 * rng.standard_normal(co)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(co)).astype(np.float32)
+    gd, btd, mm, mv = f32(gamma), f32(beta), f32(np.zeros(co)), f32(np.ones(co))
+    mean, invstd, scale, shift = (torch.empty(co, dtype=torch.float32, device=dev()) for _ in range(4))
+    N.call('rvip_bn_stats_finalize', P(ws), rows, C.c_longlong(n * h * w), co, P(gd), P(btd), P(mm), P(mv), 0.99, 1e-3, 1,
+           P(mean), P(invstd), P(scale), P(shift), stream())
+    yq = down(y).astype(np.float64)
+    _, cache = O.bn_train_fwd(yq, gamma.astype(np.float64), beta.astype(np.float64))
+    np.testing.assert_allclose(down(mean), cache[2], atol=3e-6 * max(1.0, np.abs(cache[2]).max()))
+    np.testing.assert_allclose(down(invstd), cache[1], rtol=2e-5)
+    assert N.lib().rvip_conv3x3_c1_fwd_stats(P(xd), P(wtd), P(bd), P(y), n, h, w, co, 1, ndt(dtype), P(ws), C.c_size_t(16), stream()) == -3   # RVIP_EWORKSPACE
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_first_layer_c1(dtype):
     n, h, w, co = 2, 20, 36, 16
     rng = np.random.default_rng(4)
