@@ -96,6 +96,7 @@ SIGNATURES = {
     'rvip_pack_conv3x3_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_pack_subpixel_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'rvip_pack_all_conv3x3_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    'rvip_pack_all_conv3x3_weights_tick': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     'rvip_conv3x3_wgrad_workspace': (C.c_size_t, [C.c_int] * 5),
     'rvip_conv3x3_wgrad': (C.c_int, [C.POINTER(Wgrad3x3Desc), vp]),
     'rvip_conv3x3_wgrad_splits': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),

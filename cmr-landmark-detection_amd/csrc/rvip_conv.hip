@@ -1406,9 +1406,12 @@ struct PackEntry { long long w_off; long long f_off; long long d_off; int cin, c
 // w_fwd.  (The element-per-thread form scattered 2-byte stores Cin apart: 1.5 ms for the 138 M parameters of cfg 4.)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__ theta, const PackEntry* __restrict__ tab,
-                                                       T* __restrict__ wf_base, T* __restrict__ wd_base) {
+                                                       T* __restrict__ wf_base, T* __restrict__ wd_base, uint32_t* tick) {
     constexpr int TI = 32, TO = 64, LDW = TO + 1;
     __shared__ float tile[TI * LDW];
+    // the optimiser step's closing launch also counts the step (nothing in this kernel reads the counter; its readers --
+    // Adam's bias correction and the dropout keys of the next step -- are ordered before / after this launch by the stream)
+    if (tick && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) tick[RVIP_STATE_STEP] += 1u;
     const PackEntry en = tab[blockIdx.y];
     const float* w = theta + en.w_off;
     T* wf = wf_base + en.f_off;
@@ -1678,18 +1681,28 @@ extern "C" int rvip_pack_subpixel_weights(const float* w, int cin, int cout, int
     return check_launch();
 }
 
-extern "C" int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
-                                             void* wf_base, void* wd_base, void* stream) {
+static int pack_all_launch(const float* theta, const void* table, int entries, int max_elems, int dtype,
+                           void* wf_base, void* wd_base, uint32_t* tick, void* stream) {
     (void)hipGetLastError();
-    if (!theta || !table || entries <= 0 || max_elems <= 0 || !wf_base || !wd_base) return RVIP_EINVAL;
+    if (!theta || !table || entries <= 0 || max_elems <= 0 || !wf_base || !wd_base || !RVIP_DT_OK(dtype)) return RVIP_EINVAL;
     long long nb = cdiv(max_elems, 32 * 64);                   // tiles of the largest kernel; smaller ones leave blocks idle
     if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     dim3 grid((unsigned)nb, (unsigned)entries);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == RVIP_BF16) hipLaunchKernelGGL(pack_all_kernel<bf16_t>, grid, dim3(256), 0, s, theta, (const PackEntry*)table, (bf16_t*)wf_base, (bf16_t*)wd_base);
-    else if (dtype == RVIP_F16) hipLaunchKernelGGL(pack_all_kernel<f16_t>, grid, dim3(256), 0, s, theta, (const PackEntry*)table, (f16_t*)wf_base, (f16_t*)wd_base);
-    else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_all_kernel<float>, grid, dim3(256), 0, s, theta, (const PackEntry*)table, (float*)wf_base, (float*)wd_base);
-    else return RVIP_EINVAL;
+    by_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(pack_all_kernel<T>, grid, dim3(256), 0, s, theta, (const PackEntry*)table, (T*)wf_base, (T*)wd_base, tick);
+        return 0;
+    });
     return check_launch();
+}
+extern "C" int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
+                                             void* wf_base, void* wd_base, void* stream) {
+    return pack_all_launch(theta, table, entries, max_elems, dtype, wf_base, wd_base, nullptr, stream);
+}
+extern "C" int rvip_pack_all_conv3x3_weights_tick(const float* theta, const void* table, int entries, int max_elems, int dtype,
+                                                  void* wf_base, void* wd_base, uint32_t* state, void* stream) {
+    if (!state) return RVIP_EINVAL;
+    return pack_all_launch(theta, table, entries, max_elems, dtype, wf_base, wd_base, state, stream);
 }

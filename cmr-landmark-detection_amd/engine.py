@@ -601,9 +601,11 @@ class Engine:
         self.fwd_train, self.fwd_infer, self.bwd = fwd_t, fwd_i, bwd
         self.opt = [(L.rvip_adam_step, (_ptr(P.theta), _ptr(P.grad), _ptr(P.adam_m), _ptr(P.adam_v), C.c_longlong(P.count),
                                         C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0 / self.loss_scale), _ptr(P.state)))]
-        if P.pack_entries:
-            self.opt.append(P.pack_call())
-        self.opt.append((L.rvip_state_tick, (_ptr(P.state),)))
+        if P.pack_entries:                                       # re-layout of the updated kernels; the same launch counts the step
+            fn, args = P.pack_call()
+            self.opt.append((L.rvip_pack_all_conv3x3_weights_tick, args + (_ptr(P.state),)))
+        else:
+            self.opt.append((L.rvip_state_tick, (_ptr(P.state),)))
 
     # -- execution ------------------------------------------------------------------------------------
     @staticmethod

@@ -128,6 +128,10 @@ int rvip_pack_subpixel_weights(const float* w_hwio, int cin, int cout, int dtype
 typedef struct rvip_pack_entry { long long w_off, f_off, d_off; int32_t cin, cout; int32_t taps, mode; } rvip_pack_entry;
 int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
                                   void* wf_base, void* wd_base, void* stream);
+/* The same launch as the closing one of an optimiser step: also increments state[RVIP_STATE_STEP] (= rvip_state_tick,
+ * without its launch).  Must follow rvip_adam_step on the same stream. */
+int rvip_pack_all_conv3x3_weights_tick(const float* theta, const void* table, int entries, int max_elems, int dtype,
+                                       void* wf_base, void* wd_base, uint32_t* state, void* stream);
 
 /* Weight gradient of the same conv (autodiff of KerasLayers.py:683,689,758):
  *   dw[t][i][o] = sum_{n,h,w} X[n,h+t/3-1,w+t%3-1,i] * dy[n,h,w,o],   X = virtual [up(x0), x1]

@@ -667,6 +667,24 @@ def test_head_loss_and_backward(dtype, loss):
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), O.threshold_mask(pr))
 
 
+def test_pack_all_with_step_tick_is_pack_all_plus_state_tick():
+    rng = np.random.default_rng(8)
+    w = rng.standard_normal((3, 3, 16, 24)).astype(np.float32)
+    wf0, wd0 = pack_all(w, 'bf16')
+    wm = f32(w)
+    wf, wd = torch.empty_like(wf0), torch.empty_like(wd0)
+    tab = (N.PackEntry * 1)()
+    tab[0].w_off, tab[0].f_off, tab[0].d_off, tab[0].cin, tab[0].cout, tab[0].taps = 0, 0, 0, 16, 24, 9
+    tabd = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev())
+    state = torch.zeros(N.STATE_WORDS, dtype=torch.int32, device=dev())
+    state[N.STATE_STEP] = 41
+    for _ in range(2):
+        N.call('rvip_pack_all_conv3x3_weights_tick', P(wm), P(tabd), 1, 9 * 16 * 24, N.BF16, P(wf), P(wd), P(state), stream())
+    torch.cuda.synchronize()
+    assert int(state[N.STATE_STEP]) == 43 and torch.equal(wf, wf0) and torch.equal(wd, wd0)
+    assert N.lib().rvip_pack_all_conv3x3_weights_tick(P(wm), P(tabd), 1, 9 * 16 * 24, N.BF16, P(wf), P(wd), None, stream()) == -1
+
+
 def test_adam_state_and_convert():
     rng = np.random.default_rng(7)
     cnt = 10007
