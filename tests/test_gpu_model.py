@@ -378,6 +378,24 @@ def test_f16_path_matches_f16_storage_emulation():
     np.testing.assert_allclose(dw, want, rtol=2e-3, atol=1e-7)
 
 
+def test_f16_bce_dice_loss_curve_tracks_the_float64_oracle():
+    """The f16 path with the reference's other loss (bce_dice_loss: the dice term's gradient is not a per-pixel 1/count
+    quantity, the static loss scale multiplies the whole dlogit tensor): ragged 48 x 40 maps, depth 3, eight Adam steps."""
+    cfg = _cfg(RVIP_PRECISION='fp16', FILTERS=16, DEPTH=3, DIM=[48, 40], LEARNING_RATE=1e-3, LOSS_FUNCTION=M.bce_dice_loss)
+    model = rvip.get_model(cfg, metrics=[])
+    ref, layers = _oracle_from(model, cfg)
+    B = 4
+    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=21)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    dev_losses, ref_losses = [], []
+    for step in range(8):
+        dev_losses.append(model.train_on_batch(x, y)[0])
+        lv, _ = ref.train_step(x64, y64, 'bce_dice', _masks(layers, B, model.seed, step))
+        ref_losses.append(lv)
+    np.testing.assert_allclose(np.array(dev_losses), np.array(ref_losses), rtol=2e-2, atol=2e-3)
+    assert ref_losses[-1] < ref_losses[0]
+
+
 def test_f16_loss_curve_tracks_the_float64_oracle():
     """Fifteen Adam steps, f16 device path vs the float64 oracle (same start, same dropout masks): same loss curve."""
     cfg = _cfg(RVIP_PRECISION='fp16', FILTERS=16, DIM=[64, 64], LEARNING_RATE=1e-3)
