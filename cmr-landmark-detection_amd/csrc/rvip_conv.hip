@@ -1035,7 +1035,405 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
     }
 }
 
-template <typename T, int TW, int NCT, int NPIX, int TAPS = 9, int NCW = 4>
+// ---------------------------------------------------------------------------------------------
+// igemm v5 (bf16 / f16): v4's producer / consumer structure on v_mfma_f32_16x16x32 instead of 32x32x16.  Same LDS stages,
+// DMA pieces, barriers and FLOPs; MI355X_MICROARCH.md measures 1.12-1.15 x the FLOP/s for the 16x16x32 shape with LDS-fed
+// operands (equal cycles, lower power, higher clock), and a timing mock-up of this kernel agreed (-9 % over the conv family).
+// One tap of a 32-channel chunk is exactly one K = 32 step: lane (i16, kq) reads the 16-byte slot kq of row i16 of a
+// 16-row block, so the 64-byte rows are read whole by four lanes.  Slot swizzle: physical slot = logical ^ 2 * bit2(row or
+// halo x) -- conflict-free for ds_read_b128's four lane groups at every tap shift (searched exhaustively); the DMA pieces
+// are written with the same mask.  Accumulators: f32x4 per (16-channel block, 16-pixel block), lane = pixel i16, registers =
+// channels 4 kq + r.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int slot_swz(int x) { return ((x >> 2) & 1) << 1; }
+// sum over the 16 lanes of a row of a[r] (4 values per lane): lane i16 is left with the total of r = 2 bit3(i16) + bit2(i16)
+__device__ __forceinline__ float lane16_channel_sum(const float (&a)[4], int i16) {
+    const bool b3 = i16 & 8, b2 = i16 & 4;
+    const float k0 = (b3 ? a[2] : a[0]) + swz<8>(b3 ? a[0] : a[2]);
+    const float k1 = (b3 ? a[3] : a[1]) + swz<8>(b3 ? a[1] : a[3]);
+    float e = (b2 ? k1 : k0) + swz<4>(b2 ? k0 : k1);
+    e += swz<2>(e);
+    return e + swz<1>(e);
+}
+template <typename T, int TW, int NCT, int NPIX, bool STATS, int TAPS = 9, int NCW = 4>
+__global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs2 a) {
+    static_assert(sizeof(T) == 2, "16-bit storage types");
+    static_assert(TAPS == 9 || TAPS == 4, "taps");
+    constexpr int TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
+    constexpr int NHROWS = (NHALO + 15) / 16 * 16;
+    constexpr int BN = NCT * 32, WROWS = TAPS * BN;
+    constexpr int IN_BYTES = NHROWS * 64, W_BYTES = WROWS * 64;
+    constexpr int VE = Vec<T>::VE, KCE = 4 * VE;
+    constexpr int NQI = NHROWS / 16, NQW = WROWS / 16;                 // 1 KiB DMA pieces per stage
+    constexpr int QI = (NQI + 3) / 4, QW = (NQW + 3) / 4;              // per loader wave
+    constexpr int NPT = NPIX / (32 * NCW);                              // 32-pixel tiles per compute wave
+    static_assert(NPT >= 1 && NPT * 32 * NCW == NPIX, "pixel tiles");
+    static_assert(TW == 32 ? (NPT % 2 == 0) : true, "whole tile rows per wave");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lin = smem;                       // [2][IN_BYTES]
+    unsigned char* lw = smem + 2 * IN_BYTES;         // [wres or 2][W_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * BN;
+    const int ph = (TAPS == 4) ? (int)blockIdx.z : 0, pa = ph >> 1, pb = ph & 1;      // output phase of the sub-pixel form
+    const int nch = (a.cin + KCE - 1) / KCE;         // chunks per depth tap
+    const int nchunks = nch * a.kd;
+    const bool resident = a.wres > 0;
+    const int first_tile = blockIdx.x;
+    if (first_tile >= a.ntiles) return;
+    float* lbias = reinterpret_cast<float*>(smem + a.lds_bias_off);        // [BN] bias of this output-channel tile
+    if (tid < BN) lbias[tid] = (a.bias && co0 + tid < a.cout) ? a.bias[co0 + tid] : 0.f;
+
+    if (wv >= NCW) {
+        // ------------------------------------------------ loader waves ------------------------------------------------
+        const int lwv = wv - NCW;
+        const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
+        const i32x4 rs0 = make_rsrc(a.x0, a.x0_bytes);
+        const i32x4 rs1 = make_rsrc(a.x1 ? a.x1 : a.x0, a.x1 ? a.x1_bytes : 0u);
+        const i32x4 rsw = make_rsrc(a.wp, a.wp_bytes);
+        const unsigned lds_base = lds_offset_of(smem);
+        const int drow = lane >> 2, dslot = lane & 3;
+        int wrel[QW], wch[QW];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            const int row = (lwv + 4 * i) * 16 + drow;
+            const int tap = row / BN, co = co0 + (row & (BN - 1));
+            wch[i] = (co < a.cout && row < WROWS) ? (dslot ^ slot_swz(row)) * VE : 1 << 28;
+            wrel[i] = (((tap * a.cout + co) * a.cin) + (dslot ^ slot_swz(row)) * VE) * (int)sizeof(T);
+        }
+        // The loaders' own instructions are the critical path of staging (profiles/r01_conv_ablation.txt: one K chunk in flight
+        // per workgroup, and every instruction of these waves is issued in the shadow of two MFMA-bound waves), so whatever does
+        // not depend on the K chunk is hoisted: per wave the tile-independent byte offsets of its pieces, per TILE the offsets
+        // with the image-border test folded in (t0 / t1: offset inside the tile's window of source 0 / 1, or OOB), computed in
+        // the idle window after the tile's predecessor has issued its last chunk.  A full chunk then costs one v_add per piece.
+        unsigned wfast[QW];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) wfast[i] = (wch[i] != (1 << 28)) ? (unsigned)wrel[i] : OOB;
+        int ihy[QI], ihx[QI], irel0[QI], irel1[QI], ich[QI];
+#pragma unroll
+        for (int i = 0; i < QI; ++i) {
+            const int row = (lwv + 4 * i) * 16 + drow;
+            const int hy = row / HWD, hx = row - hy * HWD;
+            ich[i] = (dslot ^ slot_swz(hx)) * VE;
+            ihy[i] = (row < NHALO) ? hy - 1 : -100000;
+            ihx[i] = hx - 1;
+            irel0[i] = ((((hy - 1) >> a.up0) * w0 + ((hx - 1) >> a.up0)) * a.c0 + ich[i]) * (int)sizeof(T);
+            irel1[i] = (((hy - 1) * a.w + (hx - 1)) * a.c1 + ich[i]) * (int)sizeof(T);
+        }
+        unsigned t0[QI], t1[QI];                         // prepared tile: per-piece offsets (border test folded in)
+        int p_nmod = 0, p_tb0 = 0, p_tb1 = 0;
+        const int img0_bytes = h0 * w0 * a.c0 * (int)sizeof(T), img1_bytes = a.h * a.w * a.c1 * (int)sizeof(T);
+        auto prep_tile = [&](int tile) __attribute__((always_inline)) {
+            unsigned bx = (unsigned)tile;
+            const unsigned tx_i = bx % (unsigned)a.tiles_x; bx /= (unsigned)a.tiles_x;
+            const unsigned ty_i = bx % (unsigned)a.tiles_y;
+            const int n_out = (int)(bx / (unsigned)a.tiles_y);
+            const int ty0 = (int)ty_i * TH, tx0 = (int)tx_i * TW;
+            p_nmod = a.depth > 1 ? n_out % a.depth : 0;
+            p_tb0 = ((n_out * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 * (int)sizeof(T);
+            p_tb1 = ((n_out * a.h + ty0) * a.w + tx0) * a.c1 * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < QI; ++i) {
+                const int gy = ty0 + ihy[i], gx = tx0 + ihx[i];
+                const bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+                const bool ok0 = a.zs ? (ok && ((gy & gx) & 1)) : ok;
+                t0[i] = ok0 ? (unsigned)irel0[i] : OOB;
+                t1[i] = ok ? (unsigned)irel1[i] : OOB;
+            }
+        };
+        auto issue_weights = [&](int kc, int wstage) __attribute__((always_inline)) {
+            const int kdi = a.kd > 1 ? kc / nch : 0;
+            const int cbase = (kc - kdi * nch) * KCE;
+            const int tapbase = ((kdi + ph) * TAPS * a.cout * a.cin + cbase) * (int)sizeof(T);
+            const unsigned lw0 = lds_base + 2 * IN_BYTES + wstage * W_BYTES + lwv * 1024;      // + i * 4096 per piece
+            if (a.cin - cbase >= KCE) {                  // full chunk: valid rows carry all their channels
+#pragma unroll
+                for (int i = 0; i < QW; ++i) {
+                    if (i < QW - 1 || lwv + 4 * i < NQW) dma16(rsw, wfast[i] + (unsigned)tapbase, lw0 + i * 4096);   // OOB + tapbase stays >= 2^31
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < QW; ++i) {
+                    if (i < QW - 1 || lwv + 4 * i < NQW) {
+                        const unsigned off = (wch[i] < a.cin - cbase) ? (unsigned)(wrel[i] + tapbase) : OOB;
+                        dma16(rsw, off, lw0 + i * 4096);
+                    }
+                }
+            }
+        };
+        // stages chunk kc of the PREPARED tile
+        auto issue_input = [&](int kc, int stage) __attribute__((always_inline)) {
+            const int kdi = a.kd > 1 ? kc / nch : 0;
+            const int dsh = kdi - (a.kd >> 1);               // depth tap: the image dsh slices away, zeros outside the volume
+            const bool dok = (unsigned)(p_nmod + dsh) < (unsigned)a.depth;
+            const int cbase = (kc - kdi * nch) * KCE;
+            const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
+            const int cb = from0 ? cbase : cbase - a.c0;
+            const int crem = dok ? (from0 ? a.c0 : a.c1) - cb : 0;
+            const unsigned li0 = lds_base + stage * IN_BYTES + lwv * 1024;                      // + i * 4096 per piece
+            const unsigned base = (unsigned)((from0 ? p_tb0 + dsh * img0_bytes : p_tb1 + dsh * img1_bytes) + cb * (int)sizeof(T));
+            if (crem >= KCE && !a.nt_in) {                   // full chunk inside the volume: offset = prepared + base
+                if (from0) {
+#pragma unroll
+                    for (int i = 0; i < QI; ++i) {
+                        if (i < QI - 1 || lwv + 4 * i < NQI) dma16(rs0, t0[i] + base, li0 + i * 4096);   // OOB + base stays >= 2^31
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < QI; ++i) {
+                        if (i < QI - 1 || lwv + 4 * i < NQI) dma16(rs1, t1[i] + base, li0 + i * 4096);
+                    }
+                }
+            } else {                                         // partial chunk / depth tap outside the volume / streaming hint
+                const i32x4 rs = from0 ? rs0 : rs1;
+#pragma unroll
+                for (int i = 0; i < QI; ++i) {
+                    if (i < QI - 1 || lwv + 4 * i < NQI) {
+                        const unsigned t = from0 ? t0[i] : t1[i];
+                        const unsigned off = (t != OOB && ich[i] < crem) ? t + base : OOB;
+                        if (a.nt_in) dma16_nt(rs, off, li0 + i * 4096);
+                        else dma16(rs, off, li0 + i * 4096);
+                    }
+                }
+            }
+        };
+        if (resident) for (int kc = 0; kc < nchunks; ++kc) issue_weights(kc, kc);
+        else issue_weights(0, 0);
+        prep_tile(first_tile);
+        issue_input(0, 0);
+        if (nchunks == 1 && first_tile + (int)gridDim.x < a.ntiles) prep_tile(first_tile + gridDim.x);
+        int it = 0;
+        for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
+            for (int kc = 0; kc < nchunks; ++kc, ++it) {
+                // my pieces of item `it` have landed; after the barrier: everybody's have, and the compute waves are done
+                // with item it-1, whose stage the next item may now overwrite
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                int ntile = tile, nkc = kc + 1;
+                if (nkc == nchunks) { nkc = 0; ntile = tile + gridDim.x; }
+                if (ntile < a.ntiles && !(a.dbg & 1)) {
+                    issue_input(nkc, (it + 1) & 1);          // the prepared tile is ntile (see below)
+                    if (!resident) issue_weights(nkc, (it + 1) & 1);
+                    // ntile's last chunk is on its way: prepare its successor while the DMAs fly
+                    if (nkc == nchunks - 1 && ntile + (int)gridDim.x < a.ntiles) prep_tile(ntile + gridDim.x);
+                }
+            }
+        }
+        if constexpr (STATS) {                           // the compute waves' reduction uses two more workgroup barriers
+            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+        return;
+    }
+
+    // -------------------------------------------------- compute waves --------------------------------------------------
+    // Fragment geometry of v_mfma_f32_16x16x32: lane = (i16 = row of the 16-row operand block, kq = which 16-byte slot of
+    // the 64-byte K row); the 4 accumulator registers of a 16 x 16 tile hold output channels 4 kq + r of pixel i16.
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y1 ? a.y1 : a.y), 0, a.y1 ? a.y1_bytes : 0, 0x00020000);
+    const int i16 = lane & 15, kq = lane >> 4;
+    constexpr int NCB = 2 * NCT, NPB = 2 * NPT, HB = NPB / 2;           // 16-channel / 16-pixel blocks per wave; blocks per half step
+    constexpr int BPR = TW / 16;                                          // pixel blocks per tile row
+    constexpr int TXN = TAPS == 9 ? 3 : 2;
+    const int row0 = (wv * (NPT * 32)) / TW;                              // first tile row of this wave
+    int in_base[TXN][BPR];
+#pragma unroll
+    for (int tx = 0; tx < TXN; ++tx)
+#pragma unroll
+        for (int cx = 0; cx < BPR; ++cx) {
+            const int hx = cx * 16 + i16 + tx + (TAPS == 4 ? pb : 0);
+            in_base[tx][cx] = (row0 * HWD + hx) * 64 + ((kq ^ slot_swz(hx)) << 4);
+        }
+    int w_addr[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int r = cb * 16 + i16;
+        w_addr[cb] = r * 64 + ((kq ^ slot_swz(r)) << 4);
+    }
+    f32x4 acc[NCB][NPB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) acc[cb][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fused BatchNormalization statistics: lane (kq, i16) ends up with the sums of channel 4 kq + 2 bit3(i16) + bit2(i16) of every
+    // 16-channel block over the wave's pixels (lane16_channel_sum), two registers per block
+    float st_sum[NCB], st_sq[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) st_sum[cb] = st_sq[cb] = 0.f;
+
+    int it = 0;
+    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
+        int bx = tile;
+        const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty_i = bx % a.tiles_y;
+        const int n = bx / a.tiles_y;
+        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+        for (int kc = 0; kc < nchunks; ++kc, ++it) {
+            asm volatile("s_barrier" ::: "memory");              // item `it` is in LDS (the loaders waited for their DMAs)
+            if (a.dbg & 2) continue;
+            const unsigned char* sin = lin + (it & 1) * IN_BYTES + (TAPS == 4 ? pa * HWD * 64 : 0);
+            const unsigned char* sw = lw + (resident ? kc : (it & 1)) * W_BYTES;
+            // one tap = one K = 32 step, issued as two half steps (all channel blocks x half of the pixel blocks); the weight
+            // fragments of the next tap and the pixel fragments of the next half step are read above the MFMAs of this one
+            uint4 fa[2][NCB], fb[2][HB];
+            auto load_a = [&](int tap, int buf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) fa[buf][cb] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + w_addr[cb]);
+            };
+            auto load_b = [&](int tap, int half, int buf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int p = 0; p < HB; ++p) {
+                    const int blk = half * HB + p;
+                    fb[buf][p] = *reinterpret_cast<const uint4*>(sin + in_base[tap % TXN][blk % BPR] + (tap / TXN + blk / BPR) * HWD * 64);
+                }
+            };
+            load_a(0, 0);
+            load_b(0, 0, 0);
+#pragma unroll
+            for (int ss = 0; ss < 2 * TAPS; ++ss) {
+                const int tap = ss >> 1, half = ss & 1;
+                if (half == 0) load_b(tap, 1, 1);
+                else if (tap + 1 < TAPS) { load_a(tap + 1, (tap + 1) & 1); load_b(tap + 1, 0, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int p = 0; p < HB; ++p) acc[cb][half * HB + p] = mfma16x16<T>(fa[tap & 1][cb], fb[half][p], acc[cb][half * HB + p]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue of this tile; compute waves never wait on their stores ----
+        // Two pixel blocks (X, Y) of one channel block at a time: after v_permlane16_swap of the packed pairs a lane with even kq
+        // holds 8 consecutive channels of X's pixel, a lane with odd kq those of Y's pixel -> one 16-byte store per lane.
+        auto store_pair = [&](int cb, const float (&x)[4], const float (&y)[4], unsigned pix, bool pix_ok) __attribute__((always_inline)) {
+            const int cbase = co0 + cb * 16;                                   // wave-uniform
+            const bool second = a.y1 && cbase >= a.csplit;                     // csplit % 32 == 0 (host)
+            const int cstride = a.y1 ? (second ? a.cout - a.csplit : a.csplit) : a.cout;
+            const int cshift = second ? a.csplit : 0;
+            const unsigned x0 = (uint32_t)Vec<T>::enc(x[0]) | ((uint32_t)Vec<T>::enc(x[1]) << 16), x1 = (uint32_t)Vec<T>::enc(x[2]) | ((uint32_t)Vec<T>::enc(x[3]) << 16);
+            const unsigned y0 = (uint32_t)Vec<T>::enc(y[0]) | ((uint32_t)Vec<T>::enc(y[1]) << 16), y1 = (uint32_t)Vec<T>::enc(y[2]) | ((uint32_t)Vec<T>::enc(y[3]) << 16);
+            auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+            auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+            const u32x4v dta = {s0[0], s1[0], s0[1], s1[1]};
+            const int co = cbase + 8 * (kq >> 1);
+            const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
+            if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, RVIP_Y1_POLICY);
+            else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
+        };
+        auto block_pixel = [&](int blk, int& gy, int& gx) __attribute__((always_inline)) {
+            gy = ty0 + row0 + blk / BPR;
+            gx = tx0 + (blk % BPR) * 16 + i16;
+        };
+        auto epilogue = [&](auto actf) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                float qs[4], qq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qs[r] = qq[r] = 0.f;
+#pragma unroll
+                for (int q = 0; q < NPB / 2; ++q) {
+                    int gy0, gx0, gy1, gx1;
+                    block_pixel(2 * q, gy0, gx0);
+                    block_pixel(2 * q + 1, gy1, gx1);
+                    const bool ok0 = gy0 < a.h && gx0 < a.w, ok1 = gy1 < a.h && gx1 < a.w;
+                    float x[4], y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float bias = lbias[cb * 16 + 4 * kq + r];
+                        x[r] = actf(acc[cb][2 * q][r] + bias);
+                        y[r] = actf(acc[cb][2 * q + 1][r] + bias);
+                        acc[cb][2 * q][r] = 0.f;
+                        acc[cb][2 * q + 1][r] = 0.f;
+                        if constexpr (STATS) {                                  // statistics of what is stored
+                            const float u0 = ok0 ? Vec<T>::round(x[r]) : 0.f, u1 = ok1 ? Vec<T>::round(y[r]) : 0.f;
+                            qs[r] += u0 + u1;
+                            qq[r] = fmaf(u0, u0, fmaf(u1, u1, qq[r]));
+                        }
+                    }
+                    // the pixel this lane stores after the swap: X's for even kq, Y's for odd kq
+                    const int gym = (kq & 1) ? gy1 : gy0, gxm = (kq & 1) ? gx1 : gx0;
+                    const bool okm = (kq & 1) ? ok1 : ok0;
+                    const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gym + pa) * 2 * a.w + 2 * gxm + pb)
+                                                   : (unsigned)((n * a.h + gym) * a.w + gxm);
+                    store_pair(cb, x, y, pix, okm);
+                }
+                if constexpr (STATS) {
+                    st_sum[cb] += lane16_channel_sum(qs, i16);
+                    st_sq[cb] += lane16_channel_sum(qq, i16);
+                }
+            }
+        };
+        // data gradient of UpSampling2D -> conv: 2 x 2 block sums.  The block's rows are two pixel blocks of the same lane, its
+        // columns lanes i16 and i16 ^ 1; units (block sums) are paired for the 16-byte store like the pixel blocks above.
+        auto epilogue_down2_16 = [&]() {
+            constexpr int NU = NPB / 2;                                        // 2-row units per wave
+            const int hl = a.h >> 1, wl = a.w >> 1;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+                for (int w2 = 0; w2 < NU / 2; ++w2) {
+                    float v[2][4];
+                    int gyu[2], gxu[2];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int u = 2 * w2 + s2;
+                        // TW = 32: unit = (row pair m, column block cx); TW = 16: unit = row pair m
+                        const int m = BPR == 2 ? (u >> 1) : u, cx = BPR == 2 ? (u & 1) : 0;
+                        const int top = (2 * m) * BPR + cx, bot = (2 * m + 1) * BPR + cx;
+                        gyu[s2] = ty0 + row0 + 2 * m;
+                        gxu[s2] = tx0 + cx * 16 + i16;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float t = acc[cb][top][r] + acc[cb][bot][r];
+                            acc[cb][top][r] = 0.f;
+                            acc[cb][bot][r] = 0.f;
+                            v[s2][r] = t + __shfl_xor(t, 1);
+                        }
+                    }
+                    const int gym = (kq & 1) ? gyu[1] : gyu[0], gxm = (kq & 1) ? gxu[1] : gxu[0];
+                    const bool keep = gym < a.h && gxm < a.w && !(i16 & 1);
+                    const unsigned pix = (unsigned)((n * hl + (gym >> 1)) * wl + (gxm >> 1));
+                    store_pair(cb, v[0], v[1], pix, keep);
+                }
+            }
+        };
+        if (a.down2) epilogue_down2_16();
+        else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
+        else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
+        else epilogue([&](float t) { return act_fwd(t, a.act); });
+    }
+    if constexpr (STATS) {
+        asm volatile("s_barrier" ::: "memory");                            // every stage has been consumed
+        float* lst = reinterpret_cast<float*>(smem);                       // [NCW compute waves][2][BN]
+        if (!(i16 & 3)) {                                                  // four lanes hold the same channel
+            const int r = 2 * ((i16 >> 3) & 1) + ((i16 >> 2) & 1);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int c = cb * 16 + 4 * kq + r;
+                lst[(wv * 2 + 0) * BN + c] = st_sum[cb];
+                lst[(wv * 2 + 1) * BN + c] = st_sq[cb];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < 2 * BN) {
+            const int k = tid / BN, c = tid % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < NCW; ++w4) t += lst[(w4 * 2 + k) * BN + c];
+            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * 2 + k) * a.cout + co0 + c] = t;
+        }
+    }
+}
+
+template <typename T, bool V5, int TW, int NCT, int NPIX, bool STATS, int TAPS, int NCW>
+static constexpr auto igemm_ws_kernel() {
+    // (the four-compute-wave 512-pixel tiling holds 128 accumulators per lane: the wider fragment set of v5 would spill there)
+    if constexpr (V5 && sizeof(T) == 2 && NPIX / (32 * NCW) <= 2) return &conv3x3_igemm_ws16<T, TW, NCT, NPIX, STATS, TAPS, NCW>;
+    else return &conv3x3_igemm_ws<T, TW, NCT, NPIX, STATS, TAPS, NCW>;
+}
+
+template <typename T, bool V5, int TW, int NCT, int NPIX, int TAPS = 9, int NCW = 4>
 static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry, int wgpc = 1) {
     constexpr int TH = NPIX / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
@@ -1069,10 +1467,10 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (lds > LDS_MAX) return RVIP_OK;
     static std::atomic<int> attr_lds{0};             // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!dry && lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, false, TAPS, NCW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, false, TAPS, NCW>()),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         if constexpr (TAPS == 9) {
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws<T, TW, NCT, NPIX, true, TAPS, NCW>),
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, true, TAPS, NCW>()),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         }
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
@@ -1089,33 +1487,33 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (rows_out) *rows_out = gx;
     if (dry) { used = true; return RVIP_OK; }
     if (stats) {
-        if constexpr (TAPS == 9) hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, true, TAPS, NCW>), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
+        if constexpr (TAPS == 9) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, true, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
         else return RVIP_EUNSUPPORTED;
-    } else hipLaunchKernelGGL((conv3x3_igemm_ws<T, TW, NCT, NPIX, false, TAPS, NCW>), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
+    } else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, false, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
     used = true;
     return check_launch();
 }
 
-template <typename T>
+template <typename T, bool V5 = false>
 static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float* stats = nullptr, int* rows_out = nullptr, bool dry = false,
                              bool wide = false) {
     const bool two = a.cout > 32;
     if (a.subpix) {                     // a.h, a.w = the low-resolution grid
-        if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry);
-        if (a.w > 16) return two ? launch_igemm_ws<T, 32, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 256, 4>(a, s, used, stats, rows_out, dry);
-        return two ? launch_igemm_ws<T, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry);
+        if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry);
+        if (a.w > 16) return two ? launch_igemm_ws<T, V5, 32, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 256, 4>(a, s, used, stats, rows_out, dry);
+        return two ? launch_igemm_ws<T, V5, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry);
     }
     if (a.w > 16 && a.h >= 16) {
         // HBM-bound shape (one K chunk, 32 output channels, e.g. 32 -> 32 at 256x256): two 8-wave workgroups per CU on
         // 256-pixel tiles (63 KB of LDS, <= 128 VGPRs each) so that one's epilogue overlaps the other's loads
         static const bool occ2 = [] { const char* e = getenv("RVIP_L0_OCC2"); return e && e[0] == '1'; }();
         if (occ2 && wide && !two && a.kd == 1 && a.cin <= 64 / (int)sizeof(T) && (long long)a.n * a.h * a.w >= 512 * 1024)
-            return launch_igemm_ws<T, 32, 1, 256>(a, s, used, stats, rows_out, dry, 2);
-        if (wide) return two ? launch_igemm_ws<T, 32, 2, 512, 9, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512, 9, 8>(a, s, used, stats, rows_out, dry);
-        return two ? launch_igemm_ws<T, 32, 2, 512>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 512>(a, s, used, stats, rows_out, dry);
+            return launch_igemm_ws<T, V5, 32, 1, 256>(a, s, used, stats, rows_out, dry, 2);
+        if (wide) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 9, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 9, 8>(a, s, used, stats, rows_out, dry);
+        return two ? launch_igemm_ws<T, V5, 32, 2, 512>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512>(a, s, used, stats, rows_out, dry);
     }
-    if (a.w > 16) return two ? launch_igemm_ws<T, 32, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 32, 1, 256>(a, s, used, stats, rows_out, dry);
-    return two ? launch_igemm_ws<T, 16, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, 16, 1, 256>(a, s, used, stats, rows_out, dry);
+    if (a.w > 16) return two ? launch_igemm_ws<T, V5, 32, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 256>(a, s, used, stats, rows_out, dry);
+    return two ? launch_igemm_ws<T, V5, 16, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 16, 1, 256>(a, s, used, stats, rows_out, dry);
 }
 
 template <typename T, int TW, int NCT, int NW>
@@ -1479,6 +1877,11 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 // EIGHT compute waves on the 512-pixel tiling (smaller maps: v3's four) - which is within 1 % of the best of v2 / v3 / v4
 // on every layer of config 2 (profiles/r01_igemm_v2_v3_v4.txt: family total 2.18 / 2.06 / 1.98 ms per step): the loaders
 // take the DMA issue out of the MFMA waves like v3, and the epilogue stores are spread over 8 waves like v2.
+// v5 (16x16x32 MFMA, 16-bit types) unless RVIP_IGEMM names an older generation (A/B measurements)
+static bool igemm_use_v5() {
+    static const bool on = [] { const char* e = getenv("RVIP_IGEMM"); return !(e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4'); }();
+    return on;
+}
 static int igemm_generation(const ConvArgs& a, bool stats = false) {
     static const int forced = [] { const char* e = getenv("RVIP_IGEMM"); return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4') ? e[1] - '0' : 0; }();
     (void)stats;
@@ -1537,7 +1940,7 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
         bool used = false;
         int rc;
         if (gen >= 3 || d->dtype == RVIP_F16)        // the A/B generation v2 is not built for f16
-            rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t)>(a, s, used, nullptr, nullptr, false, gen >= 4); });
+            rc = by_dtype(d->dtype, [&](auto t) { return igemm_use_v5() ? dispatch_igemm_ws<decltype(t), true>(a, s, used, nullptr, nullptr, false, gen >= 4) : dispatch_igemm_ws<decltype(t), false>(a, s, used, nullptr, nullptr, false, gen >= 4); });
         else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
         if (rc || used) return rc;
     }
@@ -1556,7 +1959,7 @@ extern "C" int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d) {
     bool used = false; int rows = 0;
     int rc;
     if (gen >= 3 || d->dtype == RVIP_F16)
-        rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t)>(a, nullptr, used, nullptr, &rows, true, gen >= 4); });
+        rc = by_dtype(d->dtype, [&](auto t) { return igemm_use_v5() ? dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, nullptr, &rows, true, gen >= 4) : dispatch_igemm_ws<decltype(t), false>(a, nullptr, used, nullptr, &rows, true, gen >= 4); });
     else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, nullptr, used, nullptr, &rows, true)
                                     : dispatch_igemm_dma<float>(a, nullptr, used, nullptr, &rows, true);
     return (rc == RVIP_OK && used) ? rows : 0;
@@ -1575,7 +1978,7 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
     hipStream_t s = (hipStream_t)stream;
     const int sgen = igemm_generation(a, true);
     if (sgen >= 3 || d->dtype == RVIP_F16)
-        rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t)>(a, s, used, stats_ws, nullptr, false, sgen >= 4); });
+        rc = by_dtype(d->dtype, [&](auto t) { return igemm_use_v5() ? dispatch_igemm_ws<decltype(t), true>(a, s, used, stats_ws, nullptr, false, sgen >= 4) : dispatch_igemm_ws<decltype(t), false>(a, s, used, stats_ws, nullptr, false, sgen >= 4); });
     else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used, stats_ws) : dispatch_igemm_dma<float>(a, s, used, stats_ws);
     if (rc) return rc;
     return used ? RVIP_OK : RVIP_EUNSUPPORTED;

@@ -366,7 +366,7 @@ def test_f16_path_matches_f16_storage_emulation():
     for lname in ('conv2d', 'conv2d_1', 'conv2d_3', 'conv2d_5', 'conv2d_8', 'unet'):
         rel = np.linalg.norm(got[(lname, 'kernel')] - egrads[lname][0]) / np.linalg.norm(egrads[lname][0])
         rel_x = np.linalg.norm(got[(lname, 'kernel')] - xgrads[lname][0]) / np.linalg.norm(xgrads[lname][0])
-        assert rel < 0.7 * rel_x + 0.01 and rel < 0.1, (lname, rel, rel_x)     # rel_x: rounding moves ReLU masks / max-pool winners
+        assert rel < 0.7 * rel_x + 0.02 and rel < 0.1, (lname, rel, rel_x)     # rel_x: rounding moves ReLU masks / max-pool winners
     # one optimizer step: Adam sees the UNSCALED gradient.  First Keras-Adam step: dtheta = -lr * g / (|g| + eps / sqrt(1 - beta2))
     # -- a gradient still carrying the loss scale would give -lr * sign(g) everywhere.
     w0 = model.get_weights()[0].copy()
