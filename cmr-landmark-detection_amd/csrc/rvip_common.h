@@ -82,19 +82,7 @@ template <> struct Vec<f16_t> {
 // MFMA on eight 16-bit K elements per lane (one uint4 fragment of each operand)
 template <typename T> __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& acc);
 template <> __device__ __forceinline__ f32x16 mfma16<bf16_t>(const uint4& a, const uint4& b, const f32x16& acc) {
-#ifdef RVIP_MFMA16_EXPERIMENT
-    // TIMING EXPERIMENT ONLY (wrong arithmetic): the same operand fragments and FLOPs through two 16x16x32 MFMAs, to price
-    // the instruction shape before re-deriving the fragment layouts
-    typedef __attribute__((ext_vector_type(4))) float f32x4e;
-    f32x4e lo = {acc[0], acc[1], acc[2], acc[3]}, hi = {acc[4], acc[5], acc[6], acc[7]};
-    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), lo, 0, 0, 0);
-    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), hi, 0, 0, 0);
-    f32x16 r = acc;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-#endif
 }
 template <> __device__ __forceinline__ f32x16 mfma16<f16_t>(const uint4& a, const uint4& b, const f32x16& acc) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0); }
