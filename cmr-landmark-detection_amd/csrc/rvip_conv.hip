@@ -1497,7 +1497,15 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
 template <typename T, bool V5 = false>
 static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float* stats = nullptr, int* rows_out = nullptr, bool dry = false,
                              bool wide = false) {
-    const bool two = a.cout > 32;
+    bool two = a.cout > 32;
+    if (two && !a.subpix) {
+        // small maps: 64-channel tiles can leave half of the CUs without a workgroup (e.g. 256 -> 128 at 32 x 32: 64 tiles x 2
+        // channel columns); 32-channel tiles double the workgroup count for a little more LDS traffic per FLOP
+        static const bool narrow = [] { const char* e = getenv("RVIP_NARROW_TILES"); return !(e && e[0] == '0'); }();
+        const int tpx = (a.w > 16 && a.h >= 16) ? 512 : 256, tw = a.w > 16 ? 32 : 16;
+        const long long ntiles = (long long)a.n * cdiv(a.w, tw) * cdiv(a.h, tpx / tw);
+        if (narrow && ntiles * cdiv(a.cout, 64) <= 128) two = false;
+    }
     if (a.subpix) {                     // a.h, a.w = the low-resolution grid
         if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry);
         if (a.w > 16) return two ? launch_igemm_ws<T, V5, 32, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 256, 4>(a, s, used, stats, rows_out, dry);
