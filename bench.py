@@ -188,6 +188,22 @@ def main():
         torch.cuda.synchronize()
         host_rate = round(B * hs / (time.perf_counter() - th0), 2)
 
+    # ---- inference (Model.predict: BN on the moving statistics, no dropout), forward only, eager launches; and the HBM the
+    # whole training state of this configuration occupies.  Informational keys beside `value`.
+    predict_rate = hbm_gb = None
+    if rank == 0 and world == 1:
+        for _ in range(2):
+            eng.forward(training=False)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        ps = max(3, min(args.steps, 10))
+        for _ in range(ps):
+            eng.stage_input()
+            eng.forward(training=False)
+        torch.cuda.synchronize()
+        predict_rate = round(B * ps / (time.perf_counter() - tp0), 2)
+        hbm_gb = round(torch.cuda.max_memory_allocated() / 2 ** 30, 3)
+
     # ---- roofline pass: HIP events around every launch, eager, on the launch stream -------------------------
     roof = None
     per_kernel = {}
@@ -270,7 +286,7 @@ def main():
                 args.depth, args.filters, args.dim, args.dim, B, ' + RCCL grad all-reduce' if world > 1 else ''),
                 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch, 'collective': ('%s all-reduce of %d fp32 gradients' % (backend, model._params.count)) if world > 1 else None,
                 'gflop_per_slice_fwd_bwd': round(step_flops / 1e9, 3)},
-            'host_input_slices_per_s': host_rate,
+            'host_input_slices_per_s': host_rate, 'predict_slices_per_s_eager': predict_rate, 'hbm_allocated_gib': hbm_gb,
             'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),
             'loss': loss,
             'roofline': roof,
