@@ -11,6 +11,17 @@
 
 namespace rvip {
 
+// q -> (x, y, image) for a row-major [image][h][w] index.  64-bit division is emulated on the GPU (~100 instructions per
+// quotient): three of them per 2x2 window made the pooled bn_apply VALU-bound (3.1 TB/s); the index fits 32 bits in practice.
+__device__ __forceinline__ void split_xy(long long q, int w, int h, int& x, int& y, long long& img) {
+    if (q < (1LL << 31)) {
+        const unsigned u = (unsigned)q, t = u / (unsigned)w, i = t / (unsigned)h;
+        x = (int)(u - t * (unsigned)w); y = (int)(t - i * (unsigned)h); img = i;
+    } else {
+        x = (int)(q % w); y = (int)((q / w) % h); img = q / ((long long)w * h);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // reduction geometry (host + device agree through these fields)
 // ------------------------------------------------------------------------------------------------
@@ -357,8 +368,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
                 const long long q = (g + u * G) * rpi + prow;
                 qi[u] = q;
                 ok[u] = (g + u * G) < ngroups && q < quads;
-                const int ox = (int)(q % ow), oy = (int)((q / ow) % oh);
-                const long long img = q / ((long long)ow * oh);
+                int ox, oy; long long img;
+                split_xy(q, ow, oh, ox, oy, img);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     e0[u][k] = (((size_t)img * a.h + 2 * oy + (k >> 1)) * a.w + 2 * ox + (k & 1)) * a.c + cv * VE;
@@ -381,6 +392,62 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
                 }
                 Vec<T>::store(a.pooled + ((size_t)qi[u] * a.c + cv * VE) * sizeof(T), best);
             }
+        }
+    }
+}
+
+// MaxPooling variant, column-split: thread = (window slot, pixel column, channel vector).  The two lanes `cg` apart hold the two
+// columns of a 2x2 window, so every load / store instruction of a wave covers contiguous bytes, and a thread has only 2 x UNR
+// loads and stores per round (the window-per-thread form issues 8 + 10: its stores, not its loads or its index arithmetic, hold
+// it at 3.5 TB/s -- tools/probe_apply_pool.py).  The window maximum is completed with one lane exchange.  cg must be a power of
+// two <= 32 (the two lanes share a wave).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_pool2_kernel(ApplyArgs a, int cg, int wpi, long long ngroups) {
+    constexpr int VE = Vec<T>::VE;
+#ifndef RVIP_POOL2_UNR
+#define RVIP_POOL2_UNR 2
+#endif
+    constexpr int UNR = RVIP_POOL2_UNR;
+    const int tid = threadIdx.x, cv = tid % cg, px = (tid / cg) & 1, wslot = tid / (2 * cg);
+    float sc[VE], sh[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { sc[e] = a.scale ? a.scale[cv * VE + e] : 1.f; sh[e] = a.shift ? a.shift[cv * VE + e] : 0.f; }
+    const uint32_t key = (a.drop && !a.mask) ? dropout_key(a.state[RVIP_STATE_SEED], a.state[RVIP_STATE_STEP], (uint32_t)a.layer_id) : 0u;
+    const long long G = gridDim.x;
+    const int oh = a.h >> 1, ow = a.w >> 1;
+    const long long quads = (long long)a.n * oh * ow;
+    for (long long g = blockIdx.x; g < ngroups; g += UNR * G) {
+        float v[UNR][2][VE]; size_t e0[UNR][2]; bool ok[UNR]; long long qi[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long long q = (g + u * G) * wpi + wslot;
+            qi[u] = q;
+            ok[u] = (g + u * G) < ngroups && q < quads;            // the same for both lanes of a window
+            int ox, oy; long long img;
+            split_xy(q, ow, oh, ox, oy, img);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                e0[u][r] = (((size_t)img * a.h + 2 * oy + r) * a.w + 2 * ox + px) * a.c + cv * VE;
+                if (ok[u]) Vec<T>::load_nt(a.z + e0[u][r] * sizeof(T), v[u][r]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (!ok[u]) continue;
+            float best[VE];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                apply_xform<T, VE>(a, e0[u][r], sc, sh, key, v[u][r]);
+                Vec<T>::store(a.y + e0[u][r] * sizeof(T), v[u][r]);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float vr = Vec<T>::round(v[u][r][e]);                     // pool what was stored
+                    best[e] = (r == 0 || vr > best[e]) ? vr : best[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], cg));
+            if (px == 0) Vec<T>::store(a.pooled + ((size_t)qi[u] * a.c + cv * VE) * sizeof(T), best);
         }
     }
 }
@@ -408,8 +475,8 @@ struct BnBwdArgs {
 template <typename T, int VE>
 __device__ __forceinline__ void pool_window_grads(const BnBwdArgs& a, long long q, int cbase, size_t (&e0)[4], float (&z)[4][VE], float (&g)[4][VE]) {
     const int oh = a.ph >> 1, ow = a.pw >> 1;
-    const int ox = (int)(q % ow), oy = (int)((q / ow) % oh);
-    const long long img = q / ((long long)ow * oh);
+    int ox, oy; long long img;
+    split_xy(q, ow, oh, ox, oy, img);
     float gp[VE];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -605,8 +672,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
     const int cv = (int)(idx % cg);
     const long long q = idx / cg;
     if (q >= (long long)n * oh * ow) return;
-    const int ox = (int)(q % ow), oy = (int)((q / ow) % oh);
-    const long long img = q / ((long long)ow * oh);
+    int ox, oy; long long img;
+    split_xy(q, ow, oh, ox, oy, img);
     float v[4][VE], g[VE];
     size_t e0[4];
 #pragma unroll
@@ -642,8 +709,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const unsigned char* __re
     const int cv = (int)(idx % cg);
     const long long q = idx / cg;
     if (q >= (long long)n * h * w) return;
-    const int x = (int)(q % w), yy = (int)((q / w) % h);
-    const long long img = q / ((long long)w * h);
+    int x, yy; long long img;
+    split_xy(q, w, h, x, yy, img);
     const size_t lo = ((size_t)q * c + cv * VE) * sizeof(T);
     float v[VE];
     if constexpr (!BWD) {
@@ -675,8 +742,8 @@ __global__ __launch_bounds__(256) void subsample_odd_kernel(const unsigned char*
     const int cv = (int)(idx % cg);
     const long long q = idx / cg;
     if (q >= (long long)n * h * w) return;
-    const int x = (int)(q % w), yy = (int)((q / w) % h);
-    const long long img = q / ((long long)w * h);
+    int x, yy; long long img;
+    split_xy(q, w, h, x, yy, img);
     float v[VE];
     Vec<T>::load(src + ((((size_t)img * 2 * h + 2 * yy + 1) * 2 * w + 2 * x + 1) * c + cv * VE) * sizeof(T), v);
     Vec<T>::store(dst + ((size_t)q * c + cv * VE) * sizeof(T), v);
@@ -1030,8 +1097,8 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const T* __restrict__ x, 
         for (int e = 0; e < VE; ++e) part[t][e] = 0.f;
     if (active) {
         for (long long r = r0 + prow; r < r1; r += gm.rpi) {
-            const int px = (int)(r % w), py = (int)((r / w) % h);
-            const long long img = r / ((long long)w * h);
+            int px, py; long long img;
+            split_xy(r, w, h, px, py, img);
             float g[VE];
             Vec<T>::load(dy + ((size_t)r * cout + cgi * VE) * sizeof(T), g);
 #pragma unroll
@@ -1351,7 +1418,17 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     static const long long nb_cap = [] { const char* e = getenv("RVIP_APPLY_BLOCKS"); return e ? atoll(e) : 1024LL; }();     // one resident round of workgroups: 7-10 % faster than 4096 (tools/probe_apply.py)
     if (nb > nb_cap) nb = nb_cap;
     dim3 grid((unsigned)nb);
-    if (d->pooled) {
+    static const bool pool2 = [] { const char* e = getenv("RVIP_POOL_SPLIT"); return !(e && e[0] == '0'); }();
+    if (d->pooled && pool2 && cg <= 32 && (cg & (cg - 1)) == 0) {        // column-split form: both lanes of a window in one wave
+        const int wpi = 128 / cg;
+        const long long ng2 = cdiv(units, wpi);
+        long long nb2 = cdiv(ng2, RVIP_POOL2_UNR);
+        if (nb2 > nb_cap) nb2 = nb_cap;
+        by_dtype(d->dtype, [&](auto t) {
+            hipLaunchKernelGGL((bn_apply_pool2_kernel<decltype(t)>), dim3((unsigned)nb2), dim3(256), 0, s, a, cg, wpi, ng2);
+            return 0;
+        });
+    } else if (d->pooled) {
         if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
         else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_apply_kernel<f16_t, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
         else hipLaunchKernelGGL((bn_apply_kernel<float, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
