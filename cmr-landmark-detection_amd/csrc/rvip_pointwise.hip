@@ -32,13 +32,15 @@ struct RedGeom {
     long long chunk;   // rows per workgroup (multiple of rpi)
 };
 
-static inline bool red_geom(long long rows, int c, int ve, RedGeom& g) {
+// cap: most workgroups the kernel keeps RESIDENT (256 CUs x waves/SIMD its register count allows): a grid one quarter larger than
+// that runs a second, mostly empty round
+static inline bool red_geom(long long rows, int c, int ve, RedGeom& g, int cap = 1024) {
     if (c <= 0 || c % ve || rows <= 0) return false;
     g.cg = c / ve;
     if (g.cg > 256) return false;
     g.rpi = 256 / g.cg;
     long long nb = cdiv(rows, (long long)g.rpi * 8);
-    if (nb > 1024) nb = 1024;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     long long ch = cdiv(rows, nb);
     ch = cdiv(ch, g.rpi) * g.rpi;
@@ -877,11 +879,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* __re
     block_fold<2 * RVIP_MAXK, VE>(part, active, prow * gm.cg + cgi, cin, gm.rpi, lds, ws + (size_t)blockIdx.x * 2 * RVIP_MAXK * cin);
 }
 
-struct PostHeadBwd {                   // ws columns: [2*MAXK][cin]: rows 0..MAXK-1 = dw per class, MAXK.. = db (channel 0 only)
-    float* dw; float* db; int cin, k;
+struct PostHeadBwd {                   // ws columns: [2*kmax][cin]: rows 0..kmax-1 = dw per class, kmax.. = db (channel 0 only)
+    float* dw; float* db; int cin, k, kmax;
     __device__ void run_k(int ch, int kk, double t) const {
-        if (kk < RVIP_MAXK) { if (kk < k) dw[ch * k + kk] = (float)t; }
-        else if (ch == 0 && kk - RVIP_MAXK < k) db[kk - RVIP_MAXK] = (float)t;
+        if (kk < kmax) { if (kk < k) dw[ch * k + kk] = (float)t; }
+        else if (ch == 0 && kk - kmax < k) db[kk - kmax] = (float)t;
     }
 };
 
@@ -976,27 +978,30 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
 }
 
 // incoming gradient of pixel r for this thread's channels, from the head's logit gradient
-template <typename T, int VE>
-__device__ __forceinline__ void head_grad_vec(const HeadFuse& hd, long long r, const float (&wr)[VE][RVIP_MAXK], float (&d)[RVIP_MAXK], float (&g)[VE]) {
+template <typename T, int VE, int KK = RVIP_MAXK>
+__device__ __forceinline__ void head_grad_vec(const HeadFuse& hd, long long r, const float (&wr)[VE][KK], float (&d)[KK], float (&g)[VE]) {
 #pragma unroll
-    for (int kk = 0; kk < RVIP_MAXK; ++kk) d[kk] = kk < hd.k ? hd.dlogit[(size_t)r * hd.k + kk] : 0.f;
+    for (int kk = 0; kk < KK; ++kk) d[kk] = kk < hd.k ? hd.dlogit[(size_t)r * hd.k + kk] : 0.f;
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
         float acc = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < RVIP_MAXK; ++kk) acc = fmaf(d[kk], wr[e][kk], acc);
+        for (int kk = 0; kk < KK; ++kk) acc = fmaf(d[kk], wr[e][kk], acc);
         g[e] = Vec<T>::round(acc);                                // the gy tensor the unfused path stores in the activation dtype
     }
 }
 
-template <typename T>
+// KK = class capacity of this instantiation (2 for the reference's two heat-maps, RVIP_MAXK otherwise): the per-class partials are
+// KK x VE registers each way, and with the MAXK-sized arrays the kernel had one 16-byte load in flight per thread at ~170 VGPRs --
+// latency-bound at 1.7 TB/s.  U rows in flight per thread.
+template <typename T, int KK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(BnBwdArgs a, HeadFuse hd, RedGeom gm, float* __restrict__ ws_bn, float* __restrict__ ws_hd) {
-    constexpr int VE = Vec<T>::VE;
+    constexpr int VE = Vec<T>::VE, U = 2;
     __shared__ float lds[256 * VE];
     const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
     const bool active = prow < gm.rpi;
     const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
-    float part[2][VE], hpart[2 * RVIP_MAXK][VE], mu[VE], is[VE], sc[VE], sh[VE], wr[VE][RVIP_MAXK];
+    float part[2][VE], hpart[2 * KK][VE], mu[VE], is[VE], sc[VE], sh[VE], wr[VE][KK];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
         part[0][e] = part[1][e] = 0.f;
@@ -1004,33 +1009,52 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(BnBwdArgs a, He
         mu[e] = active ? a.mean[ch] : 0.f; is[e] = active ? a.invstd[ch] : 0.f;
         sc[e] = (active && a.scale) ? a.scale[ch] : 1.f; sh[e] = (active && a.shift) ? a.shift[ch] : 0.f;
 #pragma unroll
-        for (int kk = 0; kk < RVIP_MAXK; ++kk) wr[e][kk] = (active && kk < hd.k) ? hd.w[ch * hd.k + kk] : 0.f;
+        for (int kk = 0; kk < KK; ++kk) wr[e][kk] = (active && kk < hd.k) ? hd.w[ch * hd.k + kk] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 2 * RVIP_MAXK; ++q) hpart[q][e] = 0.f;
+        for (int q = 0; q < 2 * KK; ++q) hpart[q][e] = 0.f;
     }
     if (active) {
-        for (long long r = r0 + prow; r < r1; r += gm.rpi) {
-            float z[VE], g[VE], d[RVIP_MAXK];
-            const size_t e0 = (size_t)r * a.c + cgi * VE;
-            Vec<T>::load(a.z + e0 * sizeof(T), z);
-            head_grad_vec<T, VE>(hd, r, wr, d, g);
+        for (long long rb = r0 + prow; rb < r1; rb += (long long)U * gm.rpi) {
+            float z[U][VE], d[U][KK];
+            bool ok[U];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const float y = Vec<T>::round(act_fwd(fmaf(z[e], sc[e], sh[e]), a.act_after_bn ? a.act : RVIP_ACT_NONE));
+            for (int u = 0; u < U; ++u) {                          // all loads of the round first
+                const long long r = rb + (long long)u * gm.rpi;
+                ok[u] = r < r1;
+                if (ok[u]) {
+                    Vec<T>::load(a.z + ((size_t)r * a.c + cgi * VE) * sizeof(T), z[u]);
 #pragma unroll
-                for (int kk = 0; kk < RVIP_MAXK; ++kk) hpart[kk][e] = fmaf(y, d[kk], hpart[kk][e]);     // dW_h
+                    for (int kk = 0; kk < KK; ++kk) d[u][kk] = kk < hd.k ? hd.dlogit[(size_t)r * hd.k + kk] : 0.f;
+                }
             }
-            if (cgi == 0) {
 #pragma unroll
-                for (int kk = 0; kk < RVIP_MAXK; ++kk) hpart[RVIP_MAXK + kk][0] += d[kk];               // db_h
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const long long r = rb + (long long)u * gm.rpi;
+                const size_t e0 = (size_t)r * a.c + cgi * VE;
+                float g[VE];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) acc = fmaf(d[u][kk], wr[e][kk], acc);
+                    g[e] = Vec<T>::round(acc);                    // the gy tensor the unfused path stores in the activation dtype
+                    const float y = Vec<T>::round(act_fwd(fmaf(z[u][e], sc[e], sh[e]), a.act_after_bn ? a.act : RVIP_ACT_NONE));
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) hpart[kk][e] = fmaf(y, d[u][kk], hpart[kk][e]);     // dW_h
+                }
+                if (cgi == 0) {
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) hpart[KK + kk][0] += d[u][kk];                       // db_h
+                }
+                xform_g<T, VE>(a, e0, cgi * VE, 0u, z[u], g);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) { part[0][e] += g[e]; part[1][e] = fmaf(g[e], (z[u][e] - mu[e]) * is[e], part[1][e]); }
             }
-            xform_g<T, VE>(a, e0, cgi * VE, 0u, z, g);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) { part[0][e] += g[e]; part[1][e] = fmaf(g[e], (z[e] - mu[e]) * is[e], part[1][e]); }
         }
     }
     block_fold<2, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws_bn + (size_t)blockIdx.x * 2 * a.c);
-    block_fold<2 * RVIP_MAXK, VE>(hpart, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws_hd + (size_t)blockIdx.x * 2 * RVIP_MAXK * a.c);
+    block_fold<2 * KK, VE>(hpart, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws_hd + (size_t)blockIdx.x * 2 * KK * a.c);
 }
 
 template <typename T>
@@ -1508,6 +1532,12 @@ extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
     return launch_fold<1, PostSum>(ws, g.nblk, d->c, p, s);
 }
 
+#define RVIP_APPLY_HEAD_CAP 768          // bn_bwd_apply_head_kernel: ~143 VGPRs -> 3 waves per SIMD -> 768 resident workgroups
+extern "C" int rvip_bn_bwd_apply_head_rows(long long rows, int c, int dtype) {
+    RedGeom g;
+    if (!RVIP_DT_OK(dtype) || !red_geom(rows, c, RVIP_VE(dtype), g, RVIP_APPLY_HEAD_CAP)) return 0;
+    return g.nblk;
+}
 extern "C" int rvip_bn_bwd_rows(long long rows, int c, int dtype) {      // pass rows / 4 for a pool-fused descriptor
     RedGeom g;
     if (!RVIP_DT_OK(dtype) || !red_geom(rows, c, RVIP_VE(dtype), g)) return 0;
@@ -1642,7 +1672,8 @@ extern "C" int rvip_bn_bwd_reduce_head(const rvip_bnbwd_desc* d, const float* he
     if (!d || !d->z || !head_w || !dlogit || !head_dw || !head_db || !RVIP_DT_OK(d->dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
     if (!d->gamma || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->coef || !d->workspace || d->drop_rate > 0.f) return RVIP_EINVAL;
     RedGeom g;
-    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g)) return RVIP_EINVAL;
+    const int kcap = k <= 2 ? 2 : RVIP_MAXK;                        // class capacity of the instantiation (register budget)
+    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g, kcap == 2 ? 768 : 512)) return RVIP_EINVAL;      // 3 / 2 waves per SIMD
     const size_t need = (size_t)g.nblk * (2 + 2 * RVIP_MAXK) * d->c * sizeof(float);
     if (d->workspace_bytes < need) return RVIP_EWORKSPACE;
     BnBwdArgs a;
@@ -1655,16 +1686,19 @@ extern "C" int rvip_bn_bwd_reduce_head(const rvip_bnbwd_desc* d, const float* he
     float* ws_bn = (float*)d->workspace;
     float* ws_hd = ws_bn + (size_t)g.nblk * 2 * d->c;
     HeadFuse hd{head_w, nullptr, dlogit, k};
-    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_bwd_reduce_head_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
-    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL(bn_bwd_reduce_head_kernel<f16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
-    else hipLaunchKernelGGL(bn_bwd_reduce_head_kernel<float>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
+    by_dtype(d->dtype, [&](auto t) {
+        using T = decltype(t);
+        if (kcap == 2) hipLaunchKernelGGL((bn_bwd_reduce_head_kernel<T, 2>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
+        else hipLaunchKernelGGL((bn_bwd_reduce_head_kernel<T, RVIP_MAXK>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
+        return 0;
+    });
     int rc = check_launch();
     if (rc) return rc;
     PostBnBwd p{d->gamma, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef, (double)d->rows, d->c};
     rc = launch_fold<2, PostBnBwd>(ws_bn, g.nblk, d->c, p, s);
     if (rc) return rc;
-    PostHeadBwd ph{head_dw, head_db, d->c, k};
-    return launch_fold_k<PostHeadBwd>(ws_hd, g.nblk, d->c, 2 * RVIP_MAXK, ph, s);
+    PostHeadBwd ph{head_dw, head_db, d->c, k, kcap};
+    return launch_fold_k<PostHeadBwd>(ws_hd, g.nblk, d->c, 2 * kcap, ph, s);
 }
 
 extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* head_w, const float* dlogit, int k, void* stream) {
@@ -1672,7 +1706,7 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     if (!d || !d->z || !d->dz || !head_w || !dlogit || !RVIP_DT_OK(d->dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
     if ((!d->dbias && !d->bias_rows) || (d->gamma && !d->coef) || d->drop_rate > 0.f) return RVIP_EINVAL;
     RedGeom g;
-    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g)) return RVIP_EINVAL;
+    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g, RVIP_APPLY_HEAD_CAP)) return RVIP_EINVAL;
     const bool defer = d->bias_rows != nullptr;
     if ((defer ? d->bias_rows_bytes : d->workspace_bytes) < (size_t)g.nblk * d->c * sizeof(float) || (!defer && !d->workspace)) return RVIP_EWORKSPACE;
     BnBwdArgs a;
@@ -1718,7 +1752,7 @@ extern "C" int rvip_head_bwd(const void* x, const float* w, const float* dlogit,
     else hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const unsigned char*)x, w, dlogit, (unsigned char*)dx, rows, cin, k, g, ws);
     int rc = check_launch();
     if (rc) return rc;
-    PostHeadBwd p{dw, db, cin, k};
+    PostHeadBwd p{dw, db, cin, k, RVIP_MAXK};
     return launch_fold_k<PostHeadBwd>(ws, g.nblk, cin, 2 * RVIP_MAXK, p, s);
 }
 

@@ -531,7 +531,10 @@ class Engine:
             b.rows, b.c, b.dtype = rows, st.cout, dt
             b.workspace, b.workspace_bytes = self.ws.data_ptr(), self.ws_bytes
             if defer and not (first and self.fuse_first):
-                nr = L.rvip_bn_bwd_rows(C.c_longlong(rows // 4 if fuse_pool else rows), st.cout, dt)
+                if st is last and self.fuse_head:
+                    nr = L.rvip_bn_bwd_apply_head_rows(C.c_longlong(rows), st.cout, dt)
+                else:
+                    nr = L.rvip_bn_bwd_rows(C.c_longlong(rows // 4 if fuse_pool else rows), st.cout, dt)
                 rbuf = torch.empty(nr * st.cout, dtype=torch.float32, device=self.ws.device)
                 self._fold_bufs.append(rbuf)
                 b.bias_rows, b.bias_rows_bytes = rbuf.data_ptr(), rbuf.numel() * 4
