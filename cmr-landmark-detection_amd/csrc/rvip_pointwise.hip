@@ -896,7 +896,9 @@ struct PostHeadBwd {                   // ws columns: [2*kmax][cin]: rows 0..kma
 // ------------------------------------------------------------------------------------------------
 struct HeadFuse { const float* w; const float* b; const float* dlogit; int k; };
 
-template <typename T>
+// KK = class capacity of the instantiation (2 for the reference's two heat-maps): half the shuffles and logit registers of the
+// MAXK-sized form; the target values of the round are loaded with its z rows, not after the arithmetic that depends on them.
+template <typename T, int KK>
 __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFuse hd, float* __restrict__ pred, const float* __restrict__ yt,
                                                             long long rows, long long chunk, int reduce, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE, U = 2;
@@ -904,23 +906,24 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
     const int tid = threadIdx.x, k = hd.k;
     const int cg = a.c / VE, rpi = 256 / cg, cgi = tid % cg, prow = tid / cg;
     const long long r0 = blockIdx.x * chunk, r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
-    float sc[VE], sh[VE], wr[VE][RVIP_MAXK], bias[RVIP_MAXK];
+    float sc[VE], sh[VE], wr[VE][KK], bias[KK];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
         sc[e] = a.scale ? a.scale[cgi * VE + e] : 1.f; sh[e] = a.shift ? a.shift[cgi * VE + e] : 0.f;
 #pragma unroll
-        for (int kk = 0; kk < RVIP_MAXK; ++kk) wr[e][kk] = kk < k ? hd.w[(cgi * VE + e) * k + kk] : 0.f;
+        for (int kk = 0; kk < KK; ++kk) wr[e][kk] = kk < k ? hd.w[(cgi * VE + e) * k + kk] : 0.f;
     }
 #pragma unroll
-    for (int kk = 0; kk < RVIP_MAXK; ++kk) bias[kk] = (kk < k && hd.b) ? hd.b[kk] : 0.f;
+    for (int kk = 0; kk < KK; ++kk) bias[kk] = (kk < k && hd.b) ? hd.b[kk] : 0.f;
     float s[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) s[i] = 0.f;
     for (long long rb = r0 + prow; rb < r1; rb += (long long)U * rpi) {
-        float v[U][VE];
+        float v[U][VE], tv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long r = rb + (long long)u * rpi;
+            tv[u] = (yt && r < r1 && cgi < k) ? yt[(size_t)r * k + cgi] : 0.f;      // lane cgi finishes class cgi (+ cg, ... below)
             if (r < r1) Vec<T>::load(a.z + ((size_t)r * a.c + cgi * VE) * sizeof(T), v[u]);
             else {
 #pragma unroll
@@ -930,17 +933,17 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long r = rb + (long long)u * rpi;
-            float lg[RVIP_MAXK];
+            float lg[KK];
 #pragma unroll
-            for (int kk = 0; kk < RVIP_MAXK; ++kk) lg[kk] = 0.f;
+            for (int kk = 0; kk < KK; ++kk) lg[kk] = 0.f;
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
                 const float y = Vec<T>::round(act_fwd(fmaf(v[u][e], sc[e], sh[e]), a.act));   // what rvip_bn_apply would have stored
 #pragma unroll
-                for (int kk = 0; kk < RVIP_MAXK; ++kk) lg[kk] = fmaf(y, wr[e][kk], lg[kk]);
+                for (int kk = 0; kk < KK; ++kk) lg[kk] = fmaf(y, wr[e][kk], lg[kk]);
             }
 #pragma unroll
-            for (int kk = 0; kk < RVIP_MAXK; ++kk) {
+            for (int kk = 0; kk < KK; ++kk) {
                 for (int o = cg >> 1; o > 0; o >>= 1) lg[kk] += __shfl_xor(lg[kk], o);
                 lg[kk] += bias[kk];
             }
@@ -948,13 +951,13 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
             for (int kk = cgi; kk < k; kk += cg) {
                 float zl = lg[0];
 #pragma unroll
-                for (int q = 1; q < RVIP_MAXK; ++q) zl = (kk == q) ? lg[q] : zl;
+                for (int q = 1; q < KK; ++q) zl = (kk == q) ? lg[q] : zl;
                 const float e_ = __expf(-fabsf(zl));
                 const float inv = __frcp_rn(1.f + e_);
                 const float pv = (zl >= 0.f ? 1.f : e_) * inv;
                 pred[(size_t)r * k + kk] = pv;
                 if (yt) {
-                    const float t = yt[(size_t)r * k + kk];
+                    const float t = kk == cgi ? tv[u] : yt[(size_t)r * k + kk];
                     const float d = pv - t;
                     s[0] = fmaf(d, d, s[0]);
                     s[1] += fmaxf(zl, 0.f) - zl * t + __logf(1.f + e_);
@@ -1655,9 +1658,12 @@ extern "C" int rvip_bn_apply_head(const rvip_apply_desc* d, const float* head_w,
     hipStream_t s = (hipStream_t)stream;
     float* ws = y_true ? (float*)workspace : nullptr;
     HeadFuse hd{head_w, head_b, nullptr, k};
-    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_apply_head_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
-    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL(bn_apply_head_kernel<f16_t>, dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
-    else hipLaunchKernelGGL(bn_apply_head_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
+    by_dtype(d->dtype, [&](auto t) {
+        using T = decltype(t);
+        if (k <= 2) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
+        else hipLaunchKernelGGL((bn_apply_head_kernel<T, RVIP_MAXK>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
+        return 0;
+    });
     int rc = check_launch();
     if (rc || !y_true) return rc;
     PostHeadSums p{sums};
