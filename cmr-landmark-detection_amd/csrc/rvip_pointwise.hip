@@ -1060,14 +1060,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(BnBwdArgs a, He
     block_fold<2 * KK, VE>(hpart, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws_hd + (size_t)blockIdx.x * 2 * KK * a.c);
 }
 
-template <typename T>
+template <typename T, int KK>
 __global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(BnBwdArgs a, HeadFuse hd, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
     const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
     const bool active = prow < gm.rpi;
     const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
-    float part[1][VE], c1[VE], c2[VE], c3[VE], wr[VE][RVIP_MAXK];
+    float part[1][VE], c1[VE], c2[VE], c3[VE], wr[VE][KK];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
         part[0][e] = 0.f;
@@ -1076,17 +1076,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(BnBwdArgs a, Hea
         c2[e] = (a.has_bn && active) ? a.coef[a.c + ch] : 0.f;
         c3[e] = (a.has_bn && active) ? a.coef[2 * a.c + ch] : 0.f;
 #pragma unroll
-        for (int kk = 0; kk < RVIP_MAXK; ++kk) wr[e][kk] = (active && kk < hd.k) ? hd.w[ch * hd.k + kk] : 0.f;
+        for (int kk = 0; kk < KK; ++kk) wr[e][kk] = (active && kk < hd.k) ? hd.w[ch * hd.k + kk] : 0.f;
     }
     if (active) {
         for (long long r = r0 + prow; r < r1; r += 2 * gm.rpi) {
-            float z[2][VE], g[2][VE], d[RVIP_MAXK]; size_t e0[2]; bool ok[2];
+            float z[2][VE], g[2][VE], d[KK]; size_t e0[2]; bool ok[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const long long rr = r + u * gm.rpi;
                 ok[u] = rr < r1;
                 e0[u] = (size_t)rr * a.c + cgi * VE;
-                if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); head_grad_vec<T, VE>(hd, rr, wr, d, g[u]); }
+                if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); head_grad_vec<T, VE, KK>(hd, rr, wr, d, g[u]); }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -1535,10 +1535,11 @@ extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
     return launch_fold<1, PostSum>(ws, g.nblk, d->c, p, s);
 }
 
-#define RVIP_APPLY_HEAD_CAP 768          // bn_bwd_apply_head_kernel: ~143 VGPRs -> 3 waves per SIMD -> 768 resident workgroups
-extern "C" int rvip_bn_bwd_apply_head_rows(long long rows, int c, int dtype) {
+// bn_bwd_apply_head_kernel: 127 VGPRs for <= 2 classes (4 waves per SIMD: 1024 resident workgroups), 143 beyond (3 waves: 768)
+#define RVIP_APPLY_HEAD_CAP(k) ((k) <= 2 ? 1024 : 768)
+extern "C" int rvip_bn_bwd_apply_head_rows(long long rows, int c, int dtype, int k) {
     RedGeom g;
-    if (!RVIP_DT_OK(dtype) || !red_geom(rows, c, RVIP_VE(dtype), g, RVIP_APPLY_HEAD_CAP)) return 0;
+    if (!RVIP_DT_OK(dtype) || k <= 0 || !red_geom(rows, c, RVIP_VE(dtype), g, RVIP_APPLY_HEAD_CAP(k))) return 0;
     return g.nblk;
 }
 extern "C" int rvip_bn_bwd_rows(long long rows, int c, int dtype) {      // pass rows / 4 for a pool-fused descriptor
@@ -1712,7 +1713,7 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     if (!d || !d->z || !d->dz || !head_w || !dlogit || !RVIP_DT_OK(d->dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
     if ((!d->dbias && !d->bias_rows) || (d->gamma && !d->coef) || d->drop_rate > 0.f) return RVIP_EINVAL;
     RedGeom g;
-    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g, RVIP_APPLY_HEAD_CAP)) return RVIP_EINVAL;
+    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g, RVIP_APPLY_HEAD_CAP(k))) return RVIP_EINVAL;
     const bool defer = d->bias_rows != nullptr;
     if ((defer ? d->bias_rows_bytes : d->workspace_bytes) < (size_t)g.nblk * d->c * sizeof(float) || (!defer && !d->workspace)) return RVIP_EWORKSPACE;
     BnBwdArgs a;
@@ -1724,9 +1725,12 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     hipStream_t s = (hipStream_t)stream;
     float* ws = defer ? d->bias_rows : (float*)d->workspace;
     HeadFuse hd{head_w, nullptr, dlogit, k};
-    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL(bn_bwd_apply_head_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
-    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL(bn_bwd_apply_head_kernel<f16_t>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
-    else hipLaunchKernelGGL(bn_bwd_apply_head_kernel<float>, dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
+    by_dtype(d->dtype, [&](auto t) {
+        using T = decltype(t);
+        if (k <= 2) hipLaunchKernelGGL((bn_bwd_apply_head_kernel<T, 2>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
+        else hipLaunchKernelGGL((bn_bwd_apply_head_kernel<T, RVIP_MAXK>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
+        return 0;
+    });
     int rc = check_launch();
     if (rc || defer) return rc;
     PostSum p{d->dbias};

@@ -532,7 +532,7 @@ class Engine:
             b.workspace, b.workspace_bytes = self.ws.data_ptr(), self.ws_bytes
             if defer and not (first and self.fuse_first):
                 if st is last and self.fuse_head:
-                    nr = L.rvip_bn_bwd_apply_head_rows(C.c_longlong(rows), st.cout, dt)
+                    nr = L.rvip_bn_bwd_apply_head_rows(C.c_longlong(rows), st.cout, dt, hd['k'])
                 else:
                     nr = L.rvip_bn_bwd_rows(C.c_longlong(rows // 4 if fuse_pool else rows), st.cout, dt)
                 rbuf = torch.empty(nr * st.cout, dtype=torch.float32, device=self.ws.device)

@@ -261,7 +261,7 @@ int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_rows(long long rows, int c, int dtype);
 /* the same count for rvip_bn_bwd_apply_head (its grid is one resident round of workgroups) */
-int rvip_bn_bwd_apply_head_rows(long long rows, int c, int dtype);
+int rvip_bn_bwd_apply_head_rows(long long rows, int c, int dtype, int k);
 
 /* MaxPooling2D backward: dx = route(dpooled -> first max of each 2x2 window of y) + add (add may be
  * NULL; it carries the skip-connection gradient that reaches the same tensor). */
