@@ -71,10 +71,12 @@ __device__ __forceinline__ void block_fold(const float (&part)[K][VE], bool acti
 
 // stage 2: totals[k] for channel ch = sum over workspace rows, then Post::run(ch, totals).
 // 512 threads = 32 channels x 16 row groups; every thread keeps 4 loads in flight (the loop is latency-bound).
-#define RVIP_FOLD_GROUPS 16
-template <int K, typename Post>
-__global__ __launch_bounds__(512) void fold_finalize(const float* __restrict__ ws, int nblk, int width, Post post) {
-    __shared__ double sh[RVIP_FOLD_GROUPS][K][32];
+// GROUPS row groups of 32 channels: 32 (1024 threads) halves the chain of load round trips of the 1024-row folds; a Post whose
+// epilogue needs many registers (PostBnStats: double-precision moving-average arithmetic) stays at 16 -- under the 128-VGPR
+// cap of a 1024-thread workgroup it spills, and a kernel with scratch pays for it at every (tiny) launch.
+template <int K, typename Post, int GROUPS>
+__global__ __launch_bounds__(32 * GROUPS) void fold_finalize(const float* __restrict__ ws, int nblk, int width, Post post) {
+    __shared__ double sh[GROUPS][K][32];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int ch = blockIdx.x * 32 + c;
     double s[K];
@@ -82,17 +84,17 @@ __global__ __launch_bounds__(512) void fold_finalize(const float* __restrict__ w
     for (int k = 0; k < K; ++k) s[k] = 0.0;
     if (ch < width) {
         int b = g;
-        for (; b + 3 * RVIP_FOLD_GROUPS < nblk; b += 4 * RVIP_FOLD_GROUPS) {
+        for (; b + 3 * GROUPS < nblk; b += 4 * GROUPS) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const float v0 = ws[((size_t)b * K + k) * width + ch];
-                const float v1 = ws[((size_t)(b + RVIP_FOLD_GROUPS) * K + k) * width + ch];
-                const float v2 = ws[((size_t)(b + 2 * RVIP_FOLD_GROUPS) * K + k) * width + ch];
-                const float v3 = ws[((size_t)(b + 3 * RVIP_FOLD_GROUPS) * K + k) * width + ch];
+                const float v1 = ws[((size_t)(b + GROUPS) * K + k) * width + ch];
+                const float v2 = ws[((size_t)(b + 2 * GROUPS) * K + k) * width + ch];
+                const float v3 = ws[((size_t)(b + 3 * GROUPS) * K + k) * width + ch];
                 s[k] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
             }
         }
-        for (; b < nblk; b += RVIP_FOLD_GROUPS) {
+        for (; b < nblk; b += GROUPS) {
 #pragma unroll
             for (int k = 0; k < K; ++k) s[k] += (double)ws[((size_t)b * K + k) * width + ch];
         }
@@ -106,16 +108,16 @@ __global__ __launch_bounds__(512) void fold_finalize(const float* __restrict__ w
         for (int k = 0; k < K; ++k) {
             double acc = 0.0;
 #pragma unroll
-            for (int gg = 0; gg < RVIP_FOLD_GROUPS; ++gg) acc += sh[gg][k][c];
+            for (int gg = 0; gg < GROUPS; ++gg) acc += sh[gg][k][c];
             t[k] = acc;
         }
         post.run(ch, t);
     }
 }
 
-template <int K, typename Post>
+template <int K, typename Post, int GROUPS = 32>
 static int launch_fold(const float* ws, int nblk, int width, Post post, hipStream_t s) {
-    hipLaunchKernelGGL((fold_finalize<K, Post>), dim3((unsigned)cdiv(width, 32)), dim3(32 * RVIP_FOLD_GROUPS), 0, s, ws, nblk, width, post);
+    hipLaunchKernelGGL((fold_finalize<K, Post, GROUPS>), dim3((unsigned)cdiv(width, 32)), dim3(32 * GROUPS), 0, s, ws, nblk, width, post);
     return check_launch();
 }
 
@@ -1397,7 +1399,7 @@ extern "C" int rvip_bn_train_stats(const void* z, long long rows, int c, int dty
     int rc = check_launch();
     if (rc) return rc;
     PostBnStats p{gamma, beta, moving_mean, moving_var, mean, invstd, scale, shift, (double)rows, momentum, eps, unbiased_moving};
-    return launch_fold<2, PostBnStats>(ws, g.nblk, c, p, s);
+    return launch_fold<2, PostBnStats, 16>(ws, g.nblk, c, p, s);
 }
 
 // Stage 2 alone: fold `rows` partial rows [rows][2][c] (sum, sum of squares; e.g. written by rvip_conv3x3_fwd_stats)
@@ -1408,7 +1410,7 @@ extern "C" int rvip_bn_stats_finalize(const float* partial, int rows, long long 
     (void)hipGetLastError();
     if (!partial || rows <= 0 || count <= 0 || c <= 0 || !mean || !invstd || !scale || !shift) return RVIP_EINVAL;
     PostBnStats p{gamma, beta, moving_mean, moving_var, mean, invstd, scale, shift, (double)count, momentum, eps, unbiased_moving};
-    return launch_fold<2, PostBnStats>(partial, rows, c, p, (hipStream_t)stream);
+    return launch_fold<2, PostBnStats, 16>(partial, rows, c, p, (hipStream_t)stream);
 }
 
 extern "C" int rvip_bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int c,
@@ -1858,7 +1860,7 @@ extern "C" int rvip_c1_stage_stats(const rvip_c1_desc* c, const float* gamma, co
     if (rc) return rc;
     const long long rows = (long long)c->n * c->h * c->w_;
     PostBnStats p{gamma, beta, moving_mean, moving_var, mean, invstd, scale, shift, (double)rows, momentum, eps, unbiased_moving};
-    return launch_fold<2, PostBnStats>((float*)workspace, nb, cv.c, p, s);
+    return launch_fold<2, PostBnStats, 16>((float*)workspace, nb, cv.c, p, s);
 }
 
 extern "C" int rvip_c1_stage_apply(const rvip_c1_desc* c, const rvip_apply_desc* d, void* stream) {
