@@ -1237,20 +1237,15 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     constexpr int BPR = TW / 16;                                          // pixel blocks per tile row
     constexpr int TXN = TAPS == 9 ? 3 : 2;
     const int row0 = (wv * (NPT * 32)) / TW;                              // first tile row of this wave
-    int in_base[TXN][BPR];
+    // one address register per tap column / for the weights: a second pixel block of a tile row is 16 halo columns (1 KiB) further,
+    // a further channel block 16 rows (1 KiB) further, and neither moves bit 2 of the swizzle key -- compile-time offsets
+    int in_base[TXN];
 #pragma unroll
-    for (int tx = 0; tx < TXN; ++tx)
-#pragma unroll
-        for (int cx = 0; cx < BPR; ++cx) {
-            const int hx = cx * 16 + i16 + tx + (TAPS == 4 ? pb : 0);
-            in_base[tx][cx] = (row0 * HWD + hx) * 64 + ((kq ^ slot_swz(hx)) << 4);
-        }
-    int w_addr[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        const int r = cb * 16 + i16;
-        w_addr[cb] = r * 64 + ((kq ^ slot_swz(r)) << 4);
+    for (int tx = 0; tx < TXN; ++tx) {
+        const int hx = i16 + tx + (TAPS == 4 ? pb : 0);
+        in_base[tx] = (row0 * HWD + hx) * 64 + ((kq ^ slot_swz(hx)) << 4);
     }
+    const int w_addr = i16 * 64 + ((kq ^ slot_swz(i16)) << 4);
     f32x4 acc[NCB][NPB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -1279,13 +1274,13 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             uint4 fa[2][NCB], fb[2][HB];
             auto load_a = [&](int tap, int buf) __attribute__((always_inline)) {
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) fa[buf][cb] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + w_addr[cb]);
+                for (int cb = 0; cb < NCB; ++cb) fa[buf][cb] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + cb * 1024 + w_addr);
             };
             auto load_b = [&](int tap, int half, int buf) __attribute__((always_inline)) {
 #pragma unroll
                 for (int p = 0; p < HB; ++p) {
                     const int blk = half * HB + p;
-                    fb[buf][p] = *reinterpret_cast<const uint4*>(sin + in_base[tap % TXN][blk % BPR] + (tap / TXN + blk / BPR) * HWD * 64);
+                    fb[buf][p] = *reinterpret_cast<const uint4*>(sin + in_base[tap % TXN] + (blk % BPR) * 1024 + (tap / TXN + blk / BPR) * HWD * 64);
                 }
             };
             load_a(0, 0);
