@@ -460,7 +460,10 @@ __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(ApplyArgs a, int cg
 // backward of conv -> [act] -> BN -> [act] -> dropout
 // ------------------------------------------------------------------------------------------------
 #ifndef RVIP_BWD_U
-#define RVIP_BWD_U 2             // rows in flight per thread in the BN-backward passes
+#define RVIP_BWD_U 2             // rows in flight per thread in the BN-backward reduce pass
+#endif
+#ifndef RVIP_BWD_U_APPLY
+#define RVIP_BWD_U_APPLY 1       // ... and in the apply pass, which also stores (measured 1 / 2 / 4: 0.733 / 0.761 / 0.91 ms per step; reduce 0.551 / 0.536 / 0.63)
 #endif
 struct BnBwdArgs {
     const unsigned char* dy; const unsigned char* z; unsigned char* dz;
@@ -633,10 +636,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
             }
         }
     } else if (active) {
-        for (long long r = r0 + prow; r < r1; r += RVIP_BWD_U * gm.rpi) {
-            float z[RVIP_BWD_U][VE], g[RVIP_BWD_U][VE]; size_t e0[RVIP_BWD_U]; bool ok[RVIP_BWD_U];
+        for (long long r = r0 + prow; r < r1; r += RVIP_BWD_U_APPLY * gm.rpi) {
+            float z[RVIP_BWD_U_APPLY][VE], g[RVIP_BWD_U_APPLY][VE]; size_t e0[RVIP_BWD_U_APPLY]; bool ok[RVIP_BWD_U_APPLY];
 #pragma unroll
-            for (int u = 0; u < RVIP_BWD_U; ++u) {
+            for (int u = 0; u < RVIP_BWD_U_APPLY; ++u) {
                 const long long rr = r + u * gm.rpi;
                 ok[u] = rr < r1;
                 e0[u] = (size_t)rr * a.c + cgi * VE;
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
                 if (ok[u]) { Vec<T>::load_nt(a.z + e0[u] * sizeof(T), z[u]); Vec<T>::load_nt(a.dy + e0[u] * sizeof(T), g[u]); }
             }
 #pragma unroll
-            for (int u = 0; u < RVIP_BWD_U; ++u) {
+            for (int u = 0; u < RVIP_BWD_U_APPLY; ++u) {
                 if (!ok[u]) continue;
                 xform_g<T, VE>(a, e0[u], cgi * VE, key, z[u], g[u]);
                 float d[VE];
