@@ -336,7 +336,10 @@ __device__ __forceinline__ void apply_xform(const ApplyArgs& a, size_t e0, const
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int rpi, long long ngroups) {
     constexpr int VE = Vec<T>::VE;
-    constexpr int UNR = POOL ? 2 : 4;
+#ifndef RVIP_APPLY_UNR
+#define RVIP_APPLY_UNR 1      // rows per round and thread: 1 / 2 / 4 measured 0.513 / 0.518 / 0.531 ms per step over the 17 launches (the store round size again)
+#endif
+    constexpr int UNR = POOL ? 2 : RVIP_APPLY_UNR;
     const int tid = threadIdx.x, cv = tid % cg, prow = tid / cg;
     if (prow >= rpi) return;
     float sc[VE], sh[VE];
@@ -409,7 +412,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(ApplyArgs a, int cg, int wpi, long long ngroups) {
     constexpr int VE = Vec<T>::VE;
 #ifndef RVIP_POOL2_UNR
-#define RVIP_POOL2_UNR 2
+#define RVIP_POOL2_UNR 1
 #endif
     constexpr int UNR = RVIP_POOL2_UNR;
     const int tid = threadIdx.x, cv = tid % cg, px = (tid / cg) & 1, wslot = tid / (2 * cg);
@@ -1445,7 +1448,7 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const long long units = d->pooled ? (long long)d->n * (d->h / 2) * (d->w / 2) : (long long)d->n * d->h * d->w;
     const long long ngroups = cdiv(units, rpi);
-    const int unr = d->pooled ? 2 : 4;
+    const int unr = d->pooled ? 2 : RVIP_APPLY_UNR;
     long long nb = cdiv(ngroups, unr);
     static const long long nb_cap = [] { const char* e = getenv("RVIP_APPLY_BLOCKS"); return e ? atoll(e) : 1024LL; }();     // one resident round of workgroups: 7-10 % faster than 4096 (tools/probe_apply.py)
     if (nb > nb_cap) nb = nb_cap;
