@@ -390,7 +390,7 @@ class Model:
             if shuffle:
                 np.random.shuffle(order)                       # Keras shuffles the batch order of a Sequence
             acc = None
-            for step, (xb, yb) in enumerate(_prefetch(gen, order[:steps], max_queue_size)):
+            for step, (xb, yb) in enumerate(_prefetch(gen, order[:steps], max_queue_size, workers)):
                 xb, yb = self._shard(xb, yb)
                 eng = self._engine(xb.shape[0])
                 eng.load_input(xb, yb)
@@ -433,10 +433,29 @@ class Model:
         return _Hist()
 
 
-def _prefetch(gen, order, depth):
-    """Background producer thread (the Keras OrderedEnqueuer of fit(max_queue_size=), train_model.py:111):
-    generator batches are prepared on the host while the GPU runs the previous step."""
-    q = queue.Queue(maxsize=max(int(depth), 1))
+def _prefetch(gen, order, depth, workers=1):
+    """Background producers (the Keras OrderedEnqueuer of fit(max_queue_size=, workers=), train_model.py:111): generator batches
+    are prepared on the host while the GPU runs the previous steps; `workers` > 1 prepares that many batches at a time on a
+    thread pool (NumPy / SciPy release the GIL in their kernels) and still delivers them in `order`."""
+    depth = max(int(depth), 1)
+    workers = max(int(workers or 1), 1)
+    if workers > 1:
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            pending, it = deque(), iter(order)
+            for i in it:
+                pending.append(ex.submit(gen.__getitem__, int(i)))
+                if len(pending) >= max(depth, workers):
+                    break
+            while pending:
+                item = pending.popleft().result()              # re-raises a generator error in the training thread
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(ex.submit(gen.__getitem__, int(nxt)))
+                yield item
+        return
+    q = queue.Queue(maxsize=depth)
     stop = object()
 
     def work():
