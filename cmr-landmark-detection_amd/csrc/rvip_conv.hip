@@ -668,6 +668,10 @@ template <int M>
 __device__ __forceinline__ float swz(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (M << 10) | 0x1f));
 }
+// value of lane ^ 1 through DPP (quad_perm [1,0,3,2]): __shfl_xor(v, 1) compiles to ds_bpermute_b32, a trip through the LDS crossbar
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float lane_channel_sum(const float (&a)[16], int j) {
     float b[8], c[4], d[2];
     const bool b4 = j & 16, b3 = j & 8, b2 = j & 4, b1 = j & 2;
@@ -1383,7 +1387,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                             const float t = acc[cb][top][r] + acc[cb][bot][r];
                             acc[cb][top][r] = 0.f;
                             acc[cb][bot][r] = 0.f;
-                            v[s2][r] = t + __shfl_xor(t, 1);
+                            v[s2][r] = t + lane_xor1(t);
                         }
                     }
                     const int gym = (kq & 1) ? gyu[1] : gyu[0], gxm = (kq & 1) ? gxu[1] : gxu[0];
