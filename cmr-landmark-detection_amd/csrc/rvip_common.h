@@ -135,6 +135,12 @@ __device__ __forceinline__ void dropout_keep(uint32_t key, unsigned long long e0
     }
 }
 
+// values of lane ^ 1 / lane ^ 2 through DPP quad permutes (__shfl_xor compiles to ds_bpermute_b32, a trip through the LDS crossbar)
+__device__ __forceinline__ float lane_xor1_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float lane_xor2_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -952,7 +952,12 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
             }
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                for (int o = cg >> 1; o > 0; o >>= 1) lg[kk] += __shfl_xor(lg[kk], o);
+                if (cg == 4) {                                       // 32 channels: the four lanes of a pixel are one DPP quad
+                    lg[kk] += lane_xor2_dpp(lg[kk]);
+                    lg[kk] += lane_xor1_dpp(lg[kk]);
+                } else {
+                    for (int o = cg >> 1; o > 0; o >>= 1) lg[kk] += __shfl_xor(lg[kk], o);
+                }
                 lg[kk] += bias[kk];
             }
             if (r >= r1) continue;
