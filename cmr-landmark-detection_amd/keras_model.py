@@ -161,16 +161,83 @@ class Model:
     def weight_names(self):
         return ['%s/%s:0' % (ln, wn) for (ln, wn, _, _, _) in self.plan.weight_specs()]
 
-    def save_weights(self, filepath, overwrite=True, **_):
-        """Weights-only checkpoint (ModelCheckpoint(save_weights_only=True), KerasCallbacks.py:54-61).  Keras-HDF5
-        is SURVEY 8(f) row 1 (h5py is absent here); the container is .npz keyed '<layer>/<weight>:0'."""
-        arrs = OrderedDict(zip(self.weight_names(), self.get_weights()))
-        with open(filepath, 'wb') as f:
-            np.savez(f, **arrs)
+    def _layers_with_weights(self):
+        """[(layer name, [(Keras weight name, index into get_weights())])] over EVERY layer of the table, in model.layers order."""
+        specs = self.plan.weight_specs()
+        by_layer = OrderedDict((l.name, []) for l in self.plan.layers)
+        for i, (ln, wn, _, _, _) in enumerate(specs):
+            by_layer[ln].append(('%s/%s:0' % (ln, wn), i))
+        return list(by_layer.items())
 
-    def load_weights(self, filepath, **_):
-        with np.load(filepath) as z:
-            self.set_weights([z[k] for k in self.weight_names()])
+    def save_weights(self, filepath, overwrite=True, save_format=None, **_):
+        """Weights-only checkpoint (ModelCheckpoint(save_weights_only=True), KerasCallbacks.py:54-61).  ``*.h5`` / ``*.hdf5`` /
+        ``*.keras`` (or save_format='h5') write the Keras-HDF5 layout ``model.load_weights`` of the reference reads
+        (predict_model.py:75-76) through the in-tree HDF5 writer (keras_h5.py); ``*.npz`` keeps the NumPy container keyed
+        '<layer>/<weight>:0'.  Data-parallel: BN moving statistics are mean-reduced over the replicas first (Keras
+        MirroredVariable aggregation MEAN) -- a collective every rank must enter -- and only rank 0 writes."""
+        import os
+        self.sync_moving_statistics()
+        weights = self.get_weights()
+        if self._dist()[0] != 0:
+            return
+        if not overwrite and os.path.exists(filepath):
+            raise FileExistsError(filepath)
+        ext = os.path.splitext(str(filepath))[1].lower()
+        if save_format in ('h5', 'hdf5', 'keras') or (save_format is None and ext in ('.h5', '.hdf5', '.keras')):
+            from . import keras_h5
+            layers = [(ln, [(wn, weights[i]) for wn, i in ws]) for ln, ws in self._layers_with_weights()]
+            keras_h5.save_keras_weights(filepath, layers)
+        elif save_format in (None, 'npz') :
+            arrs = OrderedDict(zip(self.weight_names(), weights))
+            with open(filepath, 'wb') as f:
+                np.savez(f, **arrs)
+        else:
+            raise ValueError("save_format=%r: 'h5' (Keras-HDF5) and 'npz' are written; the TensorFlow checkpoint format is not" % (save_format,))
+
+    def load_weights(self, filepath, by_name=False, **_):
+        """Keras-HDF5 (weights-only ``model.h5`` or the /model_weights group of a full ``model.save`` file) or ``.npz``.
+        HDF5 files load the way Keras does: by topology -- the file's layers that hold weights, in ``layer_names`` order,
+        against this model's -- or ``by_name``.  Shapes must match (Keras raises ValueError as well)."""
+        with open(filepath, 'rb') as f:
+            magic = f.read(8)
+        if magic[:2] == b'PK':                                                     # NumPy .npz (zip)
+            with np.load(filepath) as z:
+                self.set_weights([z[k] for k in self.weight_names()])
+            return
+        from . import keras_h5
+        file_layers, _ = keras_h5.load_keras_weights(filepath)
+        mine = [(ln, ws) for ln, ws in self._layers_with_weights() if ws]
+        new = self.get_weights()
+        if by_name:
+            for ln, ws in mine:
+                if ln in file_layers and file_layers[ln]:
+                    vals = file_layers[ln]
+                    if len(vals) != len(ws):
+                        raise ValueError('Layer %s expects %d weight(s), but the saved weights have %d element(s)' % (ln, len(ws), len(vals)))
+                    for (_, i), (_, arr) in zip(ws, vals):
+                        new[i] = arr
+        else:
+            theirs = [(ln, ws) for ln, ws in file_layers.items() if ws]
+            if len(theirs) != len(mine):
+                raise ValueError('You are trying to load a weight file containing %d layers into a model with %d layers.'
+                                 % (len(theirs), len(mine)))
+            for (ln, ws), (fn, vals) in zip(mine, theirs):
+                if len(vals) != len(ws):
+                    raise ValueError('Layer %s (file: %s) expects %d weight(s), but the saved weights have %d element(s)'
+                                     % (ln, fn, len(ws), len(vals)))
+                for (_, i), (_, arr) in zip(ws, vals):
+                    new[i] = arr
+        self.set_weights(new)
+
+    def sync_moving_statistics(self):
+        """BN moving mean / variance are per-replica state updated from per-replica batch statistics (plain
+        BatchNormalization under MirroredStrategy, Unets.py:70-75); Keras reads such a variable as the MEAN over the replicas
+        (SURVEY 2.3).  Called before evaluation / checkpointing: all-reduce(sum) / world of the flat moving block."""
+        rank, world = self._dist()
+        if world > 1 and self._params is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self._params.moving)
+            self._params.moving.div_(world)
 
     # ---------------------------------------------------------------------------------------------
     # device
