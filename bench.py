@@ -26,6 +26,22 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0       # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
+PMC_SUMMARY = 'r02_pmc_summary.json'
+
+
+def csrc_sha16():
+    """Identity of the kernel sources a PMC summary was taken on (tools/pmc_summary.py stores the same digest)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'cmr-landmark-detection_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'cmr-landmark-detection_amd', 'csrc', '*.h'))
+                    + [os.path.join(ROOT, 'include', 'rvip_hip.h')]):
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def workload_key(args):
+    return 'dim%d_f%d_d%d_b%d_t%d_%s' % (args.dim, args.filters, args.depth, args.batch, args.frames, args.precision)
 
 
 def main():
@@ -41,6 +57,8 @@ def main():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'], help='fp16: BASELINE.json configs[3] (static loss scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--no-fit', action='store_true', help='skip the Model.fit throughput measurement')
+    ap.add_argument('--no-aux', action='store_true', help='skip the informational predict pass (PMC runs: only training-step kernels)')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--detail', default=None, help='write a per-launch timing table (conv / wgrad shapes) to this file')
     args = ap.parse_args()
@@ -82,76 +100,18 @@ def main():
     eng.load_input(x, y)                       # synthetic batch resident in HBM before the timed region
     torch.cuda.synchronize()
 
-    def fwd_bwd():
-        eng.stage_input()                      # fp32 slice -> network input dtype (on device)
-        eng.forward(training=True)
-        eng.backward()
-
-    overlap = eng.overlap_ok()                 # N > 1: gradient all-reduce in two buckets, the first under the encoder's backward
-
-    def fwd_bwd_head():                        # forward + backward of head, decoder, bottleneck -> gradient bucket 0
-        eng.stage_input()
-        eng.forward(training=True)
-        eng.backward_part(0)
-
-    def step():                                # eager: fwd + bwd + [RCCL all-reduce] + Adam
-        if overlap:
-            fwd_bwd_head()
-            w0 = eng.allreduce_bucket_async(0)
-            eng.backward_part(1)
-            w1 = eng.allreduce_bucket_async(1)
-            w0.wait()
-            w1.wait()
-        else:
-            fwd_bwd()
-            eng.allreduce_grads()
-        eng.optimizer_step()
-
-    def capture(fn):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            fn()
-        torch.cuda.synchronize()
-        return g
-
-    for _ in range(min(2, max(args.warmup, 1))):
-        step()
+    # The step is the product's: Engine.train_step (what Model.fit / train_on_batch call) runs eagerly once, captures the
+    # step into a hipGraph on its second call (around the RCCL collectives when N > 1) and replays it from then on.
+    if args.no_graph:
+        os.environ['RVIP_GRAPH'] = '0'
+    run = eng.train_step
+    for _ in range(max(2, min(args.warmup, 3))):
+        run()
     torch.cuda.synchronize()
-    run, launch = step, 'eager'
-    if not args.no_graph:
-        try:                                   # hipGraph replay removes ~190 host launches per step; never required
-            if world == 1:
-                g_all = capture(lambda: (fwd_bwd(), eng.optimizer_step()))
-                run, launch = g_all.replay, 'hipGraph'
-            elif overlap:                      # collectives stay outside the graphs: A1 -> [bucket 0 all-reduce || A2] -> bucket 1 -> B
-                g_a1, g_a2, g_b = capture(fwd_bwd_head), capture(lambda: eng.backward_part(1)), capture(eng.optimizer_step)
-
-                def run():
-                    g_a1.replay()
-                    w0 = eng.allreduce_bucket_async(0)
-                    g_a2.replay()
-                    w1 = eng.allreduce_bucket_async(1)
-                    w0.wait()
-                    w1.wait()
-                    g_b.replay()
-                launch = 'hipGraph x3 + two overlapped all-reduce buckets'
-            else:                              # the collective stays outside the graphs: A (fwd+bwd) -> all-reduce -> B (Adam)
-                g_a, g_b = capture(fwd_bwd), capture(eng.optimizer_step)
-
-                def run():
-                    g_a.replay()
-                    eng.allreduce_grads()
-                    g_b.replay()
-                launch = 'hipGraph x2 + eager all-reduce'
-        except Exception as e:
-            sys.stderr.write('hipGraph capture failed (%s); running eagerly\n' % (e,))
-            run, launch = step, 'eager'
-            torch.cuda.synchronize()
+    launch = eng.launch_mode
+    overlap = eng.overlap_ok()
+    if world > 1 and launch.startswith('hipGraph'):
+        launch += ' (two overlapped all-reduce buckets)' if overlap else ' (one all-reduce)'
 
     def barrier():
         if world > 1:
@@ -175,23 +135,10 @@ def main():
     loss = float(eng.loss.item())
     assert np.isfinite(loss) or os.environ.get('RVIP_DBG'), 'training diverged in the benchmark'     # RVIP_DBG: timing ablations compute garbage
 
-    # ---- the same step fed from HOST buffers (what Model.fit hands over): H2D of x and y every step, then the replay.  Reported
-    # beside `value`, never as it (the contract times resident inputs).
-    host_rate = None
-    if rank == 0 and world == 1:
-        hs = max(3, min(args.steps, 10))
-        torch.cuda.synchronize()
-        th0 = time.perf_counter()
-        for _ in range(hs):
-            eng.load_input(x, y)               # pageable NumPy -> device (x 8.4 MB + y 16.8 MB at config 2), includes the fp32 -> bf16 staging
-            run()
-        torch.cuda.synchronize()
-        host_rate = round(B * hs / (time.perf_counter() - th0), 2)
-
     # ---- inference (Model.predict: BN on the moving statistics, no dropout), forward only, eager launches; and the HBM the
     # whole training state of this configuration occupies.  Informational keys beside `value`.
-    predict_rate = hbm_gb = None
-    if rank == 0 and world == 1:
+    predict_rate = hbm_gb = fit_rate = fit_info = None
+    if rank == 0 and world == 1 and not args.no_aux:
         for _ in range(2):
             eng.forward(training=False)
         torch.cuda.synchronize()
@@ -202,6 +149,8 @@ def main():
             eng.forward(training=False)
         torch.cuda.synchronize()
         predict_rate = round(B * ps / (time.perf_counter() - tp0), 2)
+
+    if rank == 0:
         hbm_gb = round(torch.cuda.max_memory_allocated() / 2 ** 30, 3)
 
     # ---- roofline pass: HIP events around every launch, eager, on the launch stream -------------------------
@@ -257,20 +206,46 @@ def main():
         ms = sum(a.elapsed_time(b) for a, b, _ in cv)
         fl = sum(f for _, _, f in cv)
         achieved = fl / (ms * 1e-3) / 1e12
-        traffic = None
-        try:                                   # HBM bytes per launch of this kernel family from the committed PMC pass
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))['kernels']
-            fam = [pm[k] for k in ('conv3x3_igemm_dma', 'conv3x3_igemm_ws') if k in pm]      # both generations serve this entry point
-            traffic = round(sum(f['hbm_bytes_per_launch'] * f['launches_sampled'] for f in fam) / sum(f['launches_sampled'] for f in fam))
-        except Exception:
-            pass
+        traffic, traffic_src, hbm_step, pmc_note = None, None, None, None
+        try:                                   # HBM bytes per launch of this kernel family from the committed PMC passes of THESE kernels
+            pm = json.load(open(os.path.join(ROOT, 'profiles', PMC_SUMMARY)))
+            if pm.get('csrc_sha16') != csrc_sha16():
+                pmc_note = '%s was taken on other kernel sources (%s, tree is %s): traffic not reported' % (PMC_SUMMARY, pm.get('csrc_sha16'), csrc_sha16())
+            elif pm.get('workload') != workload_key(args):
+                pmc_note = '%s is for workload %s' % (PMC_SUMMARY, pm.get('workload'))
+            else:
+                fam = [v for k, v in pm['kernels'].items() if k.startswith('conv3x3_igemm')]
+                if not fam:
+                    pmc_note = '%s holds no conv3x3_igemm kernel' % PMC_SUMMARY
+                else:
+                    traffic = round(sum(f['hbm_bytes_per_launch'] * f['launches_per_step'] for f in fam) / sum(f['launches_per_step'] for f in fam))
+                    traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2, KiB units)' % PMC_SUMMARY
+                    hbm_step = pm.get('hbm_bytes_per_step')
+        except FileNotFoundError:
+            pmc_note = 'profiles/%s missing' % PMC_SUMMARY
         roof = dict(bound='mfma', kernel='conv3x3_igemm (forward incl. fused BN statistics + data-gradient launches)', achieved=round(achieved, 2),
                     peak=PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3, unit='TFLOP/s',
                     frac=round(achieved / (PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3), 4),
-                    traffic=traffic, traffic_source='profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)' if traffic else None,
+                    traffic=traffic, traffic_source=traffic_src, traffic_note=pmc_note,
                     algorithmic_bytes_per_launch=round(plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * 2.0 / 3.0 * B / max(len(cv) // reps, 1)),
                     launches_per_step=len(cv) // reps, avg_launch_ms=round(ms / len(cv), 4),
                     flops_per_launch=fl / len(cv))
+
+    # ---- the product's own loop: Model.fit on a SyntheticSAXGenerator held in memory (the reference trains with in_memory=True,
+    # train_model.py:199-203): generator -> rank shard -> pinned ring -> copy stream -> replayed step, per-epoch logs.  Reported
+    # beside `value`, never as it (the contract times resident inputs).  Runs last: it trains on other batches.
+    if rank == 0 and world == 1 and not args.no_fit:
+        nb, ep = 16, max(2, min(6, args.steps // 4))
+        fgen = rvip.Generators.SyntheticSAXGenerator(nb * B, dict(DIM=cfg['DIM'], BATCHSIZE=B, GAUS=True, SIGMA=2, SHUFFLE=True, SEED=1), in_memory=True)
+        model.fit(fgen, epochs=1, verbose=0, max_queue_size=4, workers=4)          # fills the generator's sample cache (untimed)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        hist = model.fit(fgen, epochs=ep, verbose=0, max_queue_size=4, workers=4)
+        torch.cuda.synchronize()
+        fit_rate = round(nb * B * ep / (time.perf_counter() - tf0), 2)
+        fit_info = {'epochs': ep, 'steps_per_epoch': nb, 'launch': eng.launch_mode, 'loss_first_last': [hist.history['loss'][0], hist.history['loss'][-1]],
+                    'input': 'host float32 batches (x %.1f MB + y %.1f MB per step) through pinned ring + copy stream' % (
+                        eng.x_stage.numel() * 4 / 1e6, eng.y_true.numel() * 4 / 1e6)}
 
     fwd_flops, step_flops = plan.flops_per_slice()
     slices = B * world * args.steps
@@ -282,13 +257,17 @@ def main():
             'value': round(value, 2), 'unit': 'slices/s' if args.frames <= 0 else 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'fp16': 'f16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': '%d-level 2D U-Net F=%d, %dx%d, batch %d per GPU, fwd+loss(MSE)+bwd+Adam%s' % (
-                args.depth, args.filters, args.dim, args.dim, B, ' + RCCL grad all-reduce' if world > 1 else ''),
+            'config': {'workload': '%d-level %s U-Net F=%d, %s, batch %d per GPU, fwd+loss(MSE)+bwd+Adam%s' % (
+                args.depth, '3D cine (Conv3D 3x3x3, pool 1x2x2)' if args.frames > 0 else '2D', args.filters,
+                ('%dx%dx%d' % (args.frames, args.dim, args.dim)) if args.frames > 0 else '%dx%d' % (args.dim, args.dim), B,
+                ' + RCCL grad all-reduce' if world > 1 else ''),
                 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch, 'collective': ('%s all-reduce of %d fp32 gradients' % (backend, model._params.count)) if world > 1 else None,
                 'gflop_per_slice_fwd_bwd': round(step_flops / 1e9, 3)},
-            'host_input_slices_per_s': host_rate, 'predict_slices_per_s_eager': predict_rate, 'hbm_allocated_gib': hbm_gb,
+            'fit_slices_per_s': fit_rate, 'fit': fit_info, 'predict_slices_per_s_eager': predict_rate, 'hbm_allocated_gib': hbm_gb,
+            'hbm_bytes_per_step': hbm_step, 'algorithmic_bytes_per_step': round(plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * B),
+            'wasted_traffic_ratio': round(hbm_step / (plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * B), 3) if hbm_step else None,
             'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),
-            'loss': loss,
+            'loss': loss, 'steps_executed_total': max(2, min(args.warmup, 3)) + args.warmup + args.steps + 3,
             'roofline': roof,
             'kernels': per_kernel,
         }

@@ -61,6 +61,7 @@ class BaseGenerator:
         self.GAUS = config.get('GAUS', False)
         self.SIGMA = config.get('SIGMA', 1)
         self.INDICES = list(range(n_samples))
+        self._epochs_seen = 0
         self.on_epoch_end()
 
     def __len__(self):
@@ -77,7 +78,11 @@ class BaseGenerator:
     def on_epoch_end(self):
         self.INDICES = np.arange(len(self.INDICES))
         if self.SHUFFLE:
-            np.random.shuffle(self.INDICES)        # the reference draws from the global NumPy RNG as well (:172)
+            # The reference draws from the process-global NumPy RNG (:172; its SEED key is read and never used, :90).  Here the
+            # permutation comes from (SEED, number of reshuffles): every data-parallel rank -- a process of its own, unlike the
+            # one-process MirroredStrategy -- must see the same order to slice the same global batch.
+            self.INDICES = np.random.default_rng([int(self.SEED), self._epochs_seen]).permutation(len(self.INDICES))
+        self._epochs_seen += 1
 
     def __data_generation__(self, idxs):
         x = np.empty((self.BATCHSIZE, *self.DIM, 1), dtype=np.float32)

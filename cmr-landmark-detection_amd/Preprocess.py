@@ -169,8 +169,9 @@ def clip_quantile(img_nda, upper_quantile=.999, lower_boundary=0):
 
 
 def pad_and_crop(ndarray, target_shape=(10, 10, 10)):
-    """Preprocess.py:494-541: centre pad (zeros) / crop per axis; for an odd difference padding puts the extra element after,
-    cropping removes the extra element in front."""
+    """Preprocess.py:494-541: centre pad (zeros) / crop per axis.  Odd differences: the reference takes floor(x / 2) of the SIGNED
+    difference, so both padding (x < 0: |floor(x/2)| in front, one less behind) and cropping (floor(x/2) + 1 in front) put the
+    extra element in FRONT -- pinned by tests/golden/ref_numpy_fixtures.npz, which the reference's own function produced."""
     ndarray = np.asarray(ndarray)
     out = np.zeros(tuple(target_shape), dtype=np.float64)
     src, dst = [], []
@@ -179,8 +180,8 @@ def pad_and_crop(ndarray, target_shape=(10, 10, 10)):
         if diff > 0:                                   # crop: (floor+1, floor) for odd differences
             front = diff // 2 + (diff % 2)
             src.append(slice(front, front + t)); dst.append(slice(0, t))
-        elif diff < 0:                                 # pad: (floor, floor+1)
-            front = (-diff) // 2
+        elif diff < 0:                                 # pad: (|floor(diff / 2)|, |floor(diff / 2) + 1|)
+            front = (-diff + 1) // 2
             src.append(slice(0, n)); dst.append(slice(front, front + n))
         else:
             src.append(slice(0, n)); dst.append(slice(0, t))

@@ -293,7 +293,8 @@ class Engine:
         self.ws_bytes = need
         self.ws_wg = torch.empty(need_wg // 4 + 64, **f32)
         self.ws_wg_bytes = need_wg
-        self.side = torch.cuda.Stream(device=dev) if os.environ.get('RVIP_SIDE_STREAM', '0') == '1' else None
+        self._graphs, self._eager_steps, self.launch_mode = None, 0, 'eager'
+        self.pin_x = None
         self._build_lists()
 
     # -- helpers --------------------------------------------------------------------------------------
@@ -645,57 +646,7 @@ class Engine:
         self._run(self.fwd_eval, self.stream())
 
     def backward(self):
-        """Backward launch list.  With RVIP_SIDE_STREAM=1 the weight gradient of a stage (MFMA-bound, needed only by the
-        optimizer) is launched on a side stream right AFTER that stage's data gradient has been queued on the main one, so
-        that it runs next to the HBM-bound BN-backward passes of the stage below instead of next to another LDS-filling
-        conv; the side stream is joined before the batched folds.  Works eagerly and under stream capture (the fork /
-        join events become graph edges).  Off by default: measured slower on MI355X in both schedules tried (weight
-        gradient next to the data gradient: 6.97 vs 6.67 ms; next to the BN-backward passes: 6.39 vs 6.11 ms)."""
-        torch = _torch()
-        main = torch.cuda.current_stream()
-        if self.side is None:
-            return self._run(self.bwd, main.cuda_stream)
-        L = N.lib()
-        s_main, s_side = C.c_void_p(main.cuda_stream), C.c_void_p(self.side.cuda_stream)
-        state = {'pending': None, 'forked': False}
-
-        def to_side(th):
-            ev = torch.cuda.Event()
-            ev.record(main)
-            self.side.wait_event(ev)
-            state['forked'] = True
-            rc = th[0](*th[1], s_side)
-            if rc:
-                N.check(rc, th[0].__name__)
-
-        def join():
-            if state['pending'] is not None:
-                to_side(state['pending'])
-                state['pending'] = None
-            if state['forked']:
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-                main.wait_event(ev)
-                state['forked'] = False
-        for th in self.bwd:
-            fn, args = th[0], th[1]
-            if fn is L.rvip_conv3x3_wgrad:
-                if state['pending'] is not None:
-                    to_side(state['pending'])
-                state['pending'] = th                      # goes out after the data gradient that follows it in the list
-                continue
-            if fn is L.rvip_conv3x3_c1_wgrad or fn is L.rvip_conv3d_c1_wgrad:
-                to_side(th)
-                continue
-            if fn is L.rvip_fold_rows_batch:
-                join()
-            rc = fn(*args, s_main)
-            if rc:
-                N.check(rc, fn.__name__)
-            if fn is L.rvip_conv3x3_fwd and state['pending'] is not None:
-                to_side(state['pending'])
-                state['pending'] = None
-        join()
+        self._run(self.bwd, self.stream())
 
     def optimizer_step(self):
         self._run(self.opt, self.stream())
@@ -707,7 +658,7 @@ class Engine:
 
     # -- overlapped data-parallel step: two gradient buckets ------------------------------------------------------
     def overlap_ok(self):
-        return (self.world > 1 and self.side is None and self.bwd_split and 0 < self.grad_split < self.P.grad.numel()
+        return (self.world > 1 and self.bwd_split and 0 < self.grad_split < self.P.grad.numel()
                 and os.environ.get('RVIP_OVERLAP_ALLREDUCE', '1') != '0')
 
     def backward_part(self, part):
@@ -722,21 +673,120 @@ class Engine:
         g = self.P.grad[self.grad_split:] if part == 0 else self.P.grad[:self.grad_split]
         return dist.all_reduce(g, async_op=True)
 
-    def train_step(self):
-        """fwd + loss + bwd + [all-reduce] + Adam on the batch already in the device buffers."""
-        s = self.stream()
-        self._run(self.fwd_train, s)
-        if self.overlap_ok():
+    # -- the training step as the product runs it: captured once per engine, replayed ever after -------------------
+    def _step_parts(self):
+        """The step as a list of segments; a collective separates two segments (it stays outside the graphs)."""
+        def a_all():
+            self.stage_input()
+            self._run(self.fwd_train, self.stream())
+            self._run(self.bwd, self.stream())
+
+        def a_head():
+            self.stage_input()
+            self._run(self.fwd_train, self.stream())
             self.backward_part(0)
-            w0 = self.allreduce_bucket_async(0)            # 86 % of the gradient bytes (config 2) travel under the encoder's backward
-            self.backward_part(1)
-            w1 = self.allreduce_bucket_async(1)
-            w0.wait()
-            w1.wait()
-        else:
-            self.backward()
-            self.allreduce_grads()
-        self._run(self.opt, s)
+        opt = lambda: self._run(self.opt, self.stream())                                   # noqa: E731
+        if self.world == 1:
+            return [lambda: (a_all(), opt())], []
+        if self.overlap_ok():
+            return [a_head, lambda: self.backward_part(1), opt], [0, 1]
+        return [a_all, opt], [None]
+
+    def capture(self):
+        """hipGraph capture of the step (one graph on one GPU; around the RCCL collectives when data-parallel).  Needs one
+        eager step before it (lazy module / kernel loading is not capturable).  Returns False -- and the engine stays on eager
+        launches, in-process -- if the runtime refuses the capture."""
+        torch = _torch()
+        parts, _ = self._step_parts()
+        graphs = []
+        try:
+            for fn in parts:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):           # a generator thread may be pinning memory meanwhile
+                    fn()
+                graphs.append(g)
+        except Exception as e:                                                            # pragma: no cover (needs a failing runtime)
+            import sys
+            sys.stderr.write('rvip: hipGraph capture failed (%s: %s); the step runs on eager launches\n' % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            self._graphs, self.launch_mode = None, 'eager (capture failed)'
+            return False
+        torch.cuda.synchronize()
+        self._graphs, self.launch_mode = graphs, 'hipGraph' if len(graphs) == 1 else 'hipGraph x%d + RCCL between' % len(graphs)
+        return True
+
+    def train_step(self):
+        """stage input + fwd + loss + bwd + [all-reduce] + Adam on the batch in ``x_stage`` / ``y_true``.  The first call runs
+        eagerly (warm-up), the second captures the step, every later one replays it (RVIP_GRAPH=0: always eager)."""
+        if self._graphs is None and self._eager_steps >= 1 and self.launch_mode == 'eager' and os.environ.get('RVIP_GRAPH', '1') != '0':
+            self.capture()
+        parts, buckets = self._step_parts() if self._graphs is None else ([g.replay for g in self._graphs], self._step_parts()[1])
+        if self._graphs is None:
+            self._eager_steps += 1
+        pending = []
+        for i, run in enumerate(parts):
+            run()
+            if i < len(buckets):
+                if buckets[i] is None:
+                    self.allreduce_grads()
+                else:
+                    pending.append(self.allreduce_bucket_async(buckets[i]))
+            if i == len(parts) - 2:                        # every collective must have landed before the optimiser segment
+                for w in pending:
+                    w.wait()
+
+    # -- host -> device input pipeline of fit(): pinned ring + copy stream, so the H2D of batch k+1 runs under step k -----
+    def alloc_input_ring(self, slots):
+        torch = _torch()
+        if getattr(self, 'pin_x', None) is not None and len(self.pin_x) >= slots:
+            return
+        self.pin_x = [torch.empty(self.x_stage.shape, dtype=torch.float32).pin_memory() for _ in range(slots)]
+        self.pin_y = [torch.empty(self.y_true.shape, dtype=torch.float32).pin_memory() for _ in range(slots)]
+        self.dev_in = [(torch.empty_like(self.x_stage), torch.empty_like(self.y_true)) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=self.P.device)
+        self.ev_h2d = [None] * slots                       # slot -> event after which the pinned slot may be rewritten
+        self.ev_free = [None, None]                        # device staging pair -> event after which it may be refilled
+        self._fed = 0
+        self._staged = 0
+
+    def ring_slots(self):
+        return len(self.pin_x) if self.pin_x is not None else 0
+
+    def next_slot(self):
+        """(generator thread) pinned slots are used round-robin; stage_host_batch waits for the slot's previous upload."""
+        slot = self._staged % len(self.pin_x)
+        self._staged += 1
+        return slot
+
+    def stage_host_batch(self, slot, x, y):
+        """(generator thread) pageable NumPy batch -> pinned slot; waits until the slot's previous H2D has completed."""
+        ev = self.ev_h2d[slot]
+        if ev is not None:
+            ev.synchronize()
+        np.copyto(self.pin_x[slot].numpy(), np.asarray(x, np.float32).reshape(self.x_stage.shape))
+        np.copyto(self.pin_y[slot].numpy(), np.asarray(y, np.float32).reshape(self.y_true.shape))
+
+    def feed(self, slot):
+        """(training thread) pinned slot -> device staging pair on the copy stream, then a device-to-device copy into the
+        buffers the captured step reads, on the compute stream.  Only the last copy is ordered with the step."""
+        torch = _torch()
+        d = self._fed & 1
+        self._fed += 1
+        cs, main = self.copy_stream, torch.cuda.current_stream()
+        if self.ev_free[d] is not None:
+            cs.wait_event(self.ev_free[d])
+        with torch.cuda.stream(cs):
+            self.dev_in[d][0].copy_(self.pin_x[slot], non_blocking=True)
+            self.dev_in[d][1].copy_(self.pin_y[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        self.ev_h2d[slot] = ev
+        main.wait_event(ev)
+        self.x_stage.copy_(self.dev_in[d][0], non_blocking=True)
+        self.y_true.copy_(self.dev_in[d][1], non_blocking=True)
+        evf = torch.cuda.Event()
+        evf.record(main)
+        self.ev_free[d] = evf
 
     def landmarks(self, thr=0.5, want_mask=False):
         torch = _torch()

@@ -74,8 +74,8 @@ class Model:
             self._weights.append(_INIT[init](rng, tuple(shape)))
         self._params = None          # ParamStore once on the device
         self._engines = {}
+        self._rings = {}
         self._dropout_masks = None   # name -> uint8 ndarray, parity runs only
-        self._graphs = {}
 
     # ---------------------------------------------------------------------------------------------
     # Keras bookkeeping
@@ -96,7 +96,7 @@ class Model:
         self.metrics = list(metrics or [])
         self.optimizer.lr._listeners.append(self._on_lr)
         self._engines = {}
-        self._graphs = {}
+        self._rings = {}
 
     @property
     def metrics_names(self):
@@ -140,7 +140,10 @@ class Model:
     # weights (Keras get_weights() order: conv kernel, bias; BN gamma, beta, moving_mean, moving_variance)
     # ---------------------------------------------------------------------------------------------
     def get_weights(self):
+        """Keras order.  Data-parallel: BN moving statistics are read as the MEAN over the replicas (Keras reads a
+        MirroredStrategy BN variable that way) -- a collective, so every rank must call get_weights / save_weights."""
         if self._params is not None:
+            self.sync_moving_statistics()
             self._weights = self._params.download()
         return [w.copy() for w in self._weights]
 
@@ -176,8 +179,7 @@ class Model:
         '<layer>/<weight>:0'.  Data-parallel: BN moving statistics are mean-reduced over the replicas first (Keras
         MirroredVariable aggregation MEAN) -- a collective every rank must enter -- and only rank 0 writes."""
         import os
-        self.sync_moving_statistics()
-        weights = self.get_weights()
+        weights = self.get_weights()                                   # collective when data-parallel (replica mean of the BN statistics)
         if self._dist()[0] != 0:
             return
         if not overwrite and os.path.exists(filepath):
@@ -232,7 +234,9 @@ class Model:
     def sync_moving_statistics(self):
         """BN moving mean / variance are per-replica state updated from per-replica batch statistics (plain
         BatchNormalization under MirroredStrategy, Unets.py:70-75); Keras reads such a variable as the MEAN over the replicas
-        (SURVEY 2.3).  Called before evaluation / checkpointing: all-reduce(sum) / world of the flat moving block."""
+        (SURVEY 2.3).  Called before evaluation / checkpointing: all-reduce(sum) / world of the flat moving block.  The mean
+        REPLACES the local values: the moving average is linear in the batch statistics, so the replica mean evolves identically
+        whether or not the replicas were set to it on the way, and the mean is the only view this package ever reads."""
         rank, world = self._dist()
         if world > 1 and self._params is not None:
             import torch.distributed as dist
@@ -301,7 +305,7 @@ class Model:
         """Parity hook: inject keep-masks (name -> uint8 [N,H,W,C]) instead of the counter-based stream."""
         self._dropout_masks = masks
         self._engines = {}
-        self._graphs = {}
+        self._rings = {}
 
     # ---------------------------------------------------------------------------------------------
     # steps
@@ -418,6 +422,9 @@ class Model:
                 sizes.cpu().numpy().reshape(lead + (K,)))
 
     def evaluate(self, x, y=None, verbose=0, return_dict=False, **_):
+        """Mean of the per-batch loss / metric values (BN on the moving statistics, no dropout).  Data-parallel: the moving
+        statistics are mean-reduced over the replicas first (a collective: every rank calls evaluate)."""
+        self.sync_moving_statistics()
         tot, cnt = None, 0
         if isinstance(x, np.ndarray):
             batches = [(x, y)]
@@ -433,8 +440,36 @@ class Model:
     # ---------------------------------------------------------------------------------------------
     # fit (train_model.py:105-112)
     # ---------------------------------------------------------------------------------------------
+    def _values_from_sums(self, s, n, kind, w_bce, w_dice):
+        """Per-batch loss + metric values from rows of folded sums ([steps,16] float64): what _batch_logs computes on the device."""
+        dice_all = (2 * s[:, 2] + 1) / (s[:, 3] + s[:, 4] + 1)
+        loss = s[:, 0] / n if kind == 'mse' else w_bce * s[:, 1] / n - w_dice * dice_all
+        cols = [loss]
+        for m in self.metrics:
+            which = getattr(m, 'rvip_args', {}).get('sums')
+            if which == 'labels':
+                cols.append(dice_all)
+            elif which == 'lower':
+                cols.append((2 * s[:, 5] + 1) / (s[:, 6] + s[:, 7] + 1))
+            elif which == 'upper':
+                cols.append((2 * s[:, 8] + 1) / (s[:, 9] + s[:, 10] + 1))
+            else:
+                cols.append(np.full(s.shape[0], np.nan))
+        return np.stack(cols, 1)
+
     def fit(self, x=None, y=None, validation_data=None, epochs=1, callbacks=None, initial_epoch=0, max_queue_size=12,
             verbose=1, steps_per_epoch=None, shuffle=True, batch_size=None, workers=1, **_):
+        """The reference's training loop (train_model.py:105-112; Train_tests.ipynb:924-931) on the HIP engine.
+
+        Per step the training thread only (a) queues the host->device copy of the next batch from a pinned ring on a copy
+        stream and (b) replays the captured step (Engine.train_step); generator batches are produced, sharded by rank and
+        staged into pinned memory by background threads (Keras' OrderedEnqueuer: max_queue_size / workers).  Loss and metric
+        sums stay on the device (one 64-byte row per step) and are read once per epoch.
+
+        Data-parallel (one process per GPU): every rank iterates the SAME global batches -- the batch order is drawn from
+        ``(SEED, epoch)`` and generators reshuffle from their own seeded stream, not from the process-global NumPy RNG -- and
+        trains on its slice of each (MirroredStrategy, Unets.py:70-75).  Validation and checkpoints see the replica MEAN of
+        the BN moving statistics; only rank 0 writes files and prints."""
         import torch
         from .KerasCallbacks import CallbackList
         kind, w_bce, w_dice, _ = self._loss_spec()
@@ -442,6 +477,7 @@ class Model:
             from .Generators import ArrayGenerator
             x = ArrayGenerator(x, y, batch_size or 32, shuffle=shuffle)
         gen = x
+        rank, world = self._dist()
         self.history = History()
         cbs = CallbackList(list(callbacks or []) + [self.history_callback()], self)
         self.stop_training = False
@@ -454,21 +490,25 @@ class Model:
             t0 = time.time()
             steps = len(gen) if steps_per_epoch is None else min(steps_per_epoch, len(gen))
             order = np.arange(len(gen))
-            if shuffle:
-                np.random.shuffle(order)                       # Keras shuffles the batch order of a Sequence
-            acc = None
-            for step, (xb, yb) in enumerate(_prefetch(gen, order[:steps], max_queue_size, workers)):
-                xb, yb = self._shard(xb, yb)
-                eng = self._engine(xb.shape[0])
-                eng.load_input(xb, yb)
+            if shuffle:                                        # Keras shuffles the batch order of a Sequence; seeded: identical on every rank
+                order = np.random.default_rng([self.seed, epoch]).permutation(len(gen))
+            hist = eng = None
+            for step, (eng, slot) in enumerate(self._staged_batches(gen, order[:steps], max_queue_size, workers)):
+                if hist is None:
+                    hist = torch.zeros((steps, eng.sums.numel()), dtype=torch.float32, device=eng.sums.device)
+                if slot is not None:
+                    eng.feed(slot)
                 eng.train_step()
+                hist[step].copy_(eng.sums, non_blocking=True)
                 self.optimizer.iterations += 1
-                v = self._batch_logs(eng, kind, w_bce, w_dice)
-                acc = v if acc is None else acc + v
                 cbs.on_train_batch_end(step)
             logs = OrderedDict()
-            if acc is not None:
-                for k, val in zip(names, (acc / steps).cpu().numpy().tolist()):
+            if hist is not None:
+                if world > 1:
+                    import torch.distributed as dist
+                    dist.all_reduce(hist)
+                vals = self._values_from_sums(hist.cpu().numpy().astype(np.float64), float(eng.pred.numel() * world), kind, w_bce, w_dice)
+                for k, val in zip(names, vals.mean(0).tolist()):
                     logs[k] = val
             if validation_data is not None:
                 if isinstance(validation_data, (tuple, list)):
@@ -480,13 +520,67 @@ class Model:
             cbs.on_epoch_end(epoch, logs)
             if hasattr(gen, 'on_epoch_end'):
                 gen.on_epoch_end()
-            if verbose and self._dist()[0] == 0:
+            if verbose and rank == 0:
                 dt = time.time() - t0
                 print('Epoch %d/%d - %.1fs - %.0fms/step - %s' % (
                     epoch + 1, epochs, dt, 1e3 * dt / max(steps, 1), ' - '.join('%s: %.4f' % kv for kv in logs.items())))
         cbs.on_train_end()
         torch.cuda.synchronize()
         return self.history
+
+    def _staged_batches(self, gen, order, depth, workers):
+        """Yields (engine, pinned slot | None) per batch of `order`.  A stager thread takes the generator's batches in order
+        (produced by `workers` threads when > 1), shards them by rank and copies them into the engine's pinned ring; the very
+        first batch of a batch size is loaded directly (it creates the engine and its ring)."""
+        depth = max(int(depth), 1)
+        q = queue.Queue(maxsize=depth)
+        ring = self._rings                                     # batch size -> engine whose pinned ring exists (kept across epochs)
+        ready = threading.Event()
+        stop = object()
+        slots = depth + 3
+        dev = self._device()
+
+        def work():
+            try:
+                import torch
+                torch.cuda.set_device(dev)
+                for xb, yb in _prefetch(gen, order, depth, workers):
+                    xb, yb = self._shard(xb, yb)
+                    eng = ring.get(xb.shape[0])
+                    if eng is None or eng.ring_slots() < slots:
+                        ready.clear()
+                        q.put(('raw', xb, yb))
+                        ready.wait()                           # the training thread builds the engine for this batch size
+                        continue
+                    slot = eng.next_slot()
+                    eng.stage_host_batch(slot, xb, yb)
+                    q.put(('pin', eng, slot))
+            except BaseException as e:                         # surface generator errors in the training thread
+                q.put(e)
+            q.put(stop)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is stop:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                if item[0] == 'raw':
+                    _, xb, yb = item
+                    eng = self._engine(xb.shape[0])
+                    eng.alloc_input_ring(slots)
+                    eng.load_input(xb, yb)
+                    if eng.ring_slots() >= slots:
+                        ring[xb.shape[0]] = eng
+                    ready.set()
+                    yield eng, None
+                else:
+                    yield item[1], item[2]
+        finally:
+            ready.set()
 
     def history_callback(self):
         from .KerasCallbacks import Callback
@@ -501,9 +595,9 @@ class Model:
 
 
 def _prefetch(gen, order, depth, workers=1):
-    """Background producers (the Keras OrderedEnqueuer of fit(max_queue_size=, workers=), train_model.py:111): generator batches
-    are prepared on the host while the GPU runs the previous steps; `workers` > 1 prepares that many batches at a time on a
-    thread pool (NumPy / SciPy release the GIL in their kernels) and still delivers them in `order`."""
+    """In-order iterator over ``gen[i] for i in order`` (called from the stager thread).  `workers` > 1 prepares that many
+    batches at a time on a thread pool (NumPy / SciPy release the GIL in their kernels) and still delivers them in order --
+    fit(max_queue_size=, workers=) of train_model.py:111."""
     depth = max(int(depth), 1)
     workers = max(int(workers or 1), 1)
     if workers > 1:
@@ -516,29 +610,11 @@ def _prefetch(gen, order, depth, workers=1):
                 if len(pending) >= max(depth, workers):
                     break
             while pending:
-                item = pending.popleft().result()              # re-raises a generator error in the training thread
+                item = pending.popleft().result()              # re-raises a generator error
                 nxt = next(it, None)
                 if nxt is not None:
                     pending.append(ex.submit(gen.__getitem__, int(nxt)))
                 yield item
         return
-    q = queue.Queue(maxsize=depth)
-    stop = object()
-
-    def work():
-        try:
-            for i in order:
-                q.put(gen[int(i)])
-        except BaseException as e:           # surface generator errors in the training thread
-            q.put(e)
-        q.put(stop)
-
-    th = threading.Thread(target=work, daemon=True)
-    th.start()
-    while True:
-        item = q.get()
-        if item is stop:
-            break
-        if isinstance(item, BaseException):
-            raise item
-        yield item
+    for i in order:
+        yield gen[int(i)]

@@ -424,11 +424,49 @@ def test_fit_with_generator_and_callbacks(tmp_path):
     h = hist.history
     assert set(h) >= {'loss', 'dice_coef_labels', 'val_loss', 'val_dice_coef_labels', 'lr'}
     assert len(h['loss']) == 6 and h['loss'][-1] < h['loss'][0]
-    assert (tmp_path / 'model.npz').exists()
+    assert model._engine(8).launch_mode == 'hipGraph'                  # fit replays the captured step (the one bench.py measures)
+    assert model.optimizer.iterations == 24 and model._params.step_count() == 24
+    assert (tmp_path / 'model.h5').exists()                            # the reference's checkpoint name and format (KerasCallbacks.py:55)
     m2 = rvip.get_model(cfg)
-    m2.load_weights(str(tmp_path / 'model.npz'))
+    m2.load_weights(str(tmp_path / 'model.h5'))
     xb, _ = val[0]
     assert m2.predict(xb).shape == (8, 64, 64, 2)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_graph_replay_equals_eager_launches(precision, monkeypatch):
+    """Engine.train_step: step 1 eager, step 2 captures, steps 3.. replay.  The replayed step must be the eager step bit for bit
+    (fresh dropout stream, Adam bias correction and learning rate come from device words the kernels read), including a
+    learning-rate change between replays and fit()'s pinned-ring input path."""
+    cfg = _cfg(RVIP_PRECISION=precision, DIM=[32, 32], FILTERS=8, LEARNING_RATE=1e-3)
+    x, y = O.synthetic_batch(4, cfg['DIM'], 2, seed=21)
+    x2, y2 = O.synthetic_batch(4, cfg['DIM'], 2, seed=22)
+
+    def run(graph):
+        monkeypatch.setenv('RVIP_GRAPH', '1' if graph else '0')
+        model = rvip.get_model(cfg, metrics=[])
+        losses = []
+        for i in range(6):
+            if i == 4:
+                model.optimizer.lr = 2.5e-4
+            losses.append(model.train_on_batch(x if i % 2 == 0 else x2, y if i % 2 == 0 else y2)[0])
+        return model, losses
+    mg, lg = run(True)
+    me, le = run(False)
+    assert mg._engine(4).launch_mode == 'hipGraph' and me._engine(4).launch_mode == 'eager'
+    assert lg == le, (lg, le)
+    for a_, b_ in zip(mg.get_weights(), me.get_weights()):
+        np.testing.assert_array_equal(a_, b_)
+    # fit() through the pinned ring + copy stream == train_on_batch on the same batches in the same order
+    monkeypatch.setenv('RVIP_GRAPH', '1')
+    xs, ys = np.concatenate([x, x2, x, x2]), np.concatenate([y, y2, y, y2])
+    mf = rvip.get_model(cfg, metrics=[])
+    hist = mf.fit(xs, ys, batch_size=4, epochs=2, shuffle=False, verbose=0, max_queue_size=2)
+    mt = rvip.get_model(cfg, metrics=[])
+    lt = [mt.train_on_batch(xs[i:i + 4], ys[i:i + 4])[0] for _ in range(2) for i in range(0, 16, 4)]
+    np.testing.assert_allclose(hist.history['loss'], [np.mean(lt[:4]), np.mean(lt[4:])], rtol=1e-6)
+    for a_, b_ in zip(mf.get_weights(), mt.get_weights()):
+        np.testing.assert_array_equal(a_, b_)
 
 
 def _dp_gpu_worker(rank, world, port, overlap, q):
@@ -473,6 +511,58 @@ def test_two_rank_data_parallel_step_matches_single_rank(overlap):
     for rank, losses, _, _ in res:                       # the logged loss is the global one (loss sums are all-reduced)
         for step in range(2):
             assert abs(losses[step] - ref_losses[step]) <= 2e-5 * max(1.0, abs(ref_losses[step])), (rank, step)
+
+
+def _dp_fit_worker(rank, world, port, path, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        np.random.seed(1000 + rank)                                     # the process-global NumPy stream DIFFERS per rank on purpose
+        cfg = _cfg(DIM=[32, 32], FILTERS=8, LEARNING_RATE=1e-3, MODEL_PATH=os.path.join(path, 'rank%d' % rank if rank else 'chief'))
+        gcfg = dict(DIM=[32, 32], BATCHSIZE=8, GAUS=True, SIGMA=2, SHUFFLE=True, SEED=7)
+        train = rvip.Generators.SyntheticSAXGenerator(32, gcfg, in_memory=True)
+        val = rvip.Generators.SyntheticSAXGenerator(8, dict(gcfg, SHUFFLE=False), in_memory=True)
+        seen = []
+        orig = train.__getitem__.__func__
+
+        class Spy(type(train)):
+            def __getitem__(self, i):
+                seen.append(tuple(int(v) for v in self.INDICES[i * self.BATCHSIZE:(i + 1) * self.BATCHSIZE]))
+                return orig(self, i)
+        train.__class__ = Spy
+        model = rvip.get_model(cfg, metrics=[M.dice_coef_labels])
+        cbs = rvip.KerasCallbacks.get_callbacks(cfg, train, val)
+        hist = model.fit(x=train, validation_data=val, epochs=2, callbacks=cbs, verbose=0, max_queue_size=2)
+        w = model.get_weights()                                          # collective: replica mean of the BN moving statistics
+        local_mv = model._params.moving.detach().cpu().numpy().copy()
+        q.put((rank, seen, hist.history, [a.copy() for a in w], local_mv, os.path.exists(os.path.join(cfg['MODEL_PATH'], 'model.h5'))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_fit_is_rank_consistent(tmp_path):
+    """fit() for 2 epochs on 2 ranks (gloo, both on this GPU) with BN and dropout on: both ranks draw the same global batches in the
+    same order although their process-global NumPy streams differ, train on different halves, and end with identical weights,
+    identical (replica-mean) BN moving statistics and identical epoch logs; only rank 0 writes the checkpoint."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_fit_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    (_, seen0, h0, w0, mv0, ck0), (_, seen1, h1, w1, mv1, ck1) = res
+    assert seen0 == seen1 and len(seen0) == 8 and sorted(sum(seen0[:4], ())) == list(range(32))      # same global batches, each sample once per epoch
+    assert seen0[:4] != seen0[4:]                                                                     # ... reshuffled between the epochs
+    assert set(h0) == set(h1) and all(h0[k] == h1[k] for k in h0), (h0, h1)
+    for a_, b_ in zip(w0, w1):
+        np.testing.assert_array_equal(a_, b_)
+    np.testing.assert_array_equal(mv0, mv1)
+    assert ck0 and not ck1
 
 
 @pytest.mark.parametrize('variant', [dict(DIM=[4, 64, 64], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32),
