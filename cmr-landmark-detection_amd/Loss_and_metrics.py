@@ -88,7 +88,13 @@ def bce_dice_loss(y_true, y_pred, w_bce=0.5, w_dice=1.):
 
 
 class BceDiceLoss:
-    """Loss_and_metrics.py:208-226 (the object train_model.py:182 builds for 'BcdDiceLoss')."""
+    """Loss_and_metrics.py:208-226 (the object train_model.py:182 builds for 'BcdDiceLoss').
+
+    The reference class overrides ``tf.keras.losses.Loss.__call__`` (:220-226), which bypasses Keras' mean reduction: the
+    training objective becomes the SUM over the replica's B*H*W elements (gradient = B_local*H*W times the mean form's) while
+    the logged value stays the element mean -- the argument, with the tf.keras 2.3 source files it rests on, is in
+    ``oracle/rvip_oracle.py::bce_dice_loss``.  ``rvip_args['reduction'] = 'sum'`` makes the engine scale the loss gradient
+    accordingly; the plain function ``bce_dice_loss`` keeps 'mean'."""
     rvip_kind = 'loss'
 
     def __init__(self, w_bce=1., w_dice=1., binary=True, name='BcdDiceLoss'):
@@ -97,7 +103,7 @@ class BceDiceLoss:
         self.w_bce, self.w_dice = w_bce, w_dice
         self.name = '{}_w_{}_{}'.format(name, w_bce, w_dice)
         self.__name__ = self.name
-        self.rvip_args = dict(loss='bce_dice', w_bce=w_bce, w_dice=w_dice)
+        self.rvip_args = dict(loss='bce_dice', w_bce=w_bce, w_dice=w_dice, reduction='sum')
 
     def __call__(self, y_true, y_pred, **kwargs):
         return bce_dice_loss(y_true, y_pred, self.w_bce, self.w_dice)
@@ -127,3 +133,12 @@ def resolve_loss(loss):
     if args is None or getattr(loss, 'rvip_kind', None) != 'loss':
         raise ValueError('LOSS_FUNCTION %r is not one of this package\'s loss tags (mse, bce_dice_loss, BceDiceLoss)' % (loss,))
     return args['loss'], args.get('w_bce', 0.0), args.get('w_dice', 0.0), getattr(loss, '__name__', 'loss')
+
+
+def loss_reduction(loss):
+    """'sum' for the BceDiceLoss class form (and the string train_model.py:178-184 maps to it), else 'mean' (see BceDiceLoss)."""
+    if isinstance(loss, dict):
+        loss = loss.get('unet', next(iter(loss.values())))
+    if isinstance(loss, str):
+        return 'sum' if loss.lower() == 'bcddiceloss' else 'mean'
+    return (getattr(loss, 'rvip_args', None) or {}).get('reduction', 'mean')

@@ -193,7 +193,7 @@ class ParamStore:
 class Engine:
     """Activation/gradient buffers and pre-built launch lists for ONE (batch size, loss) configuration."""
 
-    def __init__(self, params, batch, loss_kind='mse', w_bce=0.5, w_dice=1.0, world=1, masks=None):
+    def __init__(self, params, batch, loss_kind='mse', w_bce=0.5, w_dice=1.0, world=1, masks=None, sum_reduction=False):
         torch = require_gpu()
         L = N.lib()
         self.P, self.plan, self.batch = params, params.plan, int(batch)
@@ -222,6 +222,7 @@ class Engine:
         self.world = world
         self.loss_kind = N.LOSS_MSE if loss_kind == 'mse' else N.LOSS_BCE_DICE
         self.w_bce, self.w_dice = float(w_bce), float(w_dice)
+        self.sum_reduction = bool(sum_reduction)     # BceDiceLoss class form: objective = SUM over the replica's B*H*W elements
         self.masks = masks or {}                  # dropout layer name -> uint8 device tensor (parity runs)
         H, W = plan.dim[-2:]
         K = plan.mask_classes
@@ -452,17 +453,21 @@ class Engine:
         # range.  Static loss scaling (the reference has no f16 path; this is the usual mixed-precision recipe): dlogit is
         # multiplied by a power of two ~ count (so |dlogit| <= 0.5), every gradient of the step carries the factor, and the
         # optimiser removes it exactly (rvip_adam_step grad_scale).  RVIP_LOSS_SCALE overrides.
+        # BceDiceLoss class form (Loss_and_metrics.py:220-226 overrides Loss.__call__): the gradient is that of the SUM over the
+        # replica's B*H*W elements = the mean form's times grad_factor (oracle/rvip_oracle.py::bce_dice_loss); the loss VALUE the
+        # kernel writes stays the mean.  Both factors ride on one rvip_scale_f32 pass over dlogit.
+        self.grad_factor = float(n * hd['h'] * hd['w']) if self.sum_reduction else 1.0
         if P.dt == N.F16:
             env = os.environ.get('RVIP_LOSS_SCALE')
-            self.loss_scale = float(env) if env else float(2 ** int(np.floor(np.log2(per_rank * self.world))))
+            self.loss_scale = float(env) if env else float(2 ** int(np.floor(np.log2(max(per_rank * self.world / self.grad_factor, 1.0)))))
         else:
             self.loss_scale = 1.0
         P.grad_unscale = 1.0 / self.loss_scale
         bwd.append((L.rvip_head_grad, (_ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), _ptr(self.dlogit), _ptr(self.loss),
                                        hrows, hd['k'], self.loss_kind, C.c_float(self._inv_count), C.c_float(1.0 / self.world),
                                        C.c_float(self.w_bce), C.c_float(self.w_dice))))
-        if self.loss_scale != 1.0:
-            bwd.append((L.rvip_scale_f32, (_ptr(self.dlogit), C.c_longlong(self.dlogit.numel()), C.c_float(self.loss_scale))))
+        if self.loss_scale * self.grad_factor != 1.0:
+            bwd.append((L.rvip_scale_f32, (_ptr(self.dlogit), C.c_longlong(self.dlogit.numel()), C.c_float(self.loss_scale * self.grad_factor))))
         if not self.fuse_head:
             bwd.append((L.rvip_head_bwd, (_ptr(hx), hw_, _ptr(self.dlogit), _ptr(self.grd[hd['src']]), P.g(hd['conv'], 'kernel'),
                                           P.g(hd['conv'], 'bias'), hrows, hd['cin'], hd['k'], dt, ws, wsb)))

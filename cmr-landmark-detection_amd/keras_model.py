@@ -285,7 +285,8 @@ class Model:
             if self._dropout_masks:
                 masks = {k: torch.from_numpy(np.ascontiguousarray(v[:batch], np.uint8)).to(P.device)
                          for k, v in self._dropout_masks.items()}
-            self._engines[key] = Engine(P, batch, kind or 'mse', w_bce, w_dice, world=world, masks=masks)
+            self._engines[key] = Engine(P, batch, kind or 'mse', w_bce, w_dice, world=world, masks=masks,
+                                        sum_reduction=(kind == 'bce_dice' and metr.loss_reduction(self.loss) == 'sum'))
         return self._engines[key]
 
     def _loss_spec(self, required=True):

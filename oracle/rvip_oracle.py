@@ -465,14 +465,39 @@ def dice_coef(y_true, y_pred, smooth=1.0):
     return (2.0 * inter + smooth) / (y_true.sum() + y_pred.sum() + smooth)
 
 
-def bce_dice_loss(y_true, y_pred, w_bce=0.5, w_dice=1.0, logits=None, global_batch=None):
+def bce_dice_loss(y_true, y_pred, w_bce=0.5, w_dice=1.0, logits=None, global_batch=None, reduction='mean'):
     """Loss_and_metrics.py:229-245.  BCE is Keras binary_crossentropy (mean over the channel axis,
     then Keras' mean over B,H,W); on a Sigmoid-op output Keras uses the logits form (pass
     ``logits``), otherwise clips y_pred to [1e-7, 1-1e-7].  Dice is over the flattened replica batch
     and is not divided by the global batch (it is a scalar added to every pixel's loss).
-    Returns (loss, dL/dy_pred [or dL/dlogits if logits is given])."""
-    if y_pred.shape[-1] == 4:
-        raise NotImplementedError('4-class background slicing (Loss_and_metrics.py:240-242) not restated')
+    Returns (loss, dL/dy_pred [or dL/dlogits if logits is given]).
+
+    ``reduction`` -- how Keras turns the un-reduced ``[B,H,W]`` tensor ``w_bce*BCE - w_dice*dice`` into the training objective.
+    Two call forms exist in the reference and tf.keras 2.3 treats them DIFFERENTLY (TensorFlow is third-party, environment.yml:126,
+    not runnable here: this is a reading of its source, cited by file, and stays "unpinned"):
+
+    * 'mean' -- the FUNCTION ``bce_dice_loss`` (Train_tests.ipynb:219).  ``compile`` wraps a plain callable in
+      ``LossFunctionWrapper`` (keras/engine/compile_utils.py ``LossesContainer._get_loss_object``), whose ``Loss.__call__``
+      (keras/losses.py) reduces with SUM_OVER_BATCH_SIZE = mean over the B*H*W elements (keras/utils/losses_utils.py
+      ``compute_weighted_loss``), then ``scale_loss_for_distribution`` divides by the replica count.
+    * 'sum' -- the CLASS ``BceDiceLoss`` (Loss_and_metrics.py:207-226; train_model.py:178-184 builds it for "BcdDiceLoss", the
+      template config's choice).  It subclasses ``tf.keras.losses.Loss`` but OVERRIDES ``__call__`` (:220-226), so the
+      reduction in ``Loss.__call__`` never runs: ``LossesContainer.__call__`` receives the raw ``[B,H,W]`` tensor, applies only
+      ``scale_loss_for_distribution`` (its ``reduction`` attribute is the inherited AUTO), and ``Model.train_step``
+      (keras/engine/training.py) hands that tensor to ``_minimize`` -> ``tape.gradient(loss, variables)``; the gradient of a
+      non-scalar target is the gradient of the SUM of its elements (python/eager/backprop.py ``GradientTape.gradient``).  The
+      LOGGED loss is still the element mean (the ``Mean`` metric, keras/metrics.py, averages the tensor).
+    Hence: same loss value, and  grad['sum'] == grad['mean'] * (B_local*H*W)  exactly (tests/test_oracle.py).  Under Adam the factor
+    nearly cancels except against epsilon = 1e-7, which is why it is not harmless to pick the wrong one."""
+    if reduction not in ('mean', 'sum'):
+        raise ValueError(reduction)
+    if y_pred.shape[-1] == 4:                                       # Loss_and_metrics.py:222-224 / :240-242: drop the background channel
+        y_true, y_pred = y_true[..., -3:], y_pred[..., -3:]
+        full = logits is not None and logits.shape[-1] == 4
+        loss, g = bce_dice_loss(y_true, y_pred, w_bce, w_dice, logits[..., -3:] if full else logits, global_batch, reduction)
+        gfull = np.zeros(y_pred.shape[:-1] + (4,), dtype=g.dtype)
+        gfull[..., -3:] = g
+        return loss, gfull
     n_local = y_pred.shape[0]
     gb = n_local if global_batch is None else global_batch
     per_sample = y_pred[0].size
@@ -497,6 +522,8 @@ def bce_dice_loss(y_true, y_pred, w_bce=0.5, w_dice=1.0, logits=None, global_bat
         grad = w_bce * dbce_dz / (gb * per_sample) - w_dice * scale * ddice_dp * p * (1 - p)
     else:
         grad = w_bce * dbce_dp / (gb * per_sample) - w_dice * scale * ddice_dp
+    if reduction == 'sum':
+        grad = grad * float(n_local * int(np.prod(y_pred.shape[1:-1])))
     return loss, grad
 
 
@@ -821,14 +848,14 @@ class OracleUNet:
         return OrderedDict((k, grads[k]) for k in self.params if k in grads)
 
     # -- one training step (Keras train_step: fwd, loss, bwd, BN moving update, Adam) -------
-    def loss_and_grads(self, x, y, loss='mse', dropout_masks=None, global_batch=None):
+    def loss_and_grads(self, x, y, loss='mse', dropout_masks=None, global_batch=None, **loss_kw):
         y = np.asarray(y, self.dtype)
         pred, cache = self.forward(x, training=True, dropout_masks=dropout_masks)
         if loss == 'mse':
             val, dpred = mse_loss(y, pred, global_batch)
             grads = self.backward(cache, dpred)
         elif loss == 'bce_dice':
-            val, dlogit = bce_dice_loss(y, pred, logits=cache['logits'], global_batch=global_batch)
+            val, dlogit = bce_dice_loss(y, pred, logits=cache['logits'], global_batch=global_batch, **loss_kw)     # w_bce, w_dice, reduction
             grads = self.backward(cache, dlogit, d_is_logit_grad=True)
         else:
             raise ValueError(loss)
