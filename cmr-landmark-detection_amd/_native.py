@@ -75,11 +75,6 @@ class BnBwdDesc(C.Structure):
                 ('pool_dpooled', vp), ('pool_add', vp), ('pool_h', C.c_int32), ('pool_w', C.c_int32)]
 
 
-class C1Desc(C.Structure):
-    _fields_ = [('x', vp), ('w', vp), ('bias', vp), ('n', C.c_int32), ('h', C.c_int32), ('w_', C.c_int32), ('cout', C.c_int32),
-                ('act', C.c_int32), ('dtype', C.c_int32)]
-
-
 class FoldEntry(C.Structure):
     _fields_ = [('src', vp), ('dst', vp), ('nrows', C.c_int32), ('reserved', C.c_int32), ('width', C.c_longlong)]
 
@@ -121,10 +116,6 @@ SIGNATURES = {
     'rvip_upsample2x_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_upsample2x_bwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_head_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
-    'rvip_c1_stage_stats': (C.c_int, [C.POINTER(C1Desc), vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp]),
-    'rvip_c1_stage_apply': (C.c_int, [C.POINTER(C1Desc), C.POINTER(ApplyDesc), vp]),
-    'rvip_c1_stage_bwd_reduce': (C.c_int, [C.POINTER(C1Desc), C.POINTER(BnBwdDesc), vp]),
-    'rvip_c1_stage_bwd_apply': (C.c_int, [C.POINTER(C1Desc), C.POINTER(BnBwdDesc), vp, vp]),
     'rvip_bn_apply_head': (C.c_int, [C.POINTER(ApplyDesc), vp, vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp]),
     'rvip_bn_bwd_reduce_head': (C.c_int, [C.POINTER(BnBwdDesc), vp, vp, C.c_int, vp, vp, vp]),
     'rvip_bn_bwd_apply_head': (C.c_int, [C.POINTER(BnBwdDesc), vp, vp, C.c_int, vp]),

@@ -343,315 +343,6 @@ __device__ __forceinline__ void epilogue_down2(f32x16 (&acc)[NCT][NPT], int pbas
     }
 }
 
-template <typename T, int TW, int NCT, int NW, bool STATS>
-__global__ __launch_bounds__(NW * 64, 1) void conv3x3_igemm_dma(ConvArgs2 a) {
-    constexpr int NPIX = NW * 64, TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
-    constexpr int NHROWS = (NHALO + 15) / 16 * 16;
-    constexpr int BN = NCT * 32, WROWS = 9 * BN;
-    constexpr int IN_BYTES = NHROWS * 64, W_BYTES = WROWS * 64;
-    constexpr int VE = Vec<T>::VE, KCE = 4 * VE;
-    constexpr int NQI = NHROWS / 16, NQW = WROWS / 16;                 // 1 KiB DMA pieces per stage
-    constexpr int QI = (NQI + NW - 1) / NW, QW = (NQW + NW - 1) / NW;  // per wave
-    constexpr unsigned OOB = 0x80000000u;
-    constexpr int NST = (sizeof(T) == 2) ? NCT * 2 * 2 : NCT * 2 * 4;   // buffer stores per wave per tile epilogue
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* lin = smem;                       // [2][IN_BYTES]
-    unsigned char* lw = smem + 2 * IN_BYTES;         // [wres or 2][W_BYTES]
-
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int co0 = blockIdx.y * BN;
-    const int nch = (a.cin + KCE - 1) / KCE;         // chunks per depth tap
-    const int nchunks = nch * a.kd;
-    const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
-    const bool resident = a.wres > 0;
-
-    const i32x4 rs0 = make_rsrc(a.x0, a.x0_bytes);
-    const i32x4 rs1 = make_rsrc(a.x1 ? a.x1 : a.x0, a.x1 ? a.x1_bytes : 0u);
-    const i32x4 rsw = make_rsrc(a.wp, a.wp_bytes);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y1 ? a.y1 : a.y), 0, a.y1 ? a.y1_bytes : 0, 0x00020000);
-    const unsigned lds_base = lds_offset_of(smem);
-    float* lbias = reinterpret_cast<float*>(smem + a.lds_bias_off);        // [BN] bias of this output-channel tile
-    if (tid < BN) lbias[tid] = (a.bias && co0 + tid < a.cout) ? a.bias[co0 + tid] : 0.f;
-
-    // DMA lane geometry: lane -> (row within the 16-row piece, physical 16-byte slot)
-    const int drow = lane >> 2, dslot = lane & 3;
-
-    bool nofetch = false;                    // ablation (RVIP_DBG & 4)
-    int wrel[QW], wch[QW];
-#pragma unroll
-    for (int i = 0; i < QW; ++i) {
-        const int row = (wv + NW * i) * 16 + drow;
-        const int tap = row / BN, co = co0 + (row & (BN - 1));
-        wch[i] = (co < a.cout && row < WROWS) ? (dslot ^ ((row >> 2) & 3)) * VE : 1 << 28;   // dead rows fail the channel test
-        wrel[i] = (((tap * a.cout + co) * a.cin) + (dslot ^ ((row >> 2) & 3)) * VE) * (int)sizeof(T);
-    }
-    auto issue_weights = [&](int kc, int wstage) __attribute__((always_inline)) {
-        const int kdi = kc / nch;
-        const int cbase = (kc - kdi * nch) * KCE;
-        const int tapbase = (kdi * 9 * a.cout * a.cin + cbase) * (int)sizeof(T);
-#pragma unroll
-        for (int i = 0; i < QW; ++i) {
-            const int q = wv + NW * i;
-            if (q < NQW) {
-                const unsigned off = (wch[i] < a.cin - cbase && !nofetch) ? (unsigned)(wrel[i] + tapbase) : OOB;
-                dma16(rsw, off, lds_base + 2 * IN_BYTES + wstage * W_BYTES + q * 1024);
-            }
-        }
-    };
-    // Per-lane geometry of each DMA piece this wave issues (tile independent).  Byte offset of a piece =
-    // tile/chunk base (wave-uniform) + rel (per lane); tiles start on even coordinates so the x2 reads stay linear:
-    // ((ty0 - 1 + hy) >> 1) = ty0/2 + ((hy - 1) >> 1).  Validity = a few compares folded into one select.
-    int ihy[QI], ihx[QI], irel0[QI], ich[QI];
-#pragma unroll
-    for (int i = 0; i < QI; ++i) {
-        const int row = (wv + NW * i) * 16 + drow;
-        const int hy = row / HWD, hx = row - hy * HWD;
-        ich[i] = (dslot ^ ((hx >> 2) & 3)) * VE;                  // first channel (within the chunk) of my 16-byte piece;
-                                                                  // slot swizzle by the halo x coordinate (tap-row invariant)
-        ihy[i] = (row < NHALO) ? hy - 1 : -100000;
-        ihx[i] = hx - 1;
-        irel0[i] = ((((hy - 1) >> a.up0) * w0 + ((hx - 1) >> a.up0)) * a.c0 + ich[i]) * (int)sizeof(T);
-    }
-    auto issue_input = [&](int tile, int kc, int stage) __attribute__((always_inline)) {
-        int bx = tile;
-        const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
-        const int ty_i = bx % a.tiles_y;
-        const int n_out = bx / a.tiles_y;
-        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
-        const int kdi = kc / nch;
-        const int dsh = kdi - (a.kd >> 1);               // depth tap: read the image dsh slices away, zeros outside the volume
-        const int n = n_out + dsh;
-        const bool dok = (unsigned)(n_out % a.depth + dsh) < (unsigned)a.depth;
-        const int cbase = (kc - kdi * nch) * KCE;
-        const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
-        const int cb = from0 ? cbase : cbase - a.c0;
-        const int crem = dok ? (from0 ? a.c0 : a.c1) - cb : 0;     // channels of this source left from the chunk start
-        const int base = from0 ? (((n * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 + cb) * (int)sizeof(T)
-                               : (((n * a.h + ty0) * a.w + tx0) * a.c1 + cb) * (int)sizeof(T);
-        const bool zs = from0 && a.zs;
-        const i32x4 rs = from0 ? rs0 : rs1;
-#pragma unroll
-        for (int i = 0; i < QI; ++i) {
-            const int q = wv + NW * i;
-            if (q < NQI) {
-                const int gy = ty0 + ihy[i], gx = tx0 + ihx[i];
-                bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && ich[i] < crem;
-                if (zs) ok = ok && ((gy & gx) & 1);
-                // (no `from0 ? irel0[i] : irel1[i]`: hipcc turns a select between two register arrays into scratch indexing)
-                int rel = irel0[i];
-                if (!from0) rel = ((ihy[i] * a.w + ihx[i]) * a.c1 + ich[i]) * (int)sizeof(T);
-                const unsigned off = (ok && !nofetch) ? (unsigned)(base + rel) : OOB;
-                dma16(rs, off, lds_base + stage * IN_BYTES + q * 1024);
-            }
-        }
-    };
-
-    // Fragment read addresses (stage-relative): one per-lane base per (pixel tile, tap COLUMN, k-half g) + compile-time
-    // offsets for the tap row.  The slot swizzle of a halo row depends only on its x coordinate, so it does not change
-    // with the tap row; piece p = 2g + hf sits in slot p ^ ((hx >> 2) & 3).
-    int in_base[2][3][2];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const int P = wv * 64 + pt * 32 + j;
-        const int py = P / TW, px = P % TW;
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-            const int hx = px + tx;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) in_base[pt][tx][g] = (py * HWD + hx) * 64 + (((2 * g + hf) ^ ((hx >> 2) & 3)) << 4);
-        }
-    }
-    int w_addr[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        const int r = ct * 32 + j;
-        w_addr[ct] = r * 64 + ((hf ^ ((r >> 2) & 3)) << 4);          // g = 0; g = 1 is this address ^ 32
-    }
-
-    f32x16 acc[NCT][2];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
-
-    // fused BatchNormalization statistics (optional): per-lane partial sums of the values actually stored, over every
-    // tile this workgroup produces; reduced once at the end (fixed order -> reproducible)
-    constexpr int SN = STATS ? NCT : 1, SR = STATS ? 16 : 1;
-    float ssum[SN][SR], ssq[SN][SR];
-#pragma unroll
-    for (int ct = 0; ct < SN; ++ct)
-#pragma unroll
-        for (int r = 0; r < SR; ++r) ssum[ct][r] = ssq[ct][r] = 0.f;
-
-    const int first_tile = blockIdx.x;
-    if (first_tile >= a.ntiles) return;
-    if (resident) for (int kc = 0; kc < nchunks; ++kc) issue_weights(kc, kc);
-    else issue_weights(0, 0);
-    issue_input(first_tile, 0, 0);
-
-    int it = 0;
-    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
-        int bx = tile;
-        const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
-        const int ty_i = bx % a.tiles_y;
-        const int n = bx / a.tiles_y;
-        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
-        for (int kc = 0; kc < nchunks; ++kc, ++it) {
-            // item `it` has landed for me; after the barrier for everyone, and everyone has finished item it-1.
-            // The epilogue's NST buffer stores are YOUNGER than this item's DMA: leave them in flight.
-            if (kc == 0 && it > 0) {
-                if (a.down2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TW == 32 ? NST / 2 : NST) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST) : "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            {   // prefetch the next item into the other stage
-                int ntile = tile, nkc = kc + 1;
-                if (nkc == nchunks) { nkc = 0; ntile = tile + gridDim.x; }
-                if (ntile < a.ntiles && !(a.dbg & 1)) {
-                    issue_input(ntile, nkc, (it + 1) & 1);
-                    if (!resident) issue_weights(nkc, (it + 1) & 1);
-                }
-            }
-            const unsigned char* sin = lin + (it & 1) * IN_BYTES;
-            const unsigned char* sw = lw + (resident ? kc : (it & 1)) * W_BYTES;
-            // 18 (tap, k-half) steps as a two-deep software pipeline: the NCT + 2 fragment reads of step i+1 are issued before
-            // the NCT * 2 MFMAs of step i, so an LDS round trip is always covered by ~128 cycles of matrix work (hipcc on its
-            // own emits read -> lgkmcnt(0) -> mfma with 16 recycled registers).  sched_barrier(0) pins that order.
-            if (a.dbg & 2) continue;
-            uint4 fa[2][NCT], fb[2][2];
-            auto load_step = [&](int st, int buf) __attribute__((always_inline)) {
-                const int tap = st >> 1, g = st & 1;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) fa[buf][ct] = *reinterpret_cast<const uint4*>(sw + tap * BN * 64 + (w_addr[ct] ^ (g << 5)));
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) fb[buf][pt] = *reinterpret_cast<const uint4*>(sin + in_base[pt][tap % 3][g] + (tap / 3) * HWD * 64);
-            };
-            load_step(0, 0);
-#pragma unroll
-            for (int st = 0; st < 18; ++st) {
-                const int cur = st & 1;
-                if (st + 1 < 18) load_step(st + 1, cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);             // reads of step st+1 stay ABOVE the MFMAs of step st
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) Mma<T>::run(fa[cur][ct], fb[cur][pt], acc[ct][pt]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // epilogue of this tile (the next item's DMA is already in flight).  Stores are buffer stores whose masked lanes
-        // (pixel outside the image, channel tail) carry an out-of-range offset: the instruction count per wave is fixed
-        // (= NST), which is what lets the next item-top wait be vmcnt(NST).  bf16: two accumulator quads are merged with
-        // v_permlane32_swap so that every lane stores 16 contiguous bytes (8 channels of one pixel).
-        auto epilogue = [&](auto actf) {
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const int P = wv * 64 + pt * 32 + j;
-            const int gy = ty0 + P / TW, gx = tx0 + P % TW;
-            const bool pix_ok = gy < a.h && gx < a.w;
-            const unsigned pix = (unsigned)((n * a.h + gy) * a.w + gx);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int cbase = co0 + ct * 32;                                   // wave-uniform
-                const bool second = a.y1 && cbase >= a.csplit;                     // csplit % 32 == 0 (host)
-                const int cstride = a.y1 ? (second ? a.cout - a.csplit : a.csplit) : a.cout;
-                const int cshift = second ? a.csplit : 0;
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float t = acc[ct][pt][r] + lbias[ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
-                    acc[ct][pt][r] = 0.f;
-                    v[r] = actf(t);
-                    if constexpr (STATS) {
-                        if (pix_ok) {
-                            const float q = Vec<T>::round(v[r]);
-                            ssum[ct][r] += q;
-                            ssq[ct][r] = fmaf(q, q, ssq[ct][r]);
-                        }
-                    }
-                }
-                if constexpr (sizeof(T) == 4) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int co = cbase + 8 * q + 4 * hf;
-                        const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 4u : OOB;
-                        const u32x4v dta = {__builtin_bit_cast(unsigned, v[4 * q]), __builtin_bit_cast(unsigned, v[4 * q + 1]),
-                                            __builtin_bit_cast(unsigned, v[4 * q + 2]), __builtin_bit_cast(unsigned, v[4 * q + 3])};
-                        if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        unsigned ax = (uint32_t)Vec<T>::enc(v[8 * qq + 0]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 1]) << 16);
-                        unsigned ay = (uint32_t)Vec<T>::enc(v[8 * qq + 2]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 3]) << 16);
-                        unsigned bxx = (uint32_t)Vec<T>::enc(v[8 * qq + 4]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 5]) << 16);
-                        unsigned byy = (uint32_t)Vec<T>::enc(v[8 * qq + 6]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 7]) << 16);
-                        // lanes 0-31 keep quad 2qq and receive the upper half's quad 2qq (channels +4..7);
-                        // lanes 32-63 receive the lower half's quad 2qq+1 and keep their own (channels +8..15)
-                        auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
-                        auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
-                        const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
-                        const int co = cbase + 16 * qq + 8 * hf;
-                        const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
-                        if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
-                    }
-                }
-            }
-        }
-        };
-        // the activation is launch-uniform: specialise the hot cases so the epilogue stays a few hundred instructions
-        if (a.down2) epilogue_down2<T, TW, NCT, 2>(acc, wv * 64, j, hf, n, ty0, tx0, co0, a, ry);
-        else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
-        else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
-        else epilogue([&](float t) { return act_fwd(t, a.act); });
-    }
-    if constexpr (STATS) {
-        // lanes of one half-wave hold the same 16*NCT channels for 32 different pixels: butterfly over the pixels,
-        // then the NW waves are folded in wave order through LDS (stage memory is free: everything has been consumed)
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        float* lst = reinterpret_cast<float*>(smem);                       // [NW][2][BN]
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s1 = ssum[ct][r], s2 = ssq[ct][r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-                if (j == 0) {
-                    const int c = ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
-                    lst[(wv * 2 + 0) * BN + c] = s1;
-                    lst[(wv * 2 + 1) * BN + c] = s2;
-                }
-            }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int k = tid / BN, c = tid % BN;
-            float t = 0.f;
-#pragma unroll
-            for (int w8 = 0; w8 < NW; ++w8) t += lst[(w8 * 2 + k) * BN + c];
-            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * 2 + k) * a.cout + co0 + c] = t;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// igemm v3: producer / consumer wave specialisation of v2.  Measured on v2 (RVIP_DBG ablation): the un-overlapped cost
-// of staging is the LDS-DMA INSTRUCTIONS (~100-200 issue cycles each, the same with out-of-range = zero-traffic
-// offsets), which sit in front of every wave's MFMAs.  Here a workgroup is 8 waves = one loader + one compute wave per
-// SIMD: waves 4..7 only issue the DMA pieces of the next work item, waves 0..3 only read fragments and issue MFMAs
-// (each owns NPIX/4 pixels x BN channels, so a weight fragment is reused by up to 4 pixel fragments: 0.75 KiB of LDS
-// reads per MFMA instead of 1 KiB).  One s_barrier per work item joins the two roles.
-// ---------------------------------------------------------------------------------------------
-// cache policy of the second output (the skip-connection gradient of a concat conv's data gradient: written at the start of
-// the backward pass, read by the encoder's max-pool backward at its end): 2 = non-temporal
-#ifndef RVIP_Y1_POLICY
-#define RVIP_Y1_POLICY 0
-#endif
 // TAPS = 4: sub-pixel form of UpSampling2D(2) -> conv3x3 (KerasLayers.py:756-758).  Output pixel (2i+a, 2j+b) only sees the
 // low-resolution pixels (i+a-1 .. i+a) x (j+b-1 .. j+b), each through a SUM of the 3x3 taps that fall on it, so the layer
 // is four 2x2-tap convolutions on the low-resolution image (16 instead of 36 multiply-adds per low-resolution pixel and
@@ -941,7 +632,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                     const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 4u : OOB;
                     const u32x4v dta = {__builtin_bit_cast(unsigned, v[4 * q]), __builtin_bit_cast(unsigned, v[4 * q + 1]),
                                         __builtin_bit_cast(unsigned, v[4 * q + 2]), __builtin_bit_cast(unsigned, v[4 * q + 3])};
-                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, RVIP_Y1_POLICY);
+                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
                 }
             } else {
@@ -956,7 +647,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                     const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
                     const int co = cbase + 16 * qq + 8 * hf;
                     const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
-                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, RVIP_Y1_POLICY);
+                    if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
                 }
             }
@@ -1317,7 +1008,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             const u32x4v dta = {s0[0], s1[0], s0[1], s1[1]};
             const int co = cbase + 8 * (kq >> 1);
             const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
-            if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, RVIP_Y1_POLICY);
+            if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
         };
         auto block_pixel = [&](int blk, int& gy, int& gx) __attribute__((always_inline)) {
@@ -1433,7 +1124,7 @@ static constexpr auto igemm_ws_kernel() {
 }
 
 template <typename T, bool V5, int TW, int NCT, int NPIX, int TAPS = 9, int NCW = 4>
-static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry, int wgpc = 1) {
+static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry) {
     constexpr int TH = NPIX / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int IN_BYTES = NHROWS * 64, W_BYTES = TAPS * NCT * 32 * 64;
@@ -1478,7 +1169,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     const int cot = (int)cdiv(a0.cout, NCT * 32);
     if (cot > 1) b.nt_in = 0;       // several workgroup columns re-read the same input tile: keep it cached (measured)
     constexpr int NZ = TAPS == 4 ? 4 : 1;
-    int gx = 256 * wgpc / (cot * NZ);              // wgpc workgroups per CU (LDS / VGPR budget checked by the caller)
+    int gx = 256 / (cot * NZ);                     // one workgroup per CU (LDS-limited), persistent over the pixel tiles
     if (gx < 1) gx = 1;
     if (gx > b.ntiles) gx = b.ntiles;
     b.stats = stats;
@@ -1500,10 +1191,9 @@ static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float
     if (two && !a.subpix) {
         // small maps: 64-channel tiles can leave half of the CUs without a workgroup (e.g. 256 -> 128 at 32 x 32: 64 tiles x 2
         // channel columns); 32-channel tiles double the workgroup count for a little more LDS traffic per FLOP
-        static const bool narrow = [] { const char* e = getenv("RVIP_NARROW_TILES"); return !(e && e[0] == '0'); }();
         const int tpx = (a.w > 16 && a.h >= 16) ? 512 : 256, tw = a.w > 16 ? 32 : 16;
         const long long ntiles = (long long)a.n * cdiv(a.w, tw) * cdiv(a.h, tpx / tw);
-        if (narrow && ntiles * cdiv(a.cout, 64) <= 128) two = false;
+        if (ntiles * cdiv(a.cout, 64) <= 128) two = false;
     }
     if (a.subpix) {                     // a.h, a.w = the low-resolution grid
         if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry);
@@ -1511,79 +1201,11 @@ static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float
         return two ? launch_igemm_ws<T, V5, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry);
     }
     if (a.w > 16 && a.h >= 16) {
-        // HBM-bound shape (one K chunk, 32 output channels, e.g. 32 -> 32 at 256x256): two 8-wave workgroups per CU on
-        // 256-pixel tiles (63 KB of LDS, <= 128 VGPRs each) so that one's epilogue overlaps the other's loads
-        static const bool occ2 = [] { const char* e = getenv("RVIP_L0_OCC2"); return e && e[0] == '1'; }();
-        if (occ2 && wide && !two && a.kd == 1 && a.cin <= 64 / (int)sizeof(T) && (long long)a.n * a.h * a.w >= 512 * 1024)
-            return launch_igemm_ws<T, V5, 32, 1, 256>(a, s, used, stats, rows_out, dry, 2);
         if (wide) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 9, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 9, 8>(a, s, used, stats, rows_out, dry);
         return two ? launch_igemm_ws<T, V5, 32, 2, 512>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512>(a, s, used, stats, rows_out, dry);
     }
     if (a.w > 16) return two ? launch_igemm_ws<T, V5, 32, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 256>(a, s, used, stats, rows_out, dry);
     return two ? launch_igemm_ws<T, V5, 16, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 16, 1, 256>(a, s, used, stats, rows_out, dry);
-}
-
-template <typename T, int TW, int NCT, int NW>
-static int launch_igemm_dma(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry) {
-    constexpr int NPIX = NW * 64, TH = NPIX / TW;
-    constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
-    constexpr int IN_BYTES = NHROWS * 64, W_BYTES = 9 * NCT * 32 * 64;
-    constexpr int KCE = 64 / (int)sizeof(T);
-    constexpr int LDS_MAX = 160 * 1024;
-    used = false;
-    const int nchunks = (int)cdiv(a0.cin, KCE) * a0.kd;
-    // eligibility: 32-bit byte offsets, chunks never straddle the concat boundary
-    const long long x0b = (long long)a0.n * (a0.h >> a0.up0) * (a0.w >> a0.up0) * a0.c0 * (long long)sizeof(T);
-    const long long x1b = (long long)a0.n * a0.h * a0.w * a0.c1 * (long long)sizeof(T);
-    const long long wpb = 9LL * a0.kd * a0.cin * a0.cout * (long long)sizeof(T);
-    if (x0b >= (1LL << 31) || x1b >= (1LL << 31) || wpb >= (1LL << 31)) return RVIP_OK;
-    if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
-    if (a0.y1 && a0.csplit % 32) return RVIP_OK;
-    const long long npx = (long long)a0.n * a0.h * a0.w;
-    const long long yb = (a0.down2 ? npx / 4 : npx) * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
-    if (yb >= (1LL << 31) || y1b >= (1LL << 31)) return RVIP_OK;
-    if (sizeof(T) == 2 && a0.cout % 8) return RVIP_OK;
-    ConvArgs2 b;
-    b.x0 = a0.x0; b.x1 = a0.x1; b.wp = a0.wp; b.bias = a0.bias; b.y = a0.y; b.y1 = a0.y1;
-    b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
-    b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = 0; b.nt_in = 0;
-    b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
-    b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
-    b.ntiles = a0.n * b.tiles_x * b.tiles_y;
-    const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 <= LDS_MAX;
-    b.wres = res ? nchunks : 0;
-    b.lds_bias_off = 2 * IN_BYTES + (res ? nchunks : 2) * W_BYTES;
-    const int lds = b.lds_bias_off + 256;
-    if (lds > LDS_MAX) return RVIP_OK;
-    static std::atomic<int> attr_lds{0};             // idempotent attribute call; atomic so concurrent host threads do not race on the flag
-    if (!dry && lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma<T, TW, NCT, NW, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma<T, TW, NCT, NW, true>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-        if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
-        attr_lds = LDS_MAX;
-    }
-    const int cot = (int)cdiv(a0.cout, NCT * 32);
-    int gx = 256 / cot;                      // one workgroup per CU in total (LDS-limited), persistent over tiles
-    if (gx < 1) gx = 1;
-    if (gx > b.ntiles) gx = b.ntiles;
-    b.stats = stats;
-    { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
-    if (rows_out) *rows_out = gx;
-    if (dry) { used = true; return RVIP_OK; }
-    if (stats) hipLaunchKernelGGL((conv3x3_igemm_dma<T, TW, NCT, NW, true>), dim3((unsigned)gx, (unsigned)cot), dim3(NW * 64), lds, s, b);
-    else hipLaunchKernelGGL((conv3x3_igemm_dma<T, TW, NCT, NW, false>), dim3((unsigned)gx, (unsigned)cot), dim3(NW * 64), lds, s, b);
-    used = true;
-    return check_launch();
-}
-
-template <typename T>
-static int dispatch_igemm_dma(const ConvArgs& a, hipStream_t s, bool& used, float* stats = nullptr, int* rows_out = nullptr, bool dry = false) {
-    const bool two = a.cout > 32;
-    if (a.w > 16 && a.h >= 16) return two ? launch_igemm_dma<T, 32, 2, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_dma<T, 32, 1, 8>(a, s, used, stats, rows_out, dry);
-    if (a.w > 16) return two ? launch_igemm_dma<T, 32, 2, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_dma<T, 32, 1, 4>(a, s, used, stats, rows_out, dry);
-    return two ? launch_igemm_dma<T, 16, 2, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_dma<T, 16, 1, 4>(a, s, used, stats, rows_out, dry);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1880,23 +1502,10 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     }
 }
 
-// Kernel generation per launch.  RVIP_IGEMM=v1|v2|v3|v4 forces one (A/B measurements).  Default v4 - four loader waves plus
-// EIGHT compute waves on the 512-pixel tiling (smaller maps: v3's four) - which is within 1 % of the best of v2 / v3 / v4
-// on every layer of config 2 (profiles/r01_igemm_v2_v3_v4.txt: family total 2.18 / 2.06 / 1.98 ms per step): the loaders
-// take the DMA issue out of the MFMA waves like v3, and the epilogue stores are spread over 8 waves like v2.
-// v5 (16x16x32 MFMA, 16-bit types) unless RVIP_IGEMM names an older generation (A/B measurements)
-static bool igemm_use_v5() {
-    static const bool on = [] { const char* e = getenv("RVIP_IGEMM"); return !(e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4'); }();
-    return on;
-}
-static int igemm_generation(const ConvArgs& a, bool stats = false) {
-    static const int forced = [] { const char* e = getenv("RVIP_IGEMM"); return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4') ? e[1] - '0' : 0; }();
-    (void)stats;
-    if (a.subpix) return 3;                            // only the wave-specialised kernel has the 4-tap phase form
-    if (forced) return forced;
-    return 4;
-}
-
+// Kernel selection: the wave-specialised LDS-DMA implicit GEMM (conv3x3_igemm_ws16 for the 16-bit types, conv3x3_igemm_ws for
+// f32 and for the four-compute-wave sub-pixel tiling) serves every shape it is eligible for; the register-staged conv3x3_igemm is
+// the fallback for ragged channel counts (concat halves that are not whole 64-byte chunks, Cout % 8).  The generations measured
+// and retired on the way (igemm v2: every wave stages and computes; two workgroups per CU on the one-chunk layers) are in DESIGN.md.
 }  // namespace rvip
 
 using namespace rvip;
@@ -1942,13 +1551,9 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
     int rc0 = conv_args_from_desc(d, a);
     if (rc0) return rc0;
     hipStream_t s = (hipStream_t)stream;
-    const int gen = igemm_generation(a);
-    if (gen >= 2) {
+    {
         bool used = false;
-        int rc;
-        if (gen >= 3 || d->dtype == RVIP_F16)        // the A/B generation v2 is not built for f16
-            rc = by_dtype(d->dtype, [&](auto t) { return igemm_use_v5() ? dispatch_igemm_ws<decltype(t), true>(a, s, used, nullptr, nullptr, false, gen >= 4) : dispatch_igemm_ws<decltype(t), false>(a, s, used, nullptr, nullptr, false, gen >= 4); });
-        else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used) : dispatch_igemm_dma<float>(a, s, used);
+        const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, s, used, nullptr, nullptr, false, !a.subpix); });
         if (rc || used) return rc;
     }
     if (a.kd > 1 || a.down2 || a.subpix) return RVIP_EUNSUPPORTED;        // the register-staged fallback is 2-D only and has the plain epilogue
@@ -1960,15 +1565,8 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
 extern "C" int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d) {
     ConvArgs a;
     if (conv_args_from_desc(d, a) != RVIP_OK || d->y1) return 0;
-    const int gen = igemm_generation(a, true);
-    if (gen < 2) return 0;
-    if (gen == 2 && d->cout > 32) return 0;      // v2's per-lane accumulators exceed 256 VGPRs at the 64-channel tile
     bool used = false; int rows = 0;
-    int rc;
-    if (gen >= 3 || d->dtype == RVIP_F16)
-        rc = by_dtype(d->dtype, [&](auto t) { return igemm_use_v5() ? dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, nullptr, &rows, true, gen >= 4) : dispatch_igemm_ws<decltype(t), false>(a, nullptr, used, nullptr, &rows, true, gen >= 4); });
-    else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, nullptr, used, nullptr, &rows, true)
-                                    : dispatch_igemm_dma<float>(a, nullptr, used, nullptr, &rows, true);
+    const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, nullptr, &rows, true, !a.subpix); });
     return (rc == RVIP_OK && used) ? rows : 0;
 }
 
@@ -1983,10 +1581,7 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
     if (stats_ws_bytes < (size_t)rows * 2 * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
     bool used = false;
     hipStream_t s = (hipStream_t)stream;
-    const int sgen = igemm_generation(a, true);
-    if (sgen >= 3 || d->dtype == RVIP_F16)
-        rc = by_dtype(d->dtype, [&](auto t) { return igemm_use_v5() ? dispatch_igemm_ws<decltype(t), true>(a, s, used, stats_ws, nullptr, false, sgen >= 4) : dispatch_igemm_ws<decltype(t), false>(a, s, used, stats_ws, nullptr, false, sgen >= 4); });
-    else rc = d->dtype == RVIP_BF16 ? dispatch_igemm_dma<bf16_t>(a, s, used, stats_ws) : dispatch_igemm_dma<float>(a, s, used, stats_ws);
+    rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, s, used, stats_ws, nullptr, false, !a.subpix); });
     if (rc) return rc;
     return used ? RVIP_OK : RVIP_EUNSUPPORTED;
 }

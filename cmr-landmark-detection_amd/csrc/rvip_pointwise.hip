@@ -1212,121 +1212,6 @@ struct PostC1Wgrad {
     __device__ void run_k(int ch, int k, double t) const { dw[k * cout + ch] = (float)t; }
 };
 
-// ------------------------------------------------------------------------------------------------
-// First stage without its conv output: z0 = act(conv3x3(x) + bias) has ONE input channel, so recomputing it from the 4 MB
-// input (9 FMAs per value, x tile in LDS) is cheaper than writing the 134 MB tensor once and reading it four times.
-// Four passes share the recompute (MODE): BN statistics, BN apply (+dropout) -> y, BN-backward reduce, BN-backward apply
-// fused with the first layer's weight / bias gradient (dz is never written either).  Tiling as c1_wgrad_tiled.
-// ------------------------------------------------------------------------------------------------
-struct C1Conv { const void* x; const float* w; const float* bias; int n, h, w_, c, act; int tiles_x, tiles_y; };
-enum { C1_STATS = 0, C1_APPLY = 1, C1_BWD_REDUCE = 2, C1_BWD_APPLY = 3 };
-
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void c1_stage_kernel(C1Conv cv_, ApplyArgs ap, BnBwdArgs bw, float* __restrict__ ws) {
-    constexpr int VE = Vec<T>::VE;
-    constexpr int K = MODE == C1_BWD_APPLY ? 10 : 2;
-    __shared__ float xs[10 * 34];
-    __shared__ float lds[256 * VE];
-    const T* x = reinterpret_cast<const T*>(cv_.x);
-    const int tid = threadIdx.x, c = cv_.c, cg = c / VE, cv = tid % cg, ps = tid / cg, pps = 256 / cg;
-    const int h = cv_.h, w = cv_.w_;
-    float wr[9][VE], br[VE];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int e = 0; e < VE; ++e) wr[t][e] = cv_.w[t * c + cv * VE + e];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) br[e] = cv_.bias ? cv_.bias[cv * VE + e] : 0.f;
-    float part[K][VE];
-#pragma unroll
-    for (int q = 0; q < K; ++q)
-#pragma unroll
-        for (int e = 0; e < VE; ++e) part[q][e] = 0.f;
-    // per-mode channel constants
-    float p0[VE], p1[VE], p2[VE];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-        const int ch = cv * VE + e;
-        if constexpr (MODE == C1_APPLY) { p0[e] = ap.scale ? ap.scale[ch] : 1.f; p1[e] = ap.shift ? ap.shift[ch] : 0.f; p2[e] = 0.f; }
-        else if constexpr (MODE == C1_BWD_REDUCE) { p0[e] = bw.mean[ch]; p1[e] = bw.invstd[ch]; p2[e] = 0.f; }
-        else if constexpr (MODE == C1_BWD_APPLY) {
-            p0[e] = bw.has_bn ? bw.coef[ch] : 1.f; p1[e] = bw.has_bn ? bw.coef[c + ch] : 0.f; p2[e] = bw.has_bn ? bw.coef[2 * c + ch] : 0.f;
-        } else { p0[e] = p1[e] = p2[e] = 0.f; }
-    }
-    uint32_t key = 0u;
-    if constexpr (MODE == C1_APPLY) key = (ap.drop && !ap.mask) ? dropout_key(ap.state[RVIP_STATE_SEED], ap.state[RVIP_STATE_STEP], (uint32_t)ap.layer_id) : 0u;
-    if constexpr (MODE >= C1_BWD_REDUCE) key = (bw.drop && !bw.mask) ? dropout_key(bw.state[RVIP_STATE_SEED], bw.state[RVIP_STATE_STEP], (uint32_t)bw.layer_id) : 0u;
-    const int ntiles = cv_.n * cv_.tiles_x * cv_.tiles_y;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int bx = tile;
-        const int tx0 = (bx % cv_.tiles_x) * 32; bx /= cv_.tiles_x;
-        const int ty0 = (bx % cv_.tiles_y) * 8;
-        const long long img = bx / cv_.tiles_y;
-        __syncthreads();
-        for (int i = tid; i < 340; i += 256) {
-            const int gy = ty0 - 1 + i / 34, gx = tx0 - 1 + i % 34;
-            float xv = 0.f;
-            if ((unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) {
-                if constexpr (sizeof(T) == 4) xv = x[(img * h + gy) * w + gx];
-                else xv = Vec<T>::dec(x[(img * h + gy) * w + gx].bits);
-            }
-            xs[i] = xv;
-        }
-        __syncthreads();
-        for (int p = ps; p < 256; p += pps) {
-            const int py = p >> 5, px = p & 31;
-            const int gy = ty0 + py, gx = tx0 + px;
-            if (gy >= h || gx >= w) continue;
-            float xin[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) xin[t] = xs[(py + t / 3) * 34 + px + t % 3];
-            float z[VE];
-#pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                float acc = br[e];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc = fmaf(xin[t], wr[t][e], acc);
-                z[e] = Vec<T>::round(act_fwd(acc, cv_.act));           // the value rvip_conv3x3_c1_fwd would have stored
-            }
-            const size_t e0 = (((size_t)img * h + gy) * w + gx) * c + cv * VE;
-            if constexpr (MODE == C1_STATS) {
-#pragma unroll
-                for (int e = 0; e < VE; ++e) { part[0][e] += z[e]; part[1][e] = fmaf(z[e], z[e], part[1][e]); }
-            } else if constexpr (MODE == C1_APPLY) {
-                apply_xform<T, VE>(ap, e0, p0, p1, key, z);
-                Vec<T>::store(ap.y + e0 * sizeof(T), z);
-            } else {
-                float g[VE];
-                Vec<T>::load(bw.dy + e0 * sizeof(T), g);
-                xform_g<T, VE>(bw, e0, cv * VE, key, z, g);
-                if constexpr (MODE == C1_BWD_REDUCE) {
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) { part[0][e] += g[e]; part[1][e] = fmaf(g[e], (z[e] - p0[e]) * p1[e], part[1][e]); }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) {
-                        float t = fmaf(p0[e], g[e], fmaf(p1[e], z[e], p2[e]));
-                        if (!bw.act_after_bn) t *= act_bwd(z[e], bw.act);
-                        const float dq = Vec<T>::round(t);                 // what the unfused path stores as dz and feeds to wgrad
-                        part[0][e] += dq;
-#pragma unroll
-                        for (int tp = 0; tp < 9; ++tp) part[1 + tp][e] = fmaf(xin[tp], dq, part[1 + tp][e]);
-                    }
-                }
-            }
-        }
-    }
-    if constexpr (MODE != C1_APPLY) block_fold<K, VE>(part, true, ps * cg + cv, c, pps, lds, ws + (size_t)blockIdx.x * K * c);
-}
-
-struct PostC1StageBwd {                // rows: 0 = bias gradient, 1..9 = dw taps
-    float* dbias; float* dw; int cout;
-    __device__ void run_k(int ch, int k, double t) const {
-        if (k == 0) dbias[ch] = (float)t;
-        else dw[(k - 1) * cout + ch] = (float)t;
-    }
-};
-
 // landmark = flat argmax over H*W per (slice, class), first maximum wins; optional > thr mask
 __global__ __launch_bounds__(256) void landmarks_kernel(const float* __restrict__ pred, long long* __restrict__ idx_out,
                                                         uint8_t* __restrict__ mask_out, int hw, int k, float thr) {
@@ -1834,109 +1719,6 @@ extern "C" int rvip_conv3d_c1_wgrad(const void* x, const void* dy, float* dw, in
         if (rc) return rc;
     }
     return RVIP_OK;
-}
-
-// ---- first stage without its conv output (c1_stage_kernel) ----
-static int c1_geom(const rvip_c1_desc* c, C1Conv& cv, int& nb) {
-    if (!c || !c->x || !c->w || !RVIP_DT_OK(c->dtype) || c->n <= 0 || c->h <= 0 || c->w_ <= 0) return RVIP_EINVAL;
-    const int ve = RVIP_VE(c->dtype);
-    if (c->cout <= 0 || c->cout % ve || 256 % (c->cout / ve)) return RVIP_EUNSUPPORTED;
-    cv.x = c->x; cv.w = c->w; cv.bias = c->bias; cv.n = c->n; cv.h = c->h; cv.w_ = c->w_; cv.c = c->cout; cv.act = c->act;
-    cv.tiles_x = (int)cdiv(c->w_, 32); cv.tiles_y = (int)cdiv(c->h, 8);
-    const long long nt = (long long)c->n * cv.tiles_x * cv.tiles_y;
-    nb = (int)(nt < 1024 ? nt : 1024);
-    return RVIP_OK;
-}
-
-template <int MODE>
-static int c1_launch(const rvip_c1_desc* c, const C1Conv& cv, const ApplyArgs& ap, const BnBwdArgs& bw, int nb, float* ws, hipStream_t s) {
-    if (c->dtype == RVIP_BF16) hipLaunchKernelGGL((c1_stage_kernel<bf16_t, MODE>), dim3(nb), dim3(256), 0, s, cv, ap, bw, ws);
-    else if (c->dtype == RVIP_F16) hipLaunchKernelGGL((c1_stage_kernel<f16_t, MODE>), dim3(nb), dim3(256), 0, s, cv, ap, bw, ws);
-    else hipLaunchKernelGGL((c1_stage_kernel<float, MODE>), dim3(nb), dim3(256), 0, s, cv, ap, bw, ws);
-    return check_launch();
-}
-
-extern "C" int rvip_c1_stage_stats(const rvip_c1_desc* c, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
-                                   float momentum, float eps, int unbiased_moving, float* mean, float* invstd, float* scale, float* shift,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
-    (void)hipGetLastError();
-    C1Conv cv; int nb;
-    int rc = c1_geom(c, cv, nb);
-    if (rc) return rc;
-    if (!mean || !invstd || !scale || !shift || !workspace) return RVIP_EINVAL;
-    if (workspace_bytes < (size_t)nb * 2 * cv.c * sizeof(float)) return RVIP_EWORKSPACE;
-    ApplyArgs ap{}; BnBwdArgs bw{};
-    hipStream_t s = (hipStream_t)stream;
-    rc = c1_launch<C1_STATS>(c, cv, ap, bw, nb, (float*)workspace, s);
-    if (rc) return rc;
-    const long long rows = (long long)c->n * c->h * c->w_;
-    PostBnStats p{gamma, beta, moving_mean, moving_var, mean, invstd, scale, shift, (double)rows, momentum, eps, unbiased_moving};
-    return launch_fold<2, PostBnStats, 16>((float*)workspace, nb, cv.c, p, s);
-}
-
-extern "C" int rvip_c1_stage_apply(const rvip_c1_desc* c, const rvip_apply_desc* d, void* stream) {
-    (void)hipGetLastError();
-    C1Conv cv; int nb;
-    int rc = c1_geom(c, cv, nb);
-    if (rc) return rc;
-    if (!d || !d->y || d->pooled || d->dtype != c->dtype || d->n != c->n || d->h != c->h || d->w != c->w_ || d->c != c->cout) return RVIP_EINVAL;
-    if (d->drop_rate < 0.f || d->drop_rate >= 1.f) return RVIP_EINVAL;
-    const int drop = d->drop_rate > 0.f;
-    if (drop && !d->mask && !d->state) return RVIP_EINVAL;
-    ApplyArgs ap{}; BnBwdArgs bw{};
-    ap.z = nullptr; ap.y = (unsigned char*)d->y; ap.pooled = nullptr; ap.scale = d->scale; ap.shift = d->shift; ap.act = d->act;
-    ap.inv_keep = drop ? 1.f / (1.f - d->drop_rate) : 1.f; ap.thr = dropout_thr(d->drop_rate);
-    ap.mask = d->mask; ap.state = d->state; ap.layer_id = d->layer_id; ap.drop = drop;
-    ap.n = d->n; ap.h = d->h; ap.w = d->w; ap.c = d->c;
-    return c1_launch<C1_APPLY>(c, cv, ap, bw, nb, nullptr, (hipStream_t)stream);
-}
-
-static int c1_fill_bw(const rvip_c1_desc* c, const rvip_bnbwd_desc* d, BnBwdArgs& bw) {
-    if (!d || !d->dy || d->dtype != c->dtype || d->c != c->cout || d->rows != (long long)c->n * c->h * c->w_) return RVIP_EINVAL;
-    if (d->drop_rate < 0.f || d->drop_rate >= 1.f) return RVIP_EINVAL;
-    const int drop = d->drop_rate > 0.f;
-    if (drop && !d->mask && !d->state) return RVIP_EINVAL;
-    bw.dy = (const unsigned char*)d->dy; bw.z = nullptr; bw.dz = nullptr;
-    bw.mean = d->mean; bw.invstd = d->invstd; bw.scale = d->scale; bw.shift = d->shift; bw.coef = d->coef;
-    bw.act = d->act; bw.act_after_bn = d->act_after_bn; bw.has_bn = d->gamma != nullptr;
-    bw.inv_keep = drop ? 1.f / (1.f - d->drop_rate) : 1.f; bw.thr = dropout_thr(d->drop_rate);
-    bw.mask = d->mask; bw.state = d->state; bw.layer_id = d->layer_id; bw.drop = drop;
-    bw.rows = d->rows; bw.c = d->c; bw.pool_dp = nullptr; bw.pool_add = nullptr; bw.ph = bw.pw = 0;
-    return RVIP_OK;
-}
-
-extern "C" int rvip_c1_stage_bwd_reduce(const rvip_c1_desc* c, const rvip_bnbwd_desc* d, void* stream) {
-    (void)hipGetLastError();
-    C1Conv cv; int nb;
-    int rc = c1_geom(c, cv, nb);
-    if (rc) return rc;
-    ApplyArgs ap{}; BnBwdArgs bw{};
-    rc = c1_fill_bw(c, d, bw);
-    if (rc) return rc;
-    if (!d->gamma || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->coef || !d->workspace) return RVIP_EINVAL;
-    if (d->workspace_bytes < (size_t)nb * 2 * cv.c * sizeof(float)) return RVIP_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    rc = c1_launch<C1_BWD_REDUCE>(c, cv, ap, bw, nb, (float*)d->workspace, s);
-    if (rc) return rc;
-    PostBnBwd p{d->gamma, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef, (double)d->rows, d->c};
-    return launch_fold<2, PostBnBwd>((float*)d->workspace, nb, d->c, p, s);
-}
-
-extern "C" int rvip_c1_stage_bwd_apply(const rvip_c1_desc* c, const rvip_bnbwd_desc* d, float* dw, void* stream) {
-    (void)hipGetLastError();
-    C1Conv cv; int nb;
-    int rc = c1_geom(c, cv, nb);
-    if (rc) return rc;
-    ApplyArgs ap{}; BnBwdArgs bw{};
-    rc = c1_fill_bw(c, d, bw);
-    if (rc) return rc;
-    if (!dw || !d->dbias || !d->workspace || (d->gamma && !d->coef)) return RVIP_EINVAL;
-    if (d->workspace_bytes < (size_t)nb * 10 * cv.c * sizeof(float)) return RVIP_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    rc = c1_launch<C1_BWD_APPLY>(c, cv, ap, bw, nb, (float*)d->workspace, s);
-    if (rc) return rc;
-    PostC1StageBwd p{d->dbias, dw, d->c};
-    return launch_fold_k<PostC1StageBwd>((float*)d->workspace, nb, d->c, 10, p, s);
 }
 
 extern "C" int rvip_landmarks(const float* pred, long long* idx_out, uint8_t* mask_out, int n, int hw, int k, float thr, void* stream) {

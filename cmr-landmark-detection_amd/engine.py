@@ -331,17 +331,6 @@ class Engine:
         self.fuse_head = bool(last.bn and not last.pool and not (last.drop and last.drop[1] > 0) and last.y == plan.head['src']
                               and cg_ <= 64 and (cg_ & (cg_ - 1)) == 0 and os.environ.get('RVIP_FUSE_HEAD', '1') != '0')
         last_apply = None
-        # RVIP_FUSE_FIRST=1: the first stage (Cin = 1) does not store its conv output in training, rvip_c1_stage_* recompute
-        # it from the input.  Saves 0.9 GB of traffic per step but the recompute passes are VALU / LDS bound: 6.11 vs 6.04 ms.
-        first_st = plan.stages[0]
-        self.fuse_first = bool(first_st.src0 == 'input_1' and self.kd == 1 and not first_st.pool and 256 % (first_st.cout // ve_) == 0
-                               and os.environ.get('RVIP_FUSE_FIRST', '0') == '1')   # correct (tests) but measured slower: off
-        c1d = None
-        if self.fuse_first:
-            c1d = N.C1Desc()
-            c1d.x, c1d.w, c1d.bias = self.act['input_1'].data_ptr(), P.p(first_st.conv, 'kernel').value, P.p(first_st.conv, 'bias').value
-            c1d.n, c1d.h, c1d.w_, c1d.cout, c1d.act, c1d.dtype = n, first_st.h, first_st.w, first_st.cout, A[first_st.act_conv], dt
-            self._keep.append(c1d)
         for st in plan.stages:
             rows = n * st.h * st.w
             z, y = self.act[st.z], self.act[st.y]
@@ -375,7 +364,7 @@ class Engine:
             fuse_stats = st.bn and os.environ.get('RVIP_FUSE_STATS', '1') != '0'
             if fuse_stats and not first:
                 fused_rows = L.rvip_conv3x3_fwd_stats_rows(C.byref(d))     # > 0: the LDS-DMA igemm folds them in its epilogue
-            elif fuse_stats and self.kd == 1 and not self.fuse_first:
+            elif fuse_stats and self.kd == 1:
                 fused_rows = L.rvip_conv3x3_c1_fwd_stats_rows(n, st.h, st.w, st.cout, dt)       # first layer (Cin = 1), tiled kernel
             if fused_rows > 0:
                 if first:
@@ -387,16 +376,11 @@ class Engine:
                     ws, fused_rows, C.c_longlong(rows), st.cout, P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'),
                     P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), unbiased,
                     self._bn(st, 'mean'), self._bn(st, 'invstd'), self._bn(st, 'scale'), self._bn(st, 'shift'))))
-            elif not (first and self.fuse_first):
+            else:
                 fwd_t.append(call)
             fwd_i.append(call)
             if st.bn:
-                if first and self.fuse_first:
-                    fwd_t.append((L.rvip_c1_stage_stats, (
-                        C.byref(c1d), P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'), P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'),
-                        C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), unbiased,
-                        self._bn(st, 'mean'), self._bn(st, 'invstd'), self._bn(st, 'scale'), self._bn(st, 'shift'), ws, wsb)))
-                elif fused_rows <= 0:
+                if fused_rows <= 0:
                     fwd_t.append((L.rvip_bn_train_stats, (
                         _ptr(z), C.c_longlong(rows), st.cout, dt, P.p(st.bn, 'gamma'), P.p(st.bn, 'beta'),
                         P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), unbiased,
@@ -407,7 +391,7 @@ class Engine:
             # ---- apply (BN affine, act-after-BN, dropout, pool) ----
             # (a conv that feeds MaxPooling directly shares one tensor name for z and y: the pass then runs in
             #  place as an identity and only produces the pooled tensor)
-            if st.bn or st.act_post or st.drop or st.pool or (first and self.fuse_first):
+            if st.bn or st.act_post or st.drop or st.pool:
                 for training in (True, False):
                     a = N.ApplyDesc()
                     a.z, a.y = z.data_ptr(), y.data_ptr()
@@ -424,8 +408,6 @@ class Engine:
                     self._keep.append(a)
                     if training and st is last and self.fuse_head:
                         last_apply = a                      # consumed by rvip_bn_apply_head below
-                    elif training and first and self.fuse_first:
-                        fwd_t.append((L.rvip_c1_stage_apply, (C.byref(c1d), C.byref(a))))
                     elif not training and not (st.bn or st.act_post or st.drop or st.pool):
                         pass                                # inference: y is z (no pass needed)
                     else:
@@ -536,7 +518,7 @@ class Engine:
                     b.mask = self.masks[st.drop[0]].data_ptr()
             b.rows, b.c, b.dtype = rows, st.cout, dt
             b.workspace, b.workspace_bytes = self.ws.data_ptr(), self.ws_bytes
-            if defer and not (first and self.fuse_first):
+            if defer:
                 if st is last and self.fuse_head:
                     nr = L.rvip_bn_bwd_apply_head_rows(C.c_longlong(rows), st.cout, dt, hd['k'])
                 else:
@@ -546,11 +528,6 @@ class Engine:
                 b.bias_rows, b.bias_rows_bytes = rbuf.data_ptr(), rbuf.numel() * 4
                 narrow.append((rbuf, P.g(st.conv, 'bias'), nr, st.cout))
             self._keep.append(b)
-            if first and self.fuse_first:
-                if st.bn:
-                    bwd.append((L.rvip_c1_stage_bwd_reduce, (C.byref(c1d), C.byref(b))))
-                bwd.append((L.rvip_c1_stage_bwd_apply, (C.byref(c1d), C.byref(b), P.g(st.conv, 'kernel'))))
-                continue
             if st is last and self.fuse_head:
                 b.dy = None
                 bwd.append((L.rvip_bn_bwd_reduce_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'], P.g(hd['conv'], 'kernel'),

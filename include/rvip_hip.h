@@ -301,27 +301,6 @@ int rvip_head_bwd(const void* x, const float* w, const float* dlogit, void* dx, 
                   long long rows, int cin, int k, int dtype,
                   void* workspace, size_t workspace_bytes, void* stream);
 
-/* The FIRST stage (Cin = 1) without its conv output.  z0 = act(conv3x3(x) + bias) is recomputed from the single-channel
- * input wherever it is needed (9 FMAs per value) instead of being written once and read four times:
- *   rvip_c1_stage_stats      = rvip_conv3x3_c1_fwd + rvip_bn_train_stats, nothing stored
- *   rvip_c1_stage_apply      = rvip_bn_apply on the recomputed z0 (d->z ignored, no pool) -> d->y
- *   rvip_c1_stage_bwd_reduce = rvip_bn_bwd_reduce on the recomputed z0 (d->z ignored)
- *   rvip_c1_stage_bwd_apply  = rvip_bn_bwd_apply + rvip_conv3x3_c1_wgrad: dz0 stays in registers, writes d->dbias and dw[9][Cout]
- *                              (d->z, d->dz ignored; workspace >= 1024 * 10 * Cout floats)
- * Cout / VE must divide 256 (RVIP_EUNSUPPORTED otherwise).  Inference uses rvip_conv3x3_c1_fwd + rvip_bn_apply. */
-typedef struct rvip_c1_desc {
-    const void* x; const float* w; const float* bias;   /* x [N,H,W,1]; w fp32 HWIO [9][1][Cout] */
-    int32_t n, h, w_, cout;
-    int32_t act;                                        /* activation fused into the conv (RVIP_ACT_*) */
-    int32_t dtype;
-} rvip_c1_desc;
-int rvip_c1_stage_stats(const rvip_c1_desc* c, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
-                        float momentum, float eps, int unbiased_moving, float* mean, float* invstd, float* scale, float* shift,
-                        void* workspace, size_t workspace_bytes, void* stream);
-int rvip_c1_stage_apply(const rvip_c1_desc* c, const rvip_apply_desc* d, void* stream);
-int rvip_c1_stage_bwd_reduce(const rvip_c1_desc* c, const rvip_bnbwd_desc* d, void* stream);
-int rvip_c1_stage_bwd_apply(const rvip_c1_desc* c, const rvip_bnbwd_desc* d, float* dw, void* stream);
-
 /* The LAST conv stage fused with the 1x1 sigmoid head (Unets.py:128): nothing but the head reads that stage's BN output
  * y = act(scale*z + shift), so it is built in registers instead of being stored and read back three times.
  *   rvip_bn_apply_head      = rvip_bn_apply (no dropout, no pool; d->y ignored) + rvip_head_fwd in one pass over z

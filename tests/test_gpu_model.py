@@ -48,7 +48,15 @@ def _flat_grads(grads):
     return {(k, i): g for k, gs in grads.items() for i, g in enumerate(gs)}
 
 
-CLEAN_SEED = 325             # data seed of the default variant: no knife edge at step 0 at 1.5x the margin (tools/find_clean_seed.py 0 400, KNIFE_REL=4.5e-6)
+# Data seeds whose FIRST training step has no knife edge (no ReLU / pooling decision within fp32 noise; found on the CPU with the
+# float64 oracle alone by tools/find_clean_seed.py at 1.5x the test's margin, 600 seeds tried per variant).  Variants without an
+# entry have no such seed among the first 600 (a few thousand pre-activations per layer at a 3e-6 relative margin: roughly one
+# near-zero element per layer is the norm) and keep seed 3.
+CLEAN_SEEDS = {
+    'default': 325,
+    'BATCH_NORMALISATION=False,ACTIVATION=elu': 0,
+    'USE_UPSAMPLE=False': 238,
+}
 
 VARIANTS = [
     dict(),
@@ -77,8 +85,9 @@ def test_fp32_training_steps_match_oracle(variant):
       tight  |g_dev - g_64|max <= max(3e-4 * |g_64|max, 5e-8)
       f32    ... <= |g_32 - g_64|max: no worse than the float32 CPU evaluation of the same graph (ill-conditioned BN backward)
       knife  ... <= 25 % of |g_64|max, only when the float64 oracle finds a ReLU / pooling decision inside fp32 noise
-    The tight bound must hold for >= 90 % of the (step, tensor) pairs of every variant, and the data seed of the default variant
-    is one without any knife edge in its first step (chosen on the CPU with the oracle alone: tools/find_clean_seed.py)."""
+    In every step the oracle finds free of knife edges the knife bound is not available and the tight bound must hold for >= 90 % of
+    the tensors (the rest may take the f32 bound); the data seeds of three variants (CLEAN_SEEDS, chosen on the CPU with the oracle
+    alone: tools/find_clean_seed.py) make their first step such a step, which is asserted."""
     cfg = _cfg(**variant)
     kind = M.resolve_loss(cfg['LOSS_FUNCTION'])
     red = M.loss_reduction(cfg['LOSS_FUNCTION'])       # 'sum' for the BceDiceLoss class form (oracle/rvip_oracle.py::bce_dice_loss)
@@ -87,12 +96,13 @@ def test_fp32_training_steps_match_oracle(variant):
     model = rvip.get_model(cfg, metrics=[M.dice_coef_labels, M.dice_coef_lower, M.dice_coef_upper])
     ref, layers = _oracle_from(model, cfg)
     ref32, _ = _oracle_from(model, cfg, dtype=np.float32)     # conditioning probe: the same graph evaluated in float32
-    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=CLEAN_SEED if not variant else 3)
+    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=CLEAN_SEEDS.get(_variant_id(variant), 3))
     x64, y64 = x.astype(np.float64), y.astype(np.float64)
     eng = model._engine(B)
     wname = {0: 'kernel', 1: 'bias'}
     specs = model.plan.weight_specs()
-    rep = BRANCH_REPORT.setdefault(_variant_id(variant), dict(tight=0, f32=0, knife=0, worst_tight_ratio=0.0, knife_steps=[], detail=[]))
+    rep = BRANCH_REPORT.setdefault(_variant_id(variant), dict(tight=0, f32=0, knife=0, clean_steps=0, clean_tight=0, clean_total=0,
+                                                              worst_tight_ratio=0.0, knife_steps=[], detail=[]))
     for step in range(3):
         # Adam turns fp32 noise on near-zero gradients into O(lr) weight differences, so the oracle restarts every
         # step from the DEVICE weights; the optimiser arithmetic is checked separately on the device's gradients.
@@ -124,8 +134,9 @@ def test_fp32_training_steps_match_oracle(variant):
         knife = O.knife_edges(layers, cache)
         if knife:
             rep['knife_steps'].append(step)
-        if not variant and step == 0:
-            assert not knife, 'CLEAN_SEED no longer avoids knife edges in the first step: %s' % (knife,)
+        if _variant_id(variant) in CLEAN_SEEDS and step == 0:
+            assert not knife, 'the clean seed no longer avoids knife edges in the first step: %s' % (knife,)
+        rep['clean_steps'] += 0 if knife else 1
         got = model._params.grads_host()
         dev_grads = {}
         for (lname, i), g in _flat_grads(rgrads).items():
@@ -145,6 +156,9 @@ def test_fp32_training_steps_match_oracle(variant):
             else:
                 raise AssertionError((step, lname, wn, err, dict(tight=tight, f32=f32b, knife=bool(knife), gmax=gmax)))
             rep[branch] += 1
+            if not knife:
+                rep['clean_total'] += 1
+                rep['clean_tight'] += branch == 'tight'
             if branch != 'tight':
                 rep['detail'].append([step, '%s/%s' % (lname, wn), branch, err, tight, f32b, gmax])
             dev_grads.setdefault(lname, [None, None])[i] = gg.astype(np.float64)
@@ -156,8 +170,9 @@ def test_fp32_training_steps_match_oracle(variant):
         ref.apply_adam({k: dev_grads[k] for k in rgrads})
         for a_, b_, (ln, wn, _, _, _) in zip(model.get_weights(), ref.get_weights(), specs):
             np.testing.assert_allclose(a_, b_, atol=3e-6, rtol=1e-5, err_msg='step %d %s/%s' % (step, ln, wn))
-    n_all = rep['tight'] + rep['f32'] + rep['knife']
-    assert rep['tight'] >= 0.9 * n_all, 'tight gradient bound held on %d of %d tensors only: %s' % (rep['tight'], n_all, rep['detail'][:8])
+    # wherever the float64 oracle finds the comparison well-posed (no knife edge in that step), the tight bound must be the rule
+    assert rep['clean_tight'] >= 0.9 * rep['clean_total'], 'tight gradient bound held on %d of %d tensors of knife-free steps: %s' % (
+        rep['clean_tight'], rep['clean_total'], [d for d in rep['detail'] if d[2] != 'knife'][:8])
     torch.cuda.synchronize()
     assert model._params.step_count() == 3
     # inference after training: heat-maps 1e-3, argmax bit-exact, >0.5 masks identical
@@ -180,18 +195,15 @@ def test_fp32_training_steps_match_oracle(variant):
 
 
 def test_optional_fusions_give_the_same_training_step(monkeypatch):
-    """RVIP_FUSE_FIRST=1 (first stage recomputed from the input) and RVIP_FUSE_POOLBWD=1 (max-pool backward inside the
-    BN-backward passes) are off by default (measured slower) but must stay correct: same loss, heat-maps and gradients
-    as the default path in fp32."""
+    """RVIP_FUSE_POOLBWD (max-pool backward inside the BN-backward passes) on and off: same loss, heat-maps and gradients in fp32."""
     cfg = _cfg()
     x, y = O.synthetic_batch(4, cfg['DIM'], 2, seed=3)
     outs = []
-    for env in ({}, {'RVIP_FUSE_FIRST': '1', 'RVIP_FUSE_POOLBWD': '1'}):
+    for env in ({'RVIP_FUSE_POOLBWD': '0'}, {'RVIP_FUSE_POOLBWD': '1'}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         model = rvip.get_model(cfg, metrics=[])
         eng = model._engine(4)
-        assert eng.fuse_first == bool(env)
         eng.load_input(x, y)
         eng.forward(training=True)
         eng.backward()
@@ -296,9 +308,9 @@ def test_zz_tolerance_branch_report():
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, 'r02_tolerance_branches.json'), 'w') as f:
         json.dump(BRANCH_REPORT, f, indent=1)
-    tot = {k: sum(v[k] for v in BRANCH_REPORT.values()) for k in ('tight', 'f32', 'knife')}
+    tot = {k: sum(v[k] for v in BRANCH_REPORT.values()) for k in ('tight', 'f32', 'knife', 'clean_steps', 'clean_tight', 'clean_total')}
     print('gradient tolerance branches:', tot)
-    assert tot['tight'] >= 0.9 * sum(tot.values())
+    assert tot['clean_steps'] >= 3 and tot['clean_tight'] >= 0.9 * tot['clean_total']
 
 
 def _assert_landmarks_and_masks(pg, pr, eps=2e-5):

@@ -1,0 +1,168 @@
+"""Op-level parity at the REAL layer shapes of the benchmarked networks: every distinct
+(H, Cin[, skip], Cout, addressing mode) of BASELINE config 2 (256^2, F=32, depth 4) and the largest layers of config 4
+(512^2, F=64, depth 5: 1024 -> 2048 and 2048 -> 2048 at 16^2, the up-sampled 2048 -> 1024 at 32^2, the (512+512) -> 512 concat at
+64^2) -- K loops of 1..64 chunks, 1..32 output-channel tile columns, resident and rotating weights, split-K weight gradients with
+the real slab sizes.  Forward (+ bias + ReLU, UpSampling2D / Concatenate as addressing modes, fused BN statistics), data gradient
+(plain, split into the two concat halves, 2x2-summed for an up-sampled input) and weight gradient, in f32 / bf16 / f16, through the
+C ABI against the float64 NumPy oracle.
+
+The batch is cut to 1-4 images so the oracle stays affordable; the per-image work and every channel-dependent code path are the
+full-size ones.  Inputs are drawn once per shape on a grid that bf16, f16 and f32 all represent exactly (8 significant bits, no
+f16 subnormals), so ONE oracle evaluation serves the three storage types and only accumulation order + the output rounding differ."""
+import ctypes as C
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+import cmr_landmark_detection_amd as rvip
+from oracle import rvip_oracle as O
+from test_gpu_ops import N, P, close, conv_desc, dev, down, f32, ndt, pack, stream, tdt, up
+
+pytestmark = pytest.mark.gpu
+
+# (id, n, h, c0, up0, c1, cout, bn)   h = OUTPUT size (square maps)
+CFG2 = [
+    ('enc0.conv2 32->32@256', 1, 256, 32, 0, 0, 32, True),
+    ('enc1.conv1 32->64@128', 1, 128, 32, 0, 0, 64, True),
+    ('enc1.conv2 64->64@128', 1, 128, 64, 0, 0, 64, True),
+    ('enc2.conv1 64->128@64', 2, 64, 64, 0, 0, 128, True),
+    ('enc2.conv2 128->128@64', 2, 64, 128, 0, 0, 128, True),
+    ('enc3.conv1 128->256@32', 2, 32, 128, 0, 0, 256, True),
+    ('enc3.conv2 256->256@32', 2, 32, 256, 0, 0, 256, True),
+    ('mid.conv1 256->512@16', 4, 16, 256, 0, 0, 512, True),
+    ('mid.conv2 512->512@16', 4, 16, 512, 0, 0, 512, True),
+    ('dec0.up 512->256@32', 2, 32, 512, 1, 0, 256, False),
+    ('dec0.cat 256+256->256@32', 2, 32, 256, 0, 256, 256, True),
+    ('dec1.up 256->128@64', 2, 64, 256, 1, 0, 128, False),
+    ('dec1.cat 128+128->128@64', 2, 64, 128, 0, 128, 128, True),
+    ('dec2.up 128->64@128', 1, 128, 128, 1, 0, 64, False),
+    ('dec2.cat 64+64->64@128', 1, 128, 64, 0, 64, 64, True),
+    ('dec3.up 64->32@256', 1, 256, 64, 1, 0, 32, False),
+    ('dec3.cat 32+32->32@256', 1, 256, 32, 0, 32, 32, True),
+]
+CFG4 = [
+    ('cfg4 mid.conv1 1024->2048@16', 2, 16, 1024, 0, 0, 2048, True),
+    ('cfg4 mid.conv2 2048->2048@16', 2, 16, 2048, 0, 0, 2048, True),
+    ('cfg4 dec0.up 2048->1024@32', 1, 32, 2048, 1, 0, 1024, False),
+    ('cfg4 dec2.cat 512+512->512@64', 1, 64, 512, 0, 512, 512, True),
+    ('cfg4 enc0.conv2 64->64@512', 1, 512, 64, 0, 0, 64, True),
+]
+ALL = CFG2 + CFG4
+
+
+def _grid(a, lim=6.0):
+    """values every storage type holds exactly: bf16 rounding (8 significant bits), |x| in {0} U [2^-10, lim]"""
+    t = torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+    t = np.clip(t, -lim, lim)
+    t[np.abs(t) < 2.0 ** -10] = 0.0
+    assert np.array_equal(torch.from_numpy(t).to(torch.float16).to(torch.float32).numpy(), t)
+    return t
+
+
+@functools.lru_cache(maxsize=2)
+def _case(idx):
+    """inputs + float64 oracle results of one shape (cached: the three dtypes run back to back)"""
+    name, n, h, c0, up0, c1, co, bn = ALL[idx]
+    w_ = h
+    ci = c0 + c1
+    rng = np.random.default_rng(1000 + idx)
+    hs = h // 2 if up0 else h
+    x0 = _grid(rng.standard_normal((n, hs, hs, c0)))
+    x1 = _grid(rng.standard_normal((n, h, w_, c1))) if c1 else None
+    wt = _grid(rng.standard_normal((3, 3, ci, co)) * (0.7 / np.sqrt(9 * ci)) * 8) / 8       # he-like scale, still on the grid
+    wt = _grid(wt)
+    b = rng.standard_normal(co).astype(np.float32) * 0.1
+    dy = _grid(rng.standard_normal((n, h, w_, co)))
+    xin = O.upsample_nearest_fwd(x0) if up0 else x0
+    if c1:
+        xin = np.concatenate([xin, x1], -1)
+    x64, w64, dy64 = xin.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64)
+    fwd = O.act_fwd(O.conv2d_same_fwd(x64, w64, b.astype(np.float64)), 'relu')
+    dx, dw, _ = O.conv2d_same_bwd(x64, w64, dy64)
+    return dict(x0=x0, x1=x1, wt=wt, b=b, dy=dy, fwd=fwd, dx=dx, dw=dw)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('idx', range(len(ALL)), ids=[s[0].replace(' ', '_') for s in ALL])
+def test_real_layer_shape_fwd_stats_dgrad_wgrad(idx, dtype):
+    name, n, h, c0, up0, c1, co, bn = ALL[idx]
+    w_ = h
+    ci = c0 + c1
+    k = _case(idx)
+    L = N.lib()
+    x0d = up(k['x0'], dtype)
+    x1d = up(k['x1'], dtype) if c1 else None
+    dyd, bd = up(k['dy'], dtype), f32(k['b'])
+    wf, wd = pack(k['wt'], dtype)
+    # ---- forward: bias + ReLU epilogue, UpSampling2D / Concatenate read through the addressing modes
+    y = torch.empty((n, h, w_, co), dtype=tdt(dtype), device=dev())
+    d = conv_desc(x0d, c0, up0, x1d, c1, wf, bd, y, None, 0, n, h, w_, co, N.ACT['relu'], dtype)
+    N.call('rvip_conv3x3_fwd', C.byref(d), stream())
+    close(down(y), k['fwd'], dtype, name + ' fwd')
+    # ---- the same launch with the BatchNormalization statistics of the stored tensor folded into the epilogue
+    if bn:
+        rows = L.rvip_conv3x3_fwd_stats_rows(C.byref(d))
+        assert rows > 0, 'the real shapes must take the fused-statistics path'
+        ws = torch.full((rows * 2 * co + 16,), 7.0, dtype=torch.float32, device=dev())
+        y2 = torch.empty_like(y)
+        d.y = y2.data_ptr()
+        N.call('rvip_conv3x3_fwd_stats', C.byref(d), P(ws), C.c_size_t(rows * 2 * co * 4), stream())
+        assert torch.equal(y, y2)                                         # same tensor, bit for bit
+        gamma, beta = np.linspace(0.5, 1.5, co).astype(np.float32), np.linspace(-0.2, 0.2, co).astype(np.float32)
+        gd, btd, mm, mv = f32(gamma), f32(beta), f32(np.zeros(co)), f32(np.ones(co))
+        mean, invstd, scale, shift = (torch.empty(co, dtype=torch.float32, device=dev()) for _ in range(4))
+        N.call('rvip_bn_stats_finalize', P(ws), rows, C.c_longlong(n * h * w_), co, P(gd), P(btd), P(mm), P(mv), 0.99, 1e-3, 1,
+               P(mean), P(invstd), P(scale), P(shift), stream())
+        yq = down(y).astype(np.float64)
+        _, cache = O.bn_train_fwd(yq, gamma.astype(np.float64), beta.astype(np.float64))
+        np.testing.assert_allclose(down(mean), cache[2], atol=3e-6 * max(1.0, float(np.abs(cache[2]).max())))
+        np.testing.assert_allclose(down(invstd), cache[1], rtol=2e-5)
+        np.testing.assert_allclose(down(mv), O.bn_moving_update(np.zeros(co), np.ones(co), cache[2], cache[3], n * h * w_)[1], rtol=2e-5)
+    # ---- data gradient: the same kernel on dy with the rotated operand; concat -> two outputs; up-sampled input -> 2x2 sums
+    if c1:
+        g0 = torch.empty((n, h, w_, c0), dtype=tdt(dtype), device=dev())
+        g1 = torch.empty((n, h, w_, c1), dtype=tdt(dtype), device=dev())
+        d2 = conv_desc(dyd, co, 0, None, 0, wd, None, g0, g1, c0, n, h, w_, ci, 0, dtype)
+        N.call('rvip_conv3x3_fwd', C.byref(d2), stream())
+        close(down(g0), k['dx'][..., :c0], dtype, name + ' dgrad (up half)')
+        close(down(g1), k['dx'][..., c0:], dtype, name + ' dgrad (skip half)')
+    elif up0:
+        glo = torch.empty((n, h // 2, w_ // 2, c0), dtype=tdt(dtype), device=dev())
+        d2 = conv_desc(dyd, co, 0, None, 0, wd, None, glo, None, 0, n, h, w_, ci, 0, dtype)
+        d2.down2 = 1
+        N.call('rvip_conv3x3_fwd', C.byref(d2), stream())
+        close(down(glo), O.upsample_nearest_bwd(k['dx']), dtype, name + ' dgrad (2x2-summed)')
+    else:
+        dx = torch.empty((n, h, w_, ci), dtype=tdt(dtype), device=dev())
+        d2 = conv_desc(dyd, co, 0, None, 0, wd, None, dx, None, 0, n, h, w_, ci, 0, dtype)
+        N.call('rvip_conv3x3_fwd', C.byref(d2), stream())
+        close(down(dx), k['dx'], dtype, name + ' dgrad')
+    # ---- weight gradient: fp32 HWIO, deterministic split-K, immediate and deferred (slabs + batched fold) forms agree bitwise
+    wsb = L.rvip_conv3x3_wgrad_workspace(n, h, w_, ci, co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.full((3, 3, ci, co), 7.0, dtype=torch.float32, device=dev())
+    g = N.Wgrad3x3Desc()
+    g.x0, g.c0, g.up0 = x0d.data_ptr(), c0, up0
+    g.x1, g.c1 = (x1d.data_ptr(), c1) if c1 else (None, 0)
+    g.dy, g.dw = dyd.data_ptr(), dw.data_ptr()
+    g.n, g.h, g.w, g.cout, g.dtype = n, h, w_, co, ndt(dtype)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
+    N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+    got = down(dw)
+    scale = float(np.abs(k['dw']).max())
+    # products are exact in fp32 (inputs carry 8 significant bits); only the fp32 accumulation order over N*H*W pixels differs
+    assert np.abs(got - k['dw']).max() <= 2e-5 * scale * max(1.0, np.sqrt(n * h * w_ / 4096.0)), (name, np.abs(got - k['dw']).max() / scale)
+    ns = L.rvip_conv3x3_wgrad_splits(C.byref(g))
+    assert ns >= 1
+    slabs = torch.empty(ns * 9 * ci * co, dtype=torch.float32, device=dev())
+    dw2 = torch.full((3, 3, ci, co), 3.0, dtype=torch.float32, device=dev())
+    g.workspace, g.workspace_bytes, g.defer_fold = slabs.data_ptr(), slabs.numel() * 4, 1
+    N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+    tab = (N.FoldEntry * 1)()
+    tab[0].src, tab[0].dst, tab[0].nrows, tab[0].width = slabs.data_ptr(), dw2.data_ptr(), ns, 9 * ci * co
+    tabd = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev())
+    N.call('rvip_fold_rows_batch', P(tabd), 1, C.c_longlong(9 * ci * co), 1, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2), name + ': deferred fold differs from the immediate one'

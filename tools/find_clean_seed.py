@@ -1,41 +1,40 @@
-"""Pick the data seed of tests/test_gpu_model.py::test_fp32_training_steps_match_oracle[default] on the CPU with the float64 oracle
-alone: a seed whose first training step has NO knife edge (no ReLU pre-activation / pooling decision within fp32 noise of its
-kink, `oracle.knife_edges` at twice the test margin by default: KNIFE_REL), so that the tight gradient bound is the one that applies.  The initial
-weights are the model's own seeded initialisation (no GPU needed: get_weights() before the first device call).
-    python tools/find_clean_seed.py [first] [last]"""
+"""Pick the data seeds of tests/test_gpu_model.py::test_fp32_training_steps_match_oracle on the CPU with the float64 oracle alone:
+for every variant of that test, the first seed whose FIRST training step has no knife edge (no ReLU pre-activation / pooling
+decision within fp32 noise of its kink: `oracle.knife_edges` at 1.5x the test's margin, KNIFE_REL), so that the tight gradient
+bound is the one that applies there.  The initial weights are the model's own seeded initialisation (no GPU needed).
+    python tools/find_clean_seed.py [variant index ...]      -> prints CLEAN_SEEDS entries"""
 import importlib
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-rvip = importlib.import_module('cmr-landmark-detection_amd')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import test_gpu_model as T   # noqa: E402  (importable without a GPU: only its tests need one)
 from oracle import rvip_oracle as O   # noqa: E402
-ds = importlib.import_module('cmr-landmark-detection_amd.dropout_stream')
 
-cfg = dict(DIM=[32, 32], FILTERS=8, DEPTH=2, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2, LEARNING_RATE=1e-3,
-           RVIP_PRECISION='fp32', LOSS_FUNCTION=rvip.Loss_and_metrics.mse, SEED=11)
-model = rvip.get_model(cfg, metrics=[])
-layers = O.build_graph(cfg)
-it = iter(model.get_weights())
-params = {}
-for l in layers:
-    if l['type'].startswith('Conv'):
-        params[l['name']] = [next(it), next(it)]
-    elif l['type'] == 'BatchNormalization':
-        params[l['name']] = [next(it) for _ in range(4)]
-B = 4
-drops = [l for l in layers if l['type'] == 'Dropout']
-lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 40)
-for seed in range(lo, hi):
-    net = O.OracleUNet(cfg, {k: [a.copy() for a in v] for k, v in params.items()}, dtype=np.float64)
-    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=seed)
-    clean = []
-    for step in range(3):
-        masks = {l['name']: ds.keep_mask((B,) + l['shape'], l['rate'], model.seed, step, i + 1) for i, l in enumerate(drops)}
-        _, grads, _, cache = net.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', masks)
-        clean.append(not O.knife_edges(layers, cache, rel=float(os.environ.get("KNIFE_REL", "6e-6"))))
-        net.apply_bn_moving(cache)
-        net.apply_adam(grads)
-    print('seed %d: knife-edge free steps %s' % (seed, clean), flush=True)
+REL = float(os.environ.get('KNIFE_REL', '4.5e-6'))
+LIMIT = int(os.environ.get('SEED_LIMIT', '600'))
+which = [int(a) for a in sys.argv[1:]] or range(len(T.VARIANTS))
+for vi in which:
+    variant = T.VARIANTS[vi]
+    cfg = T._cfg(**variant)
+    model = T.rvip.get_model(cfg, metrics=[])
+    ref, layers = T._oracle_from(model, cfg)
+    kind = T.M.resolve_loss(cfg['LOSS_FUNCTION'])
+    red = T.M.loss_reduction(cfg['LOSS_FUNCTION'])
+    B = 4
+    masks = T._masks(layers, B, model.seed, 0)
+    found = None
+    for seed in range(LIMIT):
+        x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=seed)
+        if kind[0] == 'mse':
+            _, _, _, cache = ref.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', masks)
+        else:
+            _, _, _, cache = ref.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'bce_dice', masks, w_bce=kind[1], w_dice=kind[2], reduction=red)
+        if not O.knife_edges(layers, cache, rel=REL):
+            found = seed
+            break
+    print('    %r: %s,' % (T._variant_id(variant), found), flush=True)
