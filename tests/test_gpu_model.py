@@ -414,6 +414,40 @@ def test_cfg4_shape_step_is_deterministic_and_finite():
     assert np.all(np.isfinite(ls)) and ls[-1] < ls[0], ls
 
 
+def test_cfg5_full_size_step_is_deterministic_and_finite():
+    """BASELINE.json configs[4] at its real size (16 x 256 x 256 cine volumes, Conv3D 3x3x3, pool (1,2,2), F=32, depth 4, batch 4 per
+    GPU, bf16): parameter count of SURVEY.md 8(d) (25 894 658), bit-identical repeat of fwd+bwd from identical state, finite non-zero
+    gradients, volumes of the batch do not leak into each other (a changed volume changes only its own heat-maps in inference), and
+    the loss falls over optimizer steps through the captured step."""
+    cfg = dict(DIM=[16, 256, 256], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, ACTIVATION='relu',
+               MASK_CLASSES=2, LEARNING_RATE=1e-4, RVIP_PRECISION='bf16', LOSS_FUNCTION=M.mse, SEED=1)
+    model = rvip.get_model(cfg, metrics=[])
+    assert model.count_params() == 25894658
+    G = rvip.Generators.SyntheticSAXGenerator(4, dict(DIM=cfg['DIM'], BATCHSIZE=4, GAUS=True, SIGMA=2, SHUFFLE=False))
+    x, y = G[0]
+    assert x.shape == (4, 16, 256, 256, 1) and y.shape == (4, 16, 256, 256, 2)
+    eng = model._engine(4)
+    outs = []
+    for _ in range(2):
+        eng.load_input(x, y)
+        eng.forward(training=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        outs.append((eng.loss.clone(), eng.pred.clone(), model._params.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.isfinite(outs[0][2]).all() and float(outs[0][2].abs().max()) > 0
+    p0 = model.predict_on_batch(x)
+    x2 = x.copy()
+    x2[2] = x[2][::-1]                                               # volume 2 played backwards
+    p1 = model.predict_on_batch(x2)
+    assert p0.shape == (4, 16, 256, 256, 2) and np.isfinite(p0).all()
+    for b in (0, 1, 3):
+        np.testing.assert_array_equal(p0[b], p1[b])                  # inference: no cross-volume coupling (BN on the moving statistics)
+    assert not np.array_equal(p0[2], p1[2])
+    ls = [model.train_on_batch(x, y)[0] for _ in range(4)]
+    assert eng.launch_mode == 'hipGraph' and np.all(np.isfinite(ls)) and ls[-1] < ls[0], ls
+
+
 def test_f16_path_matches_f16_storage_emulation():
     """f16 device path (RVIP_PRECISION='fp16': IEEE half activations / packed weights, fp32 accumulation and master weights,
     static loss scale) vs the oracle with binary16 rounding applied at every tensor the device materialises in f16 --
