@@ -15,7 +15,6 @@ LIB_PATH = os.environ.get('RVIP_LIB') or os.path.join(_HERE, 'librvip_hip.so')  
 F32, BF16, F16 = 0, 1, 2
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'elu': 2, 'sigmoid': 3}
 LOSS_MSE, LOSS_BCE_DICE = 0, 1
-EPI_BN_REDUCE, EPI_ACT_BWD = 2, 3
 STATE_STEP, STATE_LR, STATE_SEED, STATE_WORDS = 0, 1, 2, 8
 ERRORS = {-1: 'RVIP_EINVAL (bad shape / alignment / null pointer)', -2: 'RVIP_EUNSUPPORTED',
           -3: 'RVIP_EWORKSPACE (workspace too small)', -4: 'RVIP_ELAUNCH (HIP launch failed)'}
@@ -35,11 +34,6 @@ class Conv3x3Desc(C.Structure):
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('act', C.c_int32), ('dtype', C.c_int32),
                 ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32), ('subpix', C.c_int32), ('stream_in', C.c_int32)]
-
-
-class ConvBwdEpilogue(C.Structure):
-    _fields_ = [('mode', C.c_int32), ('act', C.c_int32), ('z', vp), ('mean', vp), ('invstd', vp),
-                ('drop_rate', C.c_float), ('layer_id', C.c_int32), ('state', vp)]
 
 
 class PackEntry(C.Structure):
@@ -93,9 +87,6 @@ SIGNATURES = {
     'rvip_conv3x3_fwd': (C.c_int, [C.POINTER(Conv3x3Desc), vp]),
     'rvip_conv3x3_fwd_stats_rows': (C.c_int, [C.POINTER(Conv3x3Desc)]),
     'rvip_conv3x3_fwd_stats': (C.c_int, [C.POINTER(Conv3x3Desc), vp, C.c_size_t, vp]),
-    'rvip_conv3x3_dgrad_fused_rows': (C.c_int, [C.POINTER(Conv3x3Desc), C.POINTER(ConvBwdEpilogue)]),
-    'rvip_conv3x3_dgrad_fused': (C.c_int, [C.POINTER(Conv3x3Desc), C.POINTER(ConvBwdEpilogue), vp, C.c_size_t, vp]),
-    'rvip_bn_bwd_finalize': (C.c_int, [C.POINTER(BnBwdDesc), vp, C.c_int, vp]),
     'rvip_bn_stats_finalize': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp, vp]),
     'rvip_pack_conv3x3_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_pack_subpixel_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -50,11 +50,6 @@ struct ConvArgs {
     int down2;                                // store the 2x2 block sums of the result at half resolution (gradient of UpSampling2D)
     int subpix;                               // UpSampling2D -> conv as four 2x2-tap phase convolutions on the low-resolution input
     int nt_in;                                // non-temporal input reads (last reader of x0)
-    // backward epilogue of a data gradient (conv3x3_igemm_ws16 EPI 2 / 3, see ConvArgs2); epi = 0: none
-    int epi = 0;
-    const unsigned char* ez = nullptr; const float* emean = nullptr; const float* einvstd = nullptr;
-    int eact = 0, edrop = 0, elayer = 0;
-    float einv_keep = 1.f; unsigned ethr = 65536u; const uint32_t* estate = nullptr;
 };
 
 template <typename T, int TW, int NCT>
@@ -289,15 +284,6 @@ struct ConvArgs2 {
     int nt_in;                               // input pieces with the non-temporal hint
     int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
-    // Backward epilogues of the data gradient (conv3x3_igemm_ws16, EPI 2 / 3): the tensor stored through y is the gradient reaching
-    // the output of a DESTINATION stage (conv -> act -> [BN] -> [dropout]); ez is that stage's stored conv output, same shape as y.
-    //   EPI 2: BN-backward reduction rows stats[gridDim.x][2][cout] = (sum g, sum g * (z - mean) * invstd), g = dropout-backward of
-    //          what is stored (bn_bwd_reduce_kernel's sums, KerasLayers.py:684,691 autodiff);
-    //   EPI 3: no BN: the store becomes dz = g * act'(z) and stats[gridDim.x][width] carries the bias-gradient rows (sum of the stored dz).
-    const unsigned char* ez; unsigned ez_bytes;
-    const float* emean; const float* einvstd;
-    int eact, edrop, elayer;
-    float einv_keep; unsigned ethr; const uint32_t* estate;
 };
 
 // Epilogue of the data gradient of an UpSampling2D -> conv pair (KerasLayers.py:756-758): the gradient w.r.t. the
@@ -764,11 +750,8 @@ __device__ __forceinline__ float lane16_channel_sum(const float (&a)[4], int i16
     e += swz<2>(e);
     return e + swz<1>(e);
 }
-template <typename T, int TW, int NCT, int NPIX, int EPI, int TAPS = 9, int NCW = 4>
+template <typename T, int TW, int NCT, int NPIX, bool STATS, int TAPS = 9, int NCW = 4>
 __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs2 a) {
-    constexpr bool STATS = EPI == 1;                 // forward: BN statistics of the stored output
-    constexpr bool RED = EPI != 0;                   // any mode that ends with the per-channel reduction into a.stats
-    static_assert(EPI >= 0 && EPI <= 3 && (EPI < 2 || TAPS == 9), "epilogue mode");
     static_assert(sizeof(T) == 2, "16-bit storage types");
     static_assert(TAPS == 9 || TAPS == 4, "taps");
     constexpr int TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
@@ -797,12 +780,6 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     if (first_tile >= a.ntiles) return;
     float* lbias = reinterpret_cast<float*>(smem + a.lds_bias_off);        // [BN] bias of this output-channel tile
     if (tid < BN) lbias[tid] = (a.bias && co0 + tid < a.cout) ? a.bias[co0 + tid] : 0.f;
-    if constexpr (EPI == 2) {                        // batch mean / 1/std of the destination stage's channels, next to the bias
-        if (tid < BN) {
-            lbias[64 + tid] = co0 + tid < a.cout ? a.emean[co0 + tid] : 0.f;
-            lbias[128 + tid] = co0 + tid < a.cout ? a.einvstd[co0 + tid] : 0.f;
-        }
-    }
 
     if (wv >= NCW) {
         // ------------------------------------------------ loader waves ------------------------------------------------
@@ -938,7 +915,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                 }
             }
         }
-        if constexpr (RED) {                             // the compute waves' reduction uses two more workgroup barriers
+        if constexpr (STATS) {                           // the compute waves' reduction uses two more workgroup barriers
             asm volatile("s_barrier" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
         }
@@ -1111,187 +1088,12 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                 }
             }
         };
-        // ---- EPI 2 / 3: backward epilogues (see ConvArgs2).  z of the destination stage is fetched with the lane -> (pixel, 8 channels)
-        // map of the stores and un-swapped into the accumulator layout; all fetches of the tile are issued before the first use.
-        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI >= 2 ? a.ez : a.y), 0, EPI >= 2 ? a.ez_bytes : 0, 0x00020000);
-        const uint32_t dkey = (EPI >= 2 && a.edrop) ? dropout_key(a.estate[RVIP_STATE_SEED], a.estate[RVIP_STATE_STEP], (uint32_t)a.elayer) : 0u;
-        // g (dropout backward of the stored gradient) for the 4 channels 4 kq + r of one pixel, and optionally dz = g * act'(z)
-        auto bwd_xform = [&](float (&g)[4], const float (&z)[4], unsigned e0) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g[r] = Vec<T>::round(g[r]);               // the value the next pass reads back
-            if (a.edrop) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint32_t hh = hash32(((e0 >> 1) + (unsigned)i) ^ dkey);
-                    g[2 * i] = (hh & 0xffffu) < a.ethr ? g[2 * i] * a.einv_keep : 0.f;
-                    g[2 * i + 1] = (hh >> 16) < a.ethr ? g[2 * i + 1] * a.einv_keep : 0.f;
-                }
-            }
-            if constexpr (EPI == 3) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] *= act_bwd(z[r], a.eact);
-            }
-        };
-        auto unswap_z = [&](const u32x4v& zl, float (&zx)[4], float (&zy)[4]) __attribute__((always_inline)) {
-            auto s0 = __builtin_amdgcn_permlane16_swap(zl[0], zl[2], false, false);   // the store-side swap is an involution
-            auto s1 = __builtin_amdgcn_permlane16_swap(zl[1], zl[3], false, false);
-            zx[0] = Vec<T>::dec((uint16_t)(s0[0] & 0xffffu)); zx[1] = Vec<T>::dec((uint16_t)(s0[0] >> 16));
-            zx[2] = Vec<T>::dec((uint16_t)(s1[0] & 0xffffu)); zx[3] = Vec<T>::dec((uint16_t)(s1[0] >> 16));
-            zy[0] = Vec<T>::dec((uint16_t)(s0[1] & 0xffffu)); zy[1] = Vec<T>::dec((uint16_t)(s0[1] >> 16));
-            zy[2] = Vec<T>::dec((uint16_t)(s1[1] & 0xffffu)); zy[3] = Vec<T>::dec((uint16_t)(s1[1] >> 16));
-        };
-        // one (channel block, pair of pixels X / Y) of a backward epilogue: statistics, transform, store
-        auto bwd_pair = [&](int cb, float (&x)[4], float (&y)[4], const u32x4v& zl, bool xform, unsigned pixx, unsigned pixy, bool okx, bool oky,
-                            unsigned pixm, bool okm, float (&qs)[4], float (&qq)[4]) __attribute__((always_inline)) {
-            if (xform) {
-                float zx[4], zy[4];
-                unswap_z(zl, zx, zy);
-                const unsigned cstride = a.y1 ? (unsigned)a.csplit : (unsigned)a.cout;      // the transformed half is always the first output
-                const unsigned ch = (unsigned)(co0 + cb * 16 + 4 * kq);
-                bwd_xform(x, zx, pixx * cstride + ch);
-                bwd_xform(y, zy, pixy * cstride + ch);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (EPI == 2) {
-                        const float mu = lbias[64 + cb * 16 + 4 * kq + r], is = lbias[128 + cb * 16 + 4 * kq + r];
-                        const float gx_ = okx ? x[r] : 0.f, gy_ = oky ? y[r] : 0.f;
-                        qs[r] += gx_ + gy_;
-                        qq[r] = fmaf(gx_, (zx[r] - mu) * is, fmaf(gy_, (zy[r] - mu) * is, qq[r]));
-                    } else {
-                        qs[r] += (okx ? Vec<T>::round(x[r]) : 0.f) + (oky ? Vec<T>::round(y[r]) : 0.f);     // bias gradient of what is stored
-                    }
-                }
-            }
-        };
-        auto epilogue_bwd = [&]() {
-            u32x4v zl[NCB][NPB / 2];
-            unsigned pixm[NPB / 2], pixx[NPB / 2], pixy[NPB / 2];
-            bool okm[NPB / 2], okx[NPB / 2], oky[NPB / 2];
-#pragma unroll
-            for (int q = 0; q < NPB / 2; ++q) {
-                int gy0, gx0, gy1, gx1;
-                block_pixel(2 * q, gy0, gx0);
-                block_pixel(2 * q + 1, gy1, gx1);
-                okx[q] = gy0 < a.h && gx0 < a.w; oky[q] = gy1 < a.h && gx1 < a.w;
-                pixx[q] = (unsigned)((n * a.h + gy0) * a.w + gx0); pixy[q] = (unsigned)((n * a.h + gy1) * a.w + gx1);
-                pixm[q] = (kq & 1) ? pixy[q] : pixx[q];
-                okm[q] = (kq & 1) ? oky[q] : okx[q];
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                const int cbase = co0 + cb * 16;
-                const bool xform = !(a.y1 && cbase >= a.csplit);                  // the skip half of a concat gradient is stored as it is
-                const unsigned cstride = a.y1 ? (unsigned)a.csplit : (unsigned)a.cout;
-                const int co = cbase + 8 * (kq >> 1);
-#pragma unroll
-                for (int q = 0; q < NPB / 2; ++q) {
-                    const unsigned off = (xform && okm[q] && co < (int)cstride) ? (pixm[q] * cstride + (unsigned)co) * 2u : OOB;
-                    zl[cb][q] = __builtin_amdgcn_raw_buffer_load_b128(rz, off, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                const bool xform = !(a.y1 && co0 + cb * 16 >= a.csplit);
-                float qs[4], qq[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) qs[r] = qq[r] = 0.f;
-#pragma unroll
-                for (int q = 0; q < NPB / 2; ++q) {
-                    float x[4], y[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        x[r] = acc[cb][2 * q][r]; y[r] = acc[cb][2 * q + 1][r];
-                        acc[cb][2 * q][r] = 0.f; acc[cb][2 * q + 1][r] = 0.f;
-                    }
-                    if constexpr (EPI == 2) {                                       // the gradient itself is stored; the sums use its transform
-                        float gx_[4], gy_[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { gx_[r] = x[r]; gy_[r] = y[r]; }
-                        bwd_pair(cb, gx_, gy_, zl[cb][q], xform, pixx[q], pixy[q], okx[q], oky[q], pixm[q], okm[q], qs, qq);
-                    } else {
-                        bwd_pair(cb, x, y, zl[cb][q], xform, pixx[q], pixy[q], okx[q], oky[q], pixm[q], okm[q], qs, qq);
-                    }
-                    store_pair(cb, x, y, pixm[q], okm[q]);
-                }
-                st_sum[cb] += lane16_channel_sum(qs, i16);
-                if constexpr (EPI == 2) st_sq[cb] += lane16_channel_sum(qq, i16);
-            }
-        };
-        // the same on the 2 x 2 block sums of an UpSampling2D -> conv data gradient (units instead of pixel blocks)
-        auto epilogue_down2_bwd = [&]() {
-            constexpr int NU = NPB / 2;
-            const int hl = a.h >> 1, wl = a.w >> 1;
-            u32x4v zl[NCB][NU / 2];
-            unsigned pixu[NU / 2][2], pixm[NU / 2];
-            bool oku[NU / 2][2], okm[NU / 2];
-#pragma unroll
-            for (int w2 = 0; w2 < NU / 2; ++w2) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int u = 2 * w2 + s2;
-                    const int m = BPR == 2 ? (u >> 1) : u, cx = BPR == 2 ? (u & 1) : 0;
-                    const int gyu = ty0 + row0 + 2 * m, gxu = tx0 + cx * 16 + i16;
-                    oku[w2][s2] = gyu < a.h && gxu < a.w && !(i16 & 1);
-                    pixu[w2][s2] = (unsigned)((n * hl + (gyu >> 1)) * wl + (gxu >> 1));
-                }
-                pixm[w2] = (kq & 1) ? pixu[w2][1] : pixu[w2][0];
-                okm[w2] = (kq & 1) ? oku[w2][1] : oku[w2][0];
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                const int co = co0 + cb * 16 + 8 * (kq >> 1);
-#pragma unroll
-                for (int w2 = 0; w2 < NU / 2; ++w2) {
-                    const unsigned off = (okm[w2] && co < a.cout) ? (pixm[w2] * (unsigned)a.cout + (unsigned)co) * 2u : OOB;
-                    zl[cb][w2] = __builtin_amdgcn_raw_buffer_load_b128(rz, off, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                float qs[4], qq[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) qs[r] = qq[r] = 0.f;
-#pragma unroll
-                for (int w2 = 0; w2 < NU / 2; ++w2) {
-                    float v[2][4];
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const int u = 2 * w2 + s2;
-                        const int m = BPR == 2 ? (u >> 1) : u, cx = BPR == 2 ? (u & 1) : 0;
-                        const int top = (2 * m) * BPR + cx, bot = (2 * m + 1) * BPR + cx;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float t = acc[cb][top][r] + acc[cb][bot][r];
-                            acc[cb][top][r] = 0.f;
-                            acc[cb][bot][r] = 0.f;
-                            v[s2][r] = t + lane_xor1(t);
-                        }
-                    }
-                    if constexpr (EPI == 2) {
-                        float g0[4], g1[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { g0[r] = v[0][r]; g1[r] = v[1][r]; }
-                        bwd_pair(cb, g0, g1, zl[cb][w2], true, pixu[w2][0], pixu[w2][1], oku[w2][0], oku[w2][1], pixm[w2], okm[w2], qs, qq);
-                    } else {
-                        bwd_pair(cb, v[0], v[1], zl[cb][w2], true, pixu[w2][0], pixu[w2][1], oku[w2][0], oku[w2][1], pixm[w2], okm[w2], qs, qq);
-                    }
-                    store_pair(cb, v[0], v[1], pixm[w2], okm[w2]);
-                }
-                st_sum[cb] += lane16_channel_sum(qs, i16);
-                if constexpr (EPI == 2) st_sq[cb] += lane16_channel_sum(qq, i16);
-            }
-        };
-        if constexpr (EPI >= 2) {
-            if (a.down2) epilogue_down2_bwd();
-            else epilogue_bwd();
-        } else {
-            if (a.down2) epilogue_down2_16();
-            else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
-            else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
-            else epilogue([&](float t) { return act_fwd(t, a.act); });
-        }
+        if (a.down2) epilogue_down2_16();
+        else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
+        else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
+        else epilogue([&](float t) { return act_fwd(t, a.act); });
     }
-    if constexpr (RED) {
+    if constexpr (STATS) {
         asm volatile("s_barrier" ::: "memory");                            // every stage has been consumed
         float* lst = reinterpret_cast<float*>(smem);                       // [NCW compute waves][2][BN]
         if (!(i16 & 3)) {                                                  // four lanes hold the same channel
@@ -1304,14 +1106,12 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        constexpr int KR = EPI == 3 ? 1 : 2;                                // rows per workgroup: (sum, second moment) or the bias sums alone
-        const int width = (EPI == 3 && a.y1) ? a.csplit : a.cout;
-        if (tid < KR * BN) {
+        if (tid < 2 * BN) {
             const int k = tid / BN, c = tid % BN;
             float t = 0.f;
 #pragma unroll
             for (int w4 = 0; w4 < NCW; ++w4) t += lst[(w4 * 2 + k) * BN + c];
-            if (co0 + c < width) a.stats[((size_t)blockIdx.x * KR + k) * width + co0 + c] = t;
+            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * 2 + k) * a.cout + co0 + c] = t;
         }
     }
 }
@@ -1319,7 +1119,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
 template <typename T, bool V5, int TW, int NCT, int NPIX, bool STATS, int TAPS, int NCW>
 static constexpr auto igemm_ws_kernel() {
     // (the four-compute-wave 512-pixel tiling holds 128 accumulators per lane: the wider fragment set of v5 would spill there)
-    if constexpr (V5 && sizeof(T) == 2 && NPIX / (32 * NCW) <= 2) return &conv3x3_igemm_ws16<T, TW, NCT, NPIX, STATS ? 1 : 0, TAPS, NCW>;
+    if constexpr (V5 && sizeof(T) == 2 && NPIX / (32 * NCW) <= 2) return &conv3x3_igemm_ws16<T, TW, NCT, NPIX, STATS, TAPS, NCW>;
     else return &conv3x3_igemm_ws<T, TW, NCT, NPIX, STATS, TAPS, NCW>;
 }
 
@@ -1350,31 +1150,17 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
-    constexpr int TAIL = 768;                        // bias [64] + (EPI 2) mean [64] + 1/std [64] of this workgroup's output channels
-    const bool res = 2 * IN_BYTES + nchunks * W_BYTES + TAIL <= LDS_MAX;
+    const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 <= LDS_MAX;
     b.wres = res ? nchunks : 0;
     b.lds_bias_off = 2 * IN_BYTES + (res ? nchunks : 2) * W_BYTES;
-    const int lds = b.lds_bias_off + TAIL;
+    const int lds = b.lds_bias_off + 256;
     if (lds > LDS_MAX) return RVIP_OK;
-    constexpr bool HAS_EPI = V5 && sizeof(T) == 2 && NPIX / (32 * NCW) <= 2 && TAPS == 9;     // the backward epilogues live in the 16x16x32 kernel
-    if (a0.epi >= 2) {
-        if (!HAS_EPI || (!dry && !stats) || !a0.ez || (a0.epi == 2 && (!a0.emean || !a0.einvstd || a0.y1)) || (a0.edrop && !a0.estate)) return RVIP_OK;
-        if (yb >= (1LL << 31)) return RVIP_OK;
-    }
-    b.ez = a0.ez; b.ez_bytes = (unsigned)yb; b.emean = a0.emean; b.einvstd = a0.einvstd; b.eact = a0.eact; b.edrop = a0.edrop; b.elayer = a0.elayer;
-    b.einv_keep = a0.einv_keep; b.ethr = a0.ethr; b.estate = a0.estate;
     static std::atomic<int> attr_lds{0};             // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!dry && lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, false, TAPS, NCW>()),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         if constexpr (TAPS == 9) {
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, true, TAPS, NCW>()),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-        }
-        if constexpr (HAS_EPI) {
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws16<T, TW, NCT, NPIX, 2, TAPS, NCW>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_ws16<T, TW, NCT, NPIX, 3, TAPS, NCW>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         }
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
@@ -1390,12 +1176,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
     if (rows_out) *rows_out = gx;
     if (dry) { used = true; return RVIP_OK; }
-    if (a0.epi >= 2) {
-        if constexpr (HAS_EPI) {
-            if (a0.epi == 2) hipLaunchKernelGGL((conv3x3_igemm_ws16<T, TW, NCT, NPIX, 2, TAPS, NCW>), dim3((unsigned)gx, (unsigned)cot, 1u), dim3((NCW + 4) * 64), lds, s, b);
-            else hipLaunchKernelGGL((conv3x3_igemm_ws16<T, TW, NCT, NPIX, 3, TAPS, NCW>), dim3((unsigned)gx, (unsigned)cot, 1u), dim3((NCW + 4) * 64), lds, s, b);
-        } else return RVIP_EUNSUPPORTED;
-    } else if (stats) {
+    if (stats) {
         if constexpr (TAPS == 9) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, true, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
         else return RVIP_EUNSUPPORTED;
     } else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, false, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
@@ -1801,46 +1582,6 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
     bool used = false;
     hipStream_t s = (hipStream_t)stream;
     rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, s, used, stats_ws, nullptr, false, !a.subpix); });
-    if (rc) return rc;
-    return used ? RVIP_OK : RVIP_EUNSUPPORTED;
-}
-
-// Data gradient with a backward epilogue of its DESTINATION stage (see ConvArgs2): mode 2 = BN-backward reduction rows
-// [rows][2][cout], mode 3 = dz = g * act'(z) stored instead of g, bias-gradient rows [rows][width] (width = csplit for a concat
-// gradient, whose skip half is stored untouched).  16-bit storage types on the 16x16x32 kernel only: *_rows returns 0 otherwise and the
-// caller runs the separate rvip_bn_bwd_reduce / rvip_bn_bwd_apply passes.
-static int epi_args(const rvip_conv3x3_desc* d, const rvip_conv_bwd_epilogue* e, ConvArgs& a) {
-    int rc = conv_args_from_desc(d, a);
-    if (rc) return rc;
-    if (!e || !e->z || (e->mode != RVIP_EPI_BN_REDUCE && e->mode != RVIP_EPI_ACT_BWD)) return RVIP_EINVAL;
-    if (d->bias || d->act != RVIP_ACT_NONE || d->subpix || d->dtype == RVIP_F32) return RVIP_EUNSUPPORTED;
-    if (e->mode == RVIP_EPI_BN_REDUCE && (!e->mean || !e->invstd || d->y1)) return RVIP_EINVAL;
-    if (e->drop_rate < 0.f || e->drop_rate >= 1.f || (e->drop_rate > 0.f && !e->state)) return RVIP_EINVAL;
-    a.epi = e->mode; a.ez = (const unsigned char*)e->z; a.emean = e->mean; a.einvstd = e->invstd; a.eact = e->act;
-    a.edrop = e->drop_rate > 0.f ? 1 : 0; a.elayer = e->layer_id; a.estate = e->state;
-    a.einv_keep = 1.f / (1.f - e->drop_rate); a.ethr = dropout_thr(e->drop_rate);
-    return RVIP_OK;
-}
-
-extern "C" int rvip_conv3x3_dgrad_fused_rows(const rvip_conv3x3_desc* d, const rvip_conv_bwd_epilogue* e) {
-    ConvArgs a;
-    if (epi_args(d, e, a) != RVIP_OK) return 0;
-    bool used = false; int rows = 0;
-    const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, nullptr, &rows, true, true); });
-    return (rc == RVIP_OK && used) ? rows : 0;
-}
-
-extern "C" int rvip_conv3x3_dgrad_fused(const rvip_conv3x3_desc* d, const rvip_conv_bwd_epilogue* e, float* rows_out, size_t rows_bytes, void* stream) {
-    (void)hipGetLastError();
-    ConvArgs a;
-    int rc = epi_args(d, e, a);
-    if (rc) return rc;
-    const int rows = rvip_conv3x3_dgrad_fused_rows(d, e);
-    if (!rows_out || rows <= 0) return RVIP_EUNSUPPORTED;
-    const int width = (e->mode == RVIP_EPI_ACT_BWD && d->y1) ? d->csplit : d->cout;
-    if (rows_bytes < (size_t)rows * (e->mode == RVIP_EPI_BN_REDUCE ? 2 : 1) * width * sizeof(float)) return RVIP_EWORKSPACE;
-    bool used = false;
-    rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, (hipStream_t)stream, used, rows_out, nullptr, false, true); });
     if (rc) return rc;
     return used ? RVIP_OK : RVIP_EUNSUPPORTED;
 }

@@ -1409,14 +1409,6 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     return launch_fold<2, PostBnBwd>(ws, g.nblk, d->c, p, s);
 }
 
-extern "C" int rvip_bn_bwd_finalize(const rvip_bnbwd_desc* d, const float* rows, int nrows, void* stream) {
-    (void)hipGetLastError();
-    if (!d || !rows || nrows <= 0 || d->c <= 0 || d->rows <= 0) return RVIP_EINVAL;
-    if (!d->gamma || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->coef) return RVIP_EINVAL;
-    PostBnBwd p{d->gamma, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef, (double)d->rows, d->c};
-    return launch_fold<2, PostBnBwd>(rows, nrows, d->c, p, (hipStream_t)stream);
-}
-
 extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
     (void)hipGetLastError();
     BnBwdArgs a; RedGeom g;

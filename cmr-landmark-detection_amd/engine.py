@@ -478,13 +478,6 @@ class Engine:
                 bwd.label = 'deferred folds (%s, %d layers)' % ('weight gradients' if is_wide else 'bias gradients', len(entries))
                 bwd.append((L.rvip_fold_rows_batch, (_ptr(tabd), len(entries), C.c_longlong(max(e[3] for e in entries)), is_wide)))
                 del entries[:]
-        # Backward epilogues of the data-gradient convs (rvip_conv3x3_dgrad_fused): the launch that produces the gradient reaching a
-        # stage's output also runs that stage's BN-backward reduction (-> no rvip_bn_bwd_reduce pass over gy and z), or, for a stage
-        # without BN (the up-convs), stores dz = g * act'(z) directly (-> no rvip_bn_bwd_apply pass at all).  16-bit paths only; the
-        # fp32 parity path and runs with injected dropout masks keep the separate kernels.  RVIP_FUSE_BWD_EPI=0 switches it off.
-        by_y = {s_.y: s_ for s_ in plan.stages}
-        fuse_epi = dt != N.F32 and not self.masks and os.environ.get('RVIP_FUSE_BWD_EPI', '1') != '0'
-        fused = {}                             # destination conv name -> (mode, rows tensor, nrows)
         for si, st in reversed(list(enumerate(plan.stages))):
             if si == n_enc - 1:
                 flush_folds()                  # bucket 0 (head, decoder, bottleneck) is complete here
@@ -525,9 +518,7 @@ class Engine:
                     b.mask = self.masks[st.drop[0]].data_ptr()
             b.rows, b.c, b.dtype = rows, st.cout, dt
             b.workspace, b.workspace_bytes = self.ws.data_ptr(), self.ws_bytes
-            if defer and st.conv in fused and fused[st.conv][0] == N.EPI_ACT_BWD:
-                narrow.append((fused[st.conv][1], P.g(st.conv, 'bias'), fused[st.conv][2], st.cout))
-            elif defer:
+            if defer:
                 if st is last and self.fuse_head:
                     nr = L.rvip_bn_bwd_apply_head_rows(C.c_longlong(rows), st.cout, dt, hd['k'])
                 else:
@@ -542,12 +533,8 @@ class Engine:
                 bwd.append((L.rvip_bn_bwd_reduce_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'], P.g(hd['conv'], 'kernel'),
                                                         P.g(hd['conv'], 'bias'))))
                 bwd.append((L.rvip_bn_bwd_apply_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'])))
-            elif st.conv in fused and fused[st.conv][0] == N.EPI_ACT_BWD:
-                pass                           # dz and the bias rows came out of the producing data gradient's epilogue
             else:
-                if st.bn and st.conv in fused:
-                    bwd.append((L.rvip_bn_bwd_finalize, (C.byref(b), _ptr(fused[st.conv][1]), fused[st.conv][2])))
-                elif st.bn:
+                if st.bn:
                     bwd.append((L.rvip_bn_bwd_reduce, (C.byref(b),)))
                 bwd.append((L.rvip_bn_bwd_apply, (C.byref(b),)))
             if first and self.kd == 3:
@@ -592,32 +579,7 @@ class Engine:
             else:
                 dg.y = self.grd[st.src0].data_ptr()
             self._keep.append(dg)
-            dest = by_y.get(st.src0)           # the stage whose output gradient this launch writes (None: network input / pooled tensor)
-            epi_rows = 0
-            if (fuse_epi and dest is not None and not dest.pool and not dest.act_post and (st.up0 == 0 or fuse_down)
-                    and not (dest.bn and st.src1) and (dest.bn or defer)):
-                e = N.ConvBwdEpilogue()
-                e.mode = N.EPI_BN_REDUCE if dest.bn else N.EPI_ACT_BWD
-                e.act, e.z = N.ACT[dest.act_conv], self.act[dest.z].data_ptr()
-                if dest.bn:
-                    e.mean, e.invstd = self._bn(dest, 'mean').value, self._bn(dest, 'invstd').value
-                if dest.drop and dest.drop[1] > 0:
-                    e.drop_rate, e.layer_id, e.state = dest.drop[1], dest.drop[2], state.value
-                y_keep = dg.y
-                if not dest.bn:
-                    dg.y = self.dz[dest.z].data_ptr()      # dz of the destination is written instead of its gy
-                epi_rows = L.rvip_conv3x3_dgrad_fused_rows(C.byref(dg), C.byref(e))
-                if epi_rows > 0:
-                    width = dest.cout
-                    ebuf = torch.empty(epi_rows * (2 if dest.bn else 1) * width, dtype=torch.float32, device=self.ws.device)
-                    self._fold_bufs.append(ebuf)
-                    self._keep.append(e)
-                    fused[dest.conv] = (e.mode, ebuf, epi_rows)
-                    bwd.append((L.rvip_conv3x3_dgrad_fused, (C.byref(dg), C.byref(e), _ptr(ebuf), C.c_size_t(ebuf.numel() * 4))))
-                else:
-                    dg.y = y_keep
-            if epi_rows <= 0:
-                bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
+            bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
             if st.up0 and not fuse_down:    # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions
                 back = L.rvip_upsample2x_bwd if st.up0 == 1 else L.rvip_subsample_odd
                 bwd.append((back, (_ptr(self.up_tmp[st.conv]), _ptr(self.grd[st.src0]), n, st.h // 2, st.w // 2, st.c0, dt)))

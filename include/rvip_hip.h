@@ -110,31 +110,6 @@ int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
 int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d);
 int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_ws, size_t stats_ws_bytes, void* stream);
 
-/* Data gradient (rvip_conv3x3_fwd on dy with the rotated operand: no bias, no activation) with a BACKWARD EPILOGUE of its
- * destination stage, i.e. the stage (conv -> act -> [BN] -> [dropout]) whose output gradient this launch produces.  The reference has
- * no counterpart (TensorFlow autodiff of KerasLayers.py:683-691 / :756-759); it removes one pass over the gradient tensor per stage:
- *   RVIP_EPI_BN_REDUCE  the gradient is stored as usual and the launch also writes the partial rows [rows][2][cout] of the
- *                       BatchNormalization backward reduction (sum g, sum g * (z - mean) * invstd; g = dropout-backward of the stored
- *                       value) that rvip_bn_bwd_reduce would compute in a pass of its own: finish with rvip_bn_bwd_finalize;
- *   RVIP_EPI_ACT_BWD    destination without BN (an up-conv, or BATCH_NORMALISATION off): dz = g * act'(z) is stored INSTEAD of the
- *                       gradient (what rvip_bn_bwd_apply would write) plus bias-gradient rows [rows][width]; with y1 / csplit only
- *                       the first csplit channels are transformed (width = csplit), the skip half is stored untouched.
- * z = the destination stage's stored conv output, same shape as y (half resolution with down2).  16-bit dtypes only:
- * rvip_conv3x3_dgrad_fused_rows returns 0 when the shape / dtype is not served and the caller keeps the separate passes. */
-#define RVIP_EPI_BN_REDUCE 2
-#define RVIP_EPI_ACT_BWD 3
-typedef struct rvip_conv_bwd_epilogue {
-    int32_t      mode;
-    int32_t      act;                       /* RVIP_EPI_ACT_BWD: activation of the destination conv (derivative taken on z) */
-    const void*  z;
-    const float* mean; const float* invstd; /* RVIP_EPI_BN_REDUCE: batch statistics of the destination BN (rvip_bn_stats_finalize) */
-    float        drop_rate;                 /* Dropout of the destination stage, regenerated from the counter stream (0: none) */
-    int32_t      layer_id;
-    const uint32_t* state;
-} rvip_conv_bwd_epilogue;
-int rvip_conv3x3_dgrad_fused_rows(const rvip_conv3x3_desc* d, const rvip_conv_bwd_epilogue* e);
-int rvip_conv3x3_dgrad_fused(const rvip_conv3x3_desc* d, const rvip_conv_bwd_epilogue* e, float* rows, size_t rows_bytes, void* stream);
-
 /* Re-layout the fp32 HWIO master kernel [3][3][Cin][Cout] into the two packed operands:
  *   w_fwd [9][Cout][Cin]  (w_fwd[t][o][i] = W[t][i][o])        -- forward
  *   w_dgrad [9][Cin][Cout] (w_dgrad[t][i][o] = W[8-t][i][o])   -- data gradient (taps rotated 180)
@@ -283,9 +258,6 @@ typedef struct rvip_bnbwd_desc {
     const void*  pool_dpooled; const void* pool_add; int32_t pool_h, pool_w;
 } rvip_bnbwd_desc;
 int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream);
-/* The fold of rvip_bn_bwd_reduce alone, on partial rows [nrows][2][c] produced by rvip_conv3x3_dgrad_fused (RVIP_EPI_BN_REDUCE):
- * writes dgamma, dbeta and the coefficients rvip_bn_bwd_apply reads. */
-int rvip_bn_bwd_finalize(const rvip_bnbwd_desc* d, const float* rows, int nrows, void* stream);
 int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_rows(long long rows, int c, int dtype);
 /* the same count for rvip_bn_bwd_apply_head (its grid is one resident round of workgroups) */

@@ -837,156 +837,3 @@ def test_last_stage_fused_with_head_matches_the_separate_kernels(dtype, act_afte
         sc_ = float(np.abs(down(t0)).max())
         np.testing.assert_allclose(down(t1), down(t0), atol=(2e-3 if dtype != 'f32' else 1e-5) * sc_ + 1e-9, err_msg=nm)
     close(down(out1[0]), down(out0[0]).astype(np.float64), dtype, 'dz fused vs separate')
-
-
-def _fold_rows(rows_t, nrows, k, width):
-    """host fold of partial rows [nrows][k][width] (float64), in row order"""
-    return down(rows_t)[:nrows * k * width].reshape(nrows, k, width).astype(np.float64).sum(0)
-
-
-@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
-@pytest.mark.parametrize('case', [
-    ('plain 32->32 dropout', 2, 40, 72, 32, 32, 0, 0.3),          # 512-px tiles with ragged edges, one channel tile
-    ('plain 64->128', 1, 32, 32, 64, 128, 0, 0.4),                # two 64-channel tile columns, 256-px tiling
-    ('plain 16x16 maps', 3, 16, 16, 40, 72, 0, 0.5),              # TW = 16, channel tail (72 = 64 + 8)
-    ('down2 64->96', 2, 24, 40, 64, 96, 1, 0.0),                  # gradient of an up-sampled input: 2x2 sums, destination at half size
-    ('down2 16-wide', 1, 16, 16, 32, 32, 1, 0.0),
-], ids=lambda c: c[0].replace(' ', '_'))
-def test_dgrad_with_fused_bn_backward_reduction(case, dtype):
-    """rvip_conv3x3_dgrad_fused, RVIP_EPI_BN_REDUCE: the data gradient of a conv co -> ci channels... stores exactly what rvip_conv3x3_fwd
-    stores, and its partial rows, folded by rvip_bn_bwd_finalize, give the dgamma / dbeta / coefficients of rvip_bn_bwd_reduce run
-    on that stored gradient -- the destination stage being conv -> ReLU -> BN -> Dropout (KerasLayers.py:689-691, :718) -- and match the
-    float64 oracle's BN backward."""
-    name, n, h, w, cd, co, down2, rate = case     # cd = channels of the destination stage (= Cin of the forward conv), co = its Cout
-    rng = np.random.default_rng(len(name) + n + h)
-    L = N.lib()
-    wt = rnd(rng.standard_normal((3, 3, cd, co)) * 0.2, dtype)
-    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
-    _, wd = pack(wt, dtype)
-    dyd = up(dy, dtype)
-    hd_, wd_ = (h // 2, w // 2) if down2 else (h, w)
-    rows = n * hd_ * wd_
-    z = rnd(np.maximum(rng.standard_normal((n, hd_, wd_, cd)) * 1.3 + 0.2, 0), dtype)      # destination's stored conv output (post-ReLU)
-    zd = up(z, dtype)
-    gamma = (1 + 0.3 * rng.standard_normal(cd)).astype(np.float32)
-    beta = (0.2 * rng.standard_normal(cd)).astype(np.float32)
-    gd, bd, mm, mv = f32(gamma), f32(beta), f32(np.zeros(cd)), f32(np.ones(cd))
-    wsb = L.rvip_reduce_workspace(rows, 16 * cd)
-    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
-    mean, invstd, scale, shift = (torch.empty(cd, dtype=torch.float32, device=dev()) for _ in range(4))
-    N.call('rvip_bn_train_stats', P(zd), C.c_longlong(rows), cd, ndt(dtype), P(gd), P(bd), P(mm), P(mv), 0.99, 1e-3, 1,
-           P(mean), P(invstd), P(scale), P(shift), P(ws), C.c_size_t(wsb), stream())
-    state = torch.zeros(8, dtype=torch.int32, device=dev())
-    state[2], state[0] = 4242, 5
-    lid = 3
-    # reference: plain data gradient, then the separate reduction
-    g_plain = torch.full((n, hd_, wd_, cd), 9.0, dtype=tdt(dtype), device=dev())
-    d = conv_desc(dyd, co, 0, None, 0, wd, None, g_plain, None, 0, n, h, w, cd, 0, dtype)
-    d.down2 = down2
-    N.call('rvip_conv3x3_fwd', C.byref(d), stream())
-    dgamma, dbeta, dbias = (torch.empty(cd, dtype=torch.float32, device=dev()) for _ in range(3))
-    coef = torch.empty(3 * cd, dtype=torch.float32, device=dev())
-    dz = torch.empty((n, hd_, wd_, cd), dtype=tdt(dtype), device=dev())
-    b = N.BnBwdDesc()
-    b.dy, b.z, b.dz = g_plain.data_ptr(), zd.data_ptr(), dz.data_ptr()
-    b.gamma, b.mean, b.invstd, b.scale, b.shift = gd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
-    b.dgamma, b.dbeta, b.dbias, b.coef = dgamma.data_ptr(), dbeta.data_ptr(), dbias.data_ptr(), coef.data_ptr()
-    b.act, b.act_after_bn = N.ACT['relu'], 0
-    b.drop_rate, b.mask, b.state, b.layer_id = rate, None, state.data_ptr(), lid
-    b.rows, b.c, b.dtype = rows, cd, ndt(dtype)
-    b.workspace, b.workspace_bytes = ws.data_ptr(), wsb
-    N.call('rvip_bn_bwd_reduce', C.byref(b), stream())
-    ref = [down(t).copy() for t in (dgamma, dbeta, coef)]
-    # fused
-    g_fused = torch.full((n, hd_, wd_, cd), 5.0, dtype=tdt(dtype), device=dev())
-    d.y = g_fused.data_ptr()
-    e = N.ConvBwdEpilogue()
-    e.mode, e.act, e.z, e.mean, e.invstd = N.EPI_BN_REDUCE, N.ACT['relu'], zd.data_ptr(), mean.data_ptr(), invstd.data_ptr()
-    e.drop_rate, e.layer_id, e.state = rate, lid, state.data_ptr()
-    nr = L.rvip_conv3x3_dgrad_fused_rows(C.byref(d), C.byref(e))
-    assert nr > 0
-    rbuf = torch.full((nr * 2 * cd + 8,), 77.0, dtype=torch.float32, device=dev())
-    assert L.rvip_conv3x3_dgrad_fused(C.byref(d), C.byref(e), P(rbuf), C.c_size_t(16), stream()) == -3         # RVIP_EWORKSPACE
-    N.call('rvip_conv3x3_dgrad_fused', C.byref(d), C.byref(e), P(rbuf), C.c_size_t(nr * 2 * cd * 4), stream())
-    torch.cuda.synchronize()
-    assert torch.equal(g_fused, g_plain)                               # the stored gradient is the plain launch's, bit for bit
-    for t in (dgamma, dbeta, coef):
-        t.fill_(-3.0)
-    N.call('rvip_bn_bwd_finalize', C.byref(b), P(rbuf), nr, stream())
-    got = [down(t) for t in (dgamma, dbeta, coef)]
-    for gname, g_, r_ in zip(('dgamma', 'dbeta', 'coef'), got, ref):
-        np.testing.assert_allclose(g_, r_, rtol=2e-5, atol=2e-5 * float(np.abs(r_).max()), err_msg=gname)   # summation order only
-    # ... and against the oracle: BN backward of the stored gradient through the host twin of the dropout stream
-    g_in = down(g_plain).astype(np.float64)
-    keep = ds.keep_mask((n, hd_, wd_, cd), rate, 4242, 5, lid).astype(np.float64) if rate > 0 else 1.0
-    g = g_in * keep / (1.0 - rate)
-    _, cache = O.bn_train_fwd(z.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64))
-    _, dgr, dbr = O.bn_train_bwd(g, gamma.astype(np.float64), cache)
-    np.testing.assert_allclose(got[0], dgr, rtol=1e-4, atol=2e-4 * float(np.abs(dgr).max()))
-    np.testing.assert_allclose(got[1], dbr, rtol=1e-4, atol=2e-4 * float(np.abs(dbr).max()))
-    # f32 is not served: the caller keeps the separate kernels
-    d32 = conv_desc(dyd, co, 0, None, 0, wd, None, g_fused, None, 0, n, h, w, cd, 0, 'f32')
-    assert L.rvip_conv3x3_dgrad_fused_rows(C.byref(d32), C.byref(e)) == 0
-
-
-@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
-@pytest.mark.parametrize('case', [
-    ('concat 32+32', 2, 40, 72, 32, 32, 64, 'relu', 0.0),         # one 64-channel tile straddles the split: first half transformed
-    ('concat 64+64', 1, 32, 32, 64, 64, 96, 'elu', 0.0),
-    ('plain no-BN dropout', 2, 24, 40, 32, 0, 64, 'relu', 0.4),   # BATCH_NORMALISATION off: conv -> act -> dropout, whole output transformed
-], ids=lambda c: c[0].replace(' ', '_'))
-def test_dgrad_with_fused_activation_backward(case, dtype):
-    """rvip_conv3x3_dgrad_fused, RVIP_EPI_ACT_BWD: the gradient reaching a stage WITHOUT BatchNormalization (the up-conv of
-    KerasLayers.py:756-759, or any stage when BATCH_NORMALISATION is off) leaves the data gradient's epilogue already multiplied by the
-    dropout mask and act'(z) -- exactly what rvip_conv3x3_fwd + rvip_bn_bwd_apply(no BN) store -- with the bias-gradient rows; the
-    skip half of a concat gradient is stored untouched."""
-    name, n, h, w, c0, c1, co, act, rate = case
-    ci = c0 + c1
-    rng = np.random.default_rng(len(name) + h)
-    L = N.lib()
-    wt = rnd(rng.standard_normal((3, 3, ci, co)) * 0.2, dtype)
-    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
-    _, wd = pack(wt, dtype)
-    dyd = up(dy, dtype)
-    rows = n * h * w
-    pre = rng.standard_normal((n, h, w, c0)) * 1.3
-    z = rnd(O.act_fwd(pre, act), dtype)
-    zd = up(z, dtype)
-    state = torch.zeros(8, dtype=torch.int32, device=dev())
-    state[2], state[0] = 99, 2
-    lid = 7
-    g0 = torch.empty((n, h, w, c0), dtype=tdt(dtype), device=dev())
-    g1 = torch.empty((n, h, w, max(c1, 8)), dtype=tdt(dtype), device=dev()) if c1 else None
-    d = conv_desc(dyd, co, 0, None, 0, wd, None, g0, g1, c0 if c1 else 0, n, h, w, ci, 0, dtype)
-    N.call('rvip_conv3x3_fwd', C.byref(d), stream())
-    wsb = L.rvip_reduce_workspace(rows, 16 * c0)
-    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
-    dz_ref = torch.empty((n, h, w, c0), dtype=tdt(dtype), device=dev())
-    dbias = torch.empty(c0, dtype=torch.float32, device=dev())
-    b = N.BnBwdDesc()
-    b.dy, b.z, b.dz, b.dbias = g0.data_ptr(), zd.data_ptr(), dz_ref.data_ptr(), dbias.data_ptr()
-    b.act, b.act_after_bn = N.ACT[act], 0
-    b.drop_rate, b.mask, b.state, b.layer_id = rate, None, state.data_ptr(), lid
-    b.rows, b.c, b.dtype = rows, c0, ndt(dtype)
-    b.workspace, b.workspace_bytes = ws.data_ptr(), wsb
-    N.call('rvip_bn_bwd_apply', C.byref(b), stream())
-    dz = torch.full((n, h, w, c0), 3.0, dtype=tdt(dtype), device=dev())
-    g1f = torch.full_like(g1, 4.0) if c1 else None
-    d.y, d.y1 = dz.data_ptr(), (g1f.data_ptr() if c1 else None)
-    e = N.ConvBwdEpilogue()
-    e.mode, e.act, e.z = N.EPI_ACT_BWD, N.ACT[act], zd.data_ptr()
-    e.drop_rate, e.layer_id, e.state = rate, lid, state.data_ptr()
-    nr = L.rvip_conv3x3_dgrad_fused_rows(C.byref(d), C.byref(e))
-    assert nr > 0
-    rbuf = torch.full((nr * c0 + 8,), 55.0, dtype=torch.float32, device=dev())
-    N.call('rvip_conv3x3_dgrad_fused', C.byref(d), C.byref(e), P(rbuf), C.c_size_t(nr * c0 * 4), stream())
-    torch.cuda.synchronize()
-    assert torch.equal(dz, dz_ref)
-    if c1:
-        assert torch.equal(g1f, g1)
-    db = _fold_rows(rbuf, nr, 1, c0)[0]
-    np.testing.assert_allclose(db, down(dbias), rtol=2e-5, atol=2e-5 * float(np.abs(down(dbias)).max()))
-    # oracle: dz = dropout-backward(g) * act'(z) on the stored gradient
-    keep = ds.keep_mask((n, h, w, c0), rate, 99, 2, lid).astype(np.float64) if rate > 0 else 1.0
-    want = down(g0).astype(np.float64) * keep / (1.0 - rate) * (np.where(z > 0, 1.0, z + 1.0) if act == 'elu' else (z > 0))
-    close(down(dz), want, dtype, name + ' dz')
