@@ -97,7 +97,6 @@ SIGNATURES = {
     'rvip_conv3x3_wgrad_splits': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
     'rvip_fold_rows_batch': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'rvip_bn_bwd_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
-    'rvip_bn_bwd_pool_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'rvip_bn_bwd_apply_head_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_int]),
     'rvip_conv3x3_c1_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_conv3x3_c1_fwd_stats_rows': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -34,12 +34,11 @@ struct RedGeom {
 
 // cap: most workgroups the kernel keeps RESIDENT (256 CUs x waves/SIMD its register count allows): a grid one quarter larger than
 // that runs a second, mostly empty round
-// split: lanes per row slot (2 for the pooled BN-backward kernels, whose rows are 2x2 windows handled by two lanes each)
-static inline bool red_geom(long long rows, int c, int ve, RedGeom& g, int cap = 1024, int split = 1) {
+static inline bool red_geom(long long rows, int c, int ve, RedGeom& g, int cap = 1024) {
     if (c <= 0 || c % ve || rows <= 0) return false;
     g.cg = c / ve;
-    if (g.cg * split > 256) return false;
-    g.rpi = (256 / split) / g.cg;
+    if (g.cg > 256) return false;
+    g.rpi = 256 / g.cg;
     long long nb = cdiv(rows, (long long)g.rpi * 8);
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
@@ -480,44 +479,35 @@ struct BnBwdArgs {
     const unsigned char* pool_dp; const unsigned char* pool_add; int ph, pw;
 };
 
-// MaxPooling2D backward folded into the BN-backward passes (POOL kernels), column-split like bn_apply_pool2_kernel: the two lanes
-// tid and tid ^ 1 hold the two COLUMNS of the 2x2 window `q` of one channel vector, each its two pixels (rows 0 / 1).  Two pixels per
-// thread keep the register count of the plain kernels (the whole-window-per-thread form of round 1 cost more occupancy than the saved
-// rvip_maxpool2x2_bwd pass).  The first maximum (window order (0,0) (0,1) (1,0) (1,1), strict >: MaxPooling's gradient routing,
-// KerasLayers.py:714,721 autodiff) is found on y = round(act(scale*z + shift)) recomputed exactly as rvip_bn_apply stored it, the other
-// column's two values come over one DPP exchange each: no y tensor and no gy tensor is read.
-//   e0[r], z[r], g[r]: element offset, stored conv output and incoming gradient of this lane's pixel in window row r.
+// The 2x2 window `q` of a pooled stage: element offsets of its four pixels, their z, and the gradient that MaxPooling2D's
+// backward would have written for them.  The first maximum is found on y = round(act(scale*z + shift)), recomputed exactly as
+// the forward pass stored it (bn_apply_kernel: "pool what was stored"), so no y tensor and no gy tensor is read.
 template <typename T, int VE>
-__device__ __forceinline__ void pool_column_grads(const BnBwdArgs& a, long long q, int px, int cbase, const float (&sc)[VE], const float (&sh)[VE],
-                                                  size_t (&e0)[2], float (&z)[2][VE], float (&g)[2][VE]) {
+__device__ __forceinline__ void pool_window_grads(const BnBwdArgs& a, long long q, int cbase, size_t (&e0)[4], float (&z)[4][VE], float (&g)[4][VE]) {
     const int oh = a.ph >> 1, ow = a.pw >> 1;
     int ox, oy; long long img;
     split_xy(q, ow, oh, ox, oy, img);
     float gp[VE];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        e0[r] = (((size_t)img * a.ph + 2 * oy + r) * a.pw + 2 * ox + px) * a.c + cbase;
-        Vec<T>::load(a.z + e0[r] * sizeof(T), z[r]);
-        if (a.pool_add) Vec<T>::load(a.pool_add + e0[r] * sizeof(T), g[r]);
+    for (int k = 0; k < 4; ++k) {
+        e0[k] = (((size_t)img * a.ph + 2 * oy + (k >> 1)) * a.pw + 2 * ox + (k & 1)) * a.c + cbase;
+        Vec<T>::load(a.z + e0[k] * sizeof(T), z[k]);
+        if (a.pool_add) Vec<T>::load(a.pool_add + e0[k] * sizeof(T), g[k]);
     }
     Vec<T>::load(a.pool_dp + ((size_t)q * a.c + cbase) * sizeof(T), gp);
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-        float y[2], o[2];
+        const float sc = a.scale ? a.scale[cbase + e] : 1.f, sh = a.shift ? a.shift[cbase + e] : 0.f;
+        int best = 0; float bv = 0.f;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float t = fmaf(z[r][e], sc[e], sh[e]);
-            if (a.act_after_bn) t = act_fwd(t, a.act);
-            y[r] = Vec<T>::round(t);
-            o[r] = lane_xor1_dpp(y[r]);                               // the other column's pixel of the same row
+        for (int k = 0; k < 4; ++k) {
+            float y = fmaf(z[k][e], sc, sh);
+            if (a.act_after_bn) y = act_fwd(y, a.act);
+            y = Vec<T>::round(y);
+            if (k == 0 || y > bv) { bv = y; best = k; }
         }
-        const float v00 = px ? o[0] : y[0], v01 = px ? y[0] : o[0], v10 = px ? o[1] : y[1], v11 = px ? y[1] : o[1];
-        int best = 0; float bv = v00;
-        if (v01 > bv) { bv = v01; best = 1; }
-        if (v10 > bv) { bv = v10; best = 2; }
-        if (v11 > bv) { best = 3; }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) g[r][e] = (a.pool_add ? g[r][e] : 0.f) + (best == 2 * r + px ? gp[e] : 0.f);
+        for (int k = 0; k < 4; ++k) g[k][e] = (a.pool_add ? g[k][e] : 0.f) + (best == k ? gp[e] : 0.f);
     }
 }
 
@@ -548,7 +538,7 @@ template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
-    const int tid = threadIdx.x, px = POOL ? (tid & 1) : 0, tq = POOL ? (tid >> 1) : tid, cgi = tq % gm.cg, prow = tq / gm.cg;
+    const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
     const bool active = prow < gm.rpi;
     const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
     const uint32_t key = (a.drop && !a.mask) ? dropout_key(a.state[RVIP_STATE_SEED], a.state[RVIP_STATE_STEP], (uint32_t)a.layer_id) : 0u;
@@ -559,22 +549,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom
         mu[e] = active ? a.mean[cgi * VE + e] : 0.f;
         is[e] = active ? a.invstd[cgi * VE + e] : 0.f;
     }
-    if constexpr (POOL) {                       // gm is built on windows: gm.rpi window slots per iteration, two lanes per window
-        float sc[VE], sh[VE];
+    if constexpr (POOL) {                       // rows = 2x2 windows (gm is built on rows / 4)
+        if (active) {
+            const long long nq = a.rows >> 2, q1 = r1 < nq ? r1 : nq;
+            for (long long q = r0 + prow; q < q1; q += gm.rpi) {
+                float z[4][VE], g[4][VE]; size_t e0[4];
+                pool_window_grads<T, VE>(a, q, cgi * VE, e0, z, g);
 #pragma unroll
-        for (int e = 0; e < VE; ++e) { sc[e] = (active && a.scale) ? a.scale[cgi * VE + e] : 1.f; sh[e] = (active && a.shift) ? a.shift[cgi * VE + e] : 0.f; }
-        const long long nq = a.rows >> 2, q1 = r1 < nq ? r1 : nq;
-        for (long long qb = r0; qb < q1; qb += gm.rpi) {          // uniform trip count: the DPP exchange needs both lanes of a pair
-            const long long q = qb + prow;
-            const bool ok = active && q < q1;
-            float z[2][VE], g[2][VE]; size_t e0[2];
-            pool_column_grads<T, VE>(a, ok ? q : r0, px, cgi * VE, sc, sh, e0, z, g);
-            if (!ok) continue;
+                for (int k = 0; k < 4; ++k) {
+                    xform_g<T, VE>(a, e0[k], cgi * VE, key, z[k], g[k]);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                xform_g<T, VE>(a, e0[r], cgi * VE, key, z[r], g[r]);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) { part[0][e] += g[r][e]; part[1][e] = fmaf(g[r][e], (z[r][e] - mu[e]) * is[e], part[1][e]); }
+                    for (int e = 0; e < VE; ++e) { part[0][e] += g[k][e]; part[1][e] = fmaf(g[k][e], (z[k][e] - mu[e]) * is[e], part[1][e]); }
+                }
             }
         }
     } else if (active) {
@@ -596,7 +582,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom
             }
         }
     }
-    block_fold<2, VE>(part, active, (POOL ? 2 * prow + px : prow) * gm.cg + cgi, a.c, POOL ? 2 * gm.rpi : gm.rpi, lds, ws + (size_t)blockIdx.x * 2 * a.c);
+    block_fold<2, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws + (size_t)blockIdx.x * 2 * a.c);
 }
 
 struct PostBnBwd {
@@ -618,7 +604,7 @@ template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
-    const int tid = threadIdx.x, px = POOL ? (tid & 1) : 0, tq = POOL ? (tid >> 1) : tid, cgi = tq % gm.cg, prow = tq / gm.cg;
+    const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
     const bool active = prow < gm.rpi;
     const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
     const uint32_t key = (a.drop && !a.mask) ? dropout_key(a.state[RVIP_STATE_SEED], a.state[RVIP_STATE_STEP], (uint32_t)a.layer_id) : 0u;
@@ -631,29 +617,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
         c2[e] = (a.has_bn && active) ? a.coef[a.c + ch] : 0.f;
         c3[e] = (a.has_bn && active) ? a.coef[2 * a.c + ch] : 0.f;
     }
-    if constexpr (POOL) {                       // gm is built on windows: gm.rpi window slots per iteration, two lanes per window
-        float sc[VE], sh[VE];
+    if constexpr (POOL) {                       // rows = 2x2 windows (gm is built on rows / 4)
+        if (active) {
+            const long long nq = a.rows >> 2, q1 = r1 < nq ? r1 : nq;
+            for (long long q = r0 + prow; q < q1; q += gm.rpi) {
+                float z[4][VE], g[4][VE]; size_t e0[4];
+                pool_window_grads<T, VE>(a, q, cgi * VE, e0, z, g);
 #pragma unroll
-        for (int e = 0; e < VE; ++e) { sc[e] = (active && a.scale) ? a.scale[cgi * VE + e] : 1.f; sh[e] = (active && a.shift) ? a.shift[cgi * VE + e] : 0.f; }
-        const long long nq = a.rows >> 2, q1 = r1 < nq ? r1 : nq;
-        for (long long qb = r0; qb < q1; qb += gm.rpi) {
-            const long long q = qb + prow;
-            const bool ok = active && q < q1;
-            float z[2][VE], g[2][VE]; size_t e0[2];
-            pool_column_grads<T, VE>(a, ok ? q : r0, px, cgi * VE, sc, sh, e0, z, g);
-            if (!ok) continue;
+                for (int k = 0; k < 4; ++k) {
+                    xform_g<T, VE>(a, e0[k], cgi * VE, key, z[k], g[k]);
+                    float d[VE];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                xform_g<T, VE>(a, e0[r], cgi * VE, key, z[r], g[r]);
-                float d[VE];
-#pragma unroll
-                for (int e = 0; e < VE; ++e) {
-                    float t = fmaf(c1[e], g[r][e], fmaf(c2[e], z[r][e], c3[e]));
-                    if (!a.act_after_bn) t *= act_bwd(z[r][e], a.act);
-                    d[e] = t;
-                    part[0][e] += Vec<T>::round(t);
+                    for (int e = 0; e < VE; ++e) {
+                        float t = fmaf(c1[e], g[k][e], fmaf(c2[e], z[k][e], c3[e]));
+                        if (!a.act_after_bn) t *= act_bwd(z[k][e], a.act);
+                        d[e] = t;
+                        part[0][e] += Vec<T>::round(t);
+                    }
+                    Vec<T>::store(a.dz + e0[k] * sizeof(T), d);
                 }
-                Vec<T>::store(a.dz + e0[r] * sizeof(T), d);
             }
         }
     } else if (active) {
@@ -684,7 +666,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
             }
         }
     }
-    block_fold<1, VE>(part, active, (POOL ? 2 * prow + px : prow) * gm.cg + cgi, a.c, POOL ? 2 * gm.rpi : gm.rpi, lds, ws + (size_t)blockIdx.x * a.c);
+    block_fold<1, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws + (size_t)blockIdx.x * a.c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1390,7 +1372,7 @@ static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
         if (d->pool_h <= 0 || d->pool_w <= 0 || ((d->pool_h | d->pool_w) & 1) || d->rows % ((long long)d->pool_h * d->pool_w) || d->drop_rate > 0.f)
             return RVIP_EINVAL;
     }
-    if (!red_geom(pool ? d->rows / 4 : d->rows, d->c, RVIP_VE(d->dtype), g, 1024, pool ? 2 : 1)) return pool ? RVIP_EUNSUPPORTED : RVIP_EINVAL;
+    if (!red_geom(pool ? d->rows / 4 : d->rows, d->c, RVIP_VE(d->dtype), g)) return RVIP_EINVAL;
     if (d->drop_rate < 0.f || d->drop_rate >= 1.f) return RVIP_EINVAL;
     const int drop = d->drop_rate > 0.f;
     if (drop && !d->mask && !d->state) return RVIP_EINVAL;
@@ -1458,12 +1440,7 @@ extern "C" int rvip_bn_bwd_apply_head_rows(long long rows, int c, int dtype, int
     if (!RVIP_DT_OK(dtype) || k <= 0 || !red_geom(rows, c, RVIP_VE(dtype), g, RVIP_APPLY_HEAD_CAP(k))) return 0;
     return g.nblk;
 }
-extern "C" int rvip_bn_bwd_pool_rows(long long windows, int c, int dtype) {      // partial rows of a pool-fused descriptor (0: shape not served)
-    RedGeom g;
-    if (!RVIP_DT_OK(dtype) || !red_geom(windows, c, RVIP_VE(dtype), g, 1024, 2)) return 0;
-    return g.nblk;
-}
-extern "C" int rvip_bn_bwd_rows(long long rows, int c, int dtype) {
+extern "C" int rvip_bn_bwd_rows(long long rows, int c, int dtype) {      // pass rows / 4 for a pool-fused descriptor
     RedGeom g;
     if (!RVIP_DT_OK(dtype) || !red_geom(rows, c, RVIP_VE(dtype), g)) return 0;
     return g.nblk;

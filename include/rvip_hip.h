@@ -260,8 +260,6 @@ typedef struct rvip_bnbwd_desc {
 int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_rows(long long rows, int c, int dtype);
-/* ... of a descriptor with pool_dpooled set (windows = rows / 4; two lanes per 2x2 window); 0: this shape is not served fused */
-int rvip_bn_bwd_pool_rows(long long windows, int c, int dtype);
 /* the same count for rvip_bn_bwd_apply_head (its grid is one resident round of workgroups) */
 int rvip_bn_bwd_apply_head_rows(long long rows, int c, int dtype, int k);
 
