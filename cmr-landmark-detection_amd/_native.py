@@ -71,8 +71,7 @@ class BnBwdDesc(C.Structure):
                 ('rows', C.c_longlong), ('c', C.c_int32),
                 ('dtype', C.c_int32),
                 ('workspace', vp), ('workspace_bytes', C.c_size_t),
-                ('bias_rows', vp), ('bias_rows_bytes', C.c_size_t),
-                ('pool_dpooled', vp), ('pool_add', vp), ('pool_h', C.c_int32), ('pool_w', C.c_int32)]
+                ('bias_rows', vp), ('bias_rows_bytes', C.c_size_t)]
 
 
 class FoldEntry(C.Structure):

@@ -1510,7 +1510,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 
 using namespace rvip;
 
-extern "C" int rvip_abi_version(void) { return 2; }     // 2: descriptors grew (depth taps, down2, subpix, deferred folds, pool fusion)
+extern "C" int rvip_abi_version(void) { return 3; }     // 3: round-2 prune (first-stage recompute entry points, pool-fused BN-backward descriptor fields removed)
 extern "C" const char* rvip_build_info(void) { return "rvip_hip gfx950 wave64 mfma"; }
 extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
 

@@ -474,42 +474,7 @@ struct BnBwdArgs {
     int act, act_after_bn, has_bn;
     float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
     long long rows; int c;
-    // MaxPooling2D backward folded in (POOL kernels): dy is not read; the incoming gradient of pixel p is
-    // pool_add[p] (skip connection, may be NULL) + pool_dp[window(p)] if p is the first maximum of its 2x2 window
-    const unsigned char* pool_dp; const unsigned char* pool_add; int ph, pw;
 };
-
-// The 2x2 window `q` of a pooled stage: element offsets of its four pixels, their z, and the gradient that MaxPooling2D's
-// backward would have written for them.  The first maximum is found on y = round(act(scale*z + shift)), recomputed exactly as
-// the forward pass stored it (bn_apply_kernel: "pool what was stored"), so no y tensor and no gy tensor is read.
-template <typename T, int VE>
-__device__ __forceinline__ void pool_window_grads(const BnBwdArgs& a, long long q, int cbase, size_t (&e0)[4], float (&z)[4][VE], float (&g)[4][VE]) {
-    const int oh = a.ph >> 1, ow = a.pw >> 1;
-    int ox, oy; long long img;
-    split_xy(q, ow, oh, ox, oy, img);
-    float gp[VE];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        e0[k] = (((size_t)img * a.ph + 2 * oy + (k >> 1)) * a.pw + 2 * ox + (k & 1)) * a.c + cbase;
-        Vec<T>::load(a.z + e0[k] * sizeof(T), z[k]);
-        if (a.pool_add) Vec<T>::load(a.pool_add + e0[k] * sizeof(T), g[k]);
-    }
-    Vec<T>::load(a.pool_dp + ((size_t)q * a.c + cbase) * sizeof(T), gp);
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-        const float sc = a.scale ? a.scale[cbase + e] : 1.f, sh = a.shift ? a.shift[cbase + e] : 0.f;
-        int best = 0; float bv = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float y = fmaf(z[k][e], sc, sh);
-            if (a.act_after_bn) y = act_fwd(y, a.act);
-            y = Vec<T>::round(y);
-            if (k == 0 || y > bv) { bv = y; best = k; }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) g[k][e] = (a.pool_add ? g[k][e] : 0.f) + (best == k ? gp[e] : 0.f);
-    }
-}
 
 // g = dL/d(BN-side output before dropout) [times act'(y) when the activation follows BN]
 template <typename T, int VE>
@@ -534,7 +499,7 @@ __device__ __forceinline__ void xform_g(const BnBwdArgs& a, size_t e0, int cbase
     }
 }
 
-template <typename T, bool POOL>
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
@@ -549,21 +514,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom
         mu[e] = active ? a.mean[cgi * VE + e] : 0.f;
         is[e] = active ? a.invstd[cgi * VE + e] : 0.f;
     }
-    if constexpr (POOL) {                       // rows = 2x2 windows (gm is built on rows / 4)
-        if (active) {
-            const long long nq = a.rows >> 2, q1 = r1 < nq ? r1 : nq;
-            for (long long q = r0 + prow; q < q1; q += gm.rpi) {
-                float z[4][VE], g[4][VE]; size_t e0[4];
-                pool_window_grads<T, VE>(a, q, cgi * VE, e0, z, g);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    xform_g<T, VE>(a, e0[k], cgi * VE, key, z[k], g[k]);
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) { part[0][e] += g[k][e]; part[1][e] = fmaf(g[k][e], (z[k][e] - mu[e]) * is[e], part[1][e]); }
-                }
-            }
-        }
-    } else if (active) {
+    if (active) {
         for (long long r = r0 + prow; r < r1; r += RVIP_BWD_U * gm.rpi) {
             float z[RVIP_BWD_U][VE], g[RVIP_BWD_U][VE]; size_t e0[RVIP_BWD_U]; bool ok[RVIP_BWD_U];
 #pragma unroll
@@ -600,7 +551,7 @@ struct PostBnBwd {
     }
 };
 
-template <typename T, bool POOL>
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
@@ -617,28 +568,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
         c2[e] = (a.has_bn && active) ? a.coef[a.c + ch] : 0.f;
         c3[e] = (a.has_bn && active) ? a.coef[2 * a.c + ch] : 0.f;
     }
-    if constexpr (POOL) {                       // rows = 2x2 windows (gm is built on rows / 4)
-        if (active) {
-            const long long nq = a.rows >> 2, q1 = r1 < nq ? r1 : nq;
-            for (long long q = r0 + prow; q < q1; q += gm.rpi) {
-                float z[4][VE], g[4][VE]; size_t e0[4];
-                pool_window_grads<T, VE>(a, q, cgi * VE, e0, z, g);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    xform_g<T, VE>(a, e0[k], cgi * VE, key, z[k], g[k]);
-                    float d[VE];
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) {
-                        float t = fmaf(c1[e], g[k][e], fmaf(c2[e], z[k][e], c3[e]));
-                        if (!a.act_after_bn) t *= act_bwd(z[k][e], a.act);
-                        d[e] = t;
-                        part[0][e] += Vec<T>::round(t);
-                    }
-                    Vec<T>::store(a.dz + e0[k] * sizeof(T), d);
-                }
-            }
-        }
-    } else if (active) {
+    if (active) {
         for (long long r = r0 + prow; r < r1; r += RVIP_BWD_U_APPLY * gm.rpi) {
             float z[RVIP_BWD_U_APPLY][VE], g[RVIP_BWD_U_APPLY][VE]; size_t e0[RVIP_BWD_U_APPLY]; bool ok[RVIP_BWD_U_APPLY];
 #pragma unroll
@@ -1366,13 +1296,8 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
 }
 
 static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
-    if (!d || (!d->dy && !d->pool_dpooled) || !d->z || !RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
-    const bool pool = d->pool_dpooled != nullptr;
-    if (pool) {           // fused MaxPooling2D backward: whole 2x2 windows per thread, no dropout between BN and the pool
-        if (d->pool_h <= 0 || d->pool_w <= 0 || ((d->pool_h | d->pool_w) & 1) || d->rows % ((long long)d->pool_h * d->pool_w) || d->drop_rate > 0.f)
-            return RVIP_EINVAL;
-    }
-    if (!red_geom(pool ? d->rows / 4 : d->rows, d->c, RVIP_VE(d->dtype), g)) return RVIP_EINVAL;
+    if (!d || !d->dy || !d->z || !RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
+    if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g)) return RVIP_EINVAL;
     if (d->drop_rate < 0.f || d->drop_rate >= 1.f) return RVIP_EINVAL;
     const int drop = d->drop_rate > 0.f;
     if (drop && !d->mask && !d->state) return RVIP_EINVAL;
@@ -1383,7 +1308,6 @@ static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
     a.inv_keep = drop ? 1.f / (1.f - d->drop_rate) : 1.f; a.thr = dropout_thr(d->drop_rate);
     a.mask = d->mask; a.state = d->state; a.layer_id = d->layer_id; a.drop = drop;
     a.rows = d->rows; a.c = d->c;
-    a.pool_dp = (const unsigned char*)d->pool_dpooled; a.pool_add = (const unsigned char*)d->pool_add; a.ph = d->pool_h; a.pw = d->pool_w;
     return RVIP_OK;
 }
 
@@ -1396,13 +1320,9 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     if (d->workspace_bytes < (size_t)g.nblk * 2 * d->c * sizeof(float)) return RVIP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)d->workspace;
-    if (a.pool_dp) {
-        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-        else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16_t, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    } else if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16_t, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16_t>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     rc = check_launch();
     if (rc) return rc;
     PostBnBwd p{d->gamma, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef, (double)d->rows, d->c};
@@ -1420,13 +1340,9 @@ extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
     if ((defer ? d->bias_rows_bytes : d->workspace_bytes) < (size_t)g.nblk * d->c * sizeof(float)) return RVIP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* ws = defer ? d->bias_rows : (float*)d->workspace;
-    if (a.pool_dp) {
-        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-        else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16_t, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-        else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    } else if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16_t, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16_t>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
     rc = check_launch();
     if (rc || defer) return rc;
     PostSum p{d->dbias};
@@ -1586,7 +1502,7 @@ extern "C" int rvip_bn_bwd_reduce_head(const rvip_bnbwd_desc* d, const float* he
     a.mean = d->mean; a.invstd = d->invstd; a.scale = d->scale; a.shift = d->shift; a.coef = d->coef;
     a.act = d->act; a.act_after_bn = d->act_after_bn; a.has_bn = 1;
     a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;
-    a.rows = d->rows; a.c = d->c; a.pool_dp = nullptr; a.pool_add = nullptr; a.ph = a.pw = 0;
+    a.rows = d->rows; a.c = d->c;
     hipStream_t s = (hipStream_t)stream;
     float* ws_bn = (float*)d->workspace;
     float* ws_hd = ws_bn + (size_t)g.nblk * 2 * d->c;
@@ -1619,7 +1535,7 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     a.mean = d->mean; a.invstd = d->invstd; a.scale = d->scale; a.shift = d->shift; a.coef = d->coef;
     a.act = d->act; a.act_after_bn = d->act_after_bn; a.has_bn = d->gamma != nullptr;
     a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;
-    a.rows = d->rows; a.c = d->c; a.pool_dp = nullptr; a.pool_add = nullptr; a.ph = a.pw = 0;
+    a.rows = d->rows; a.c = d->c;
     hipStream_t s = (hipStream_t)stream;
     float* ws = defer ? d->bias_rows : (float*)d->workspace;
     HeadFuse hd{head_w, nullptr, dlogit, k};

@@ -486,10 +486,7 @@ class Engine:
             first = st.src0 == 'input_1'
             bwd.label = '%s %dx%dx%d->%d tensor=%.1fMB' % (st.conv, st.h, st.w, st.cin, st.cout, rows * st.cout * esz / 1e6)
             gy, dz, z = self.grd[st.y], self.dz[st.z], self.act[st.z]
-            # MaxPooling2D backward inside the BN-backward passes (no gy tensor): correct (tests) but measured SLOWER on MI355X
-            # (6.66 vs 6.51 ms per step: four pixels per thread cost more occupancy than the saved pass) -> off unless asked for
-            fuse_pool = bool(st.pool) and not (st.drop and st.drop[1] > 0) and os.environ.get('RVIP_FUSE_POOLBWD', '0') == '1'
-            if st.pool and not fuse_pool:
+            if st.pool:
                 add = self.gskip.get(st.y)
                 bwd.append((L.rvip_maxpool2x2_bwd, (_ptr(self.act[st.y]), _ptr(self.grd[st.pooled]),
                                                     _ptr(add) if add is not None else None, _ptr(gy), n, st.h, st.w, st.cout, dt)))
@@ -497,11 +494,6 @@ class Engine:
                 raise NotImplementedError('skip tensor without pooling')
             b = N.BnBwdDesc()
             b.dy, b.z, b.dz = gy.data_ptr(), z.data_ptr(), dz.data_ptr()
-            if fuse_pool:       # MaxPooling2D backward inside the BN-backward passes: gy is never materialised
-                add = self.gskip.get(st.y)
-                b.dy, b.pool_dpooled = None, self.grd[st.pooled].data_ptr()
-                b.pool_add = add.data_ptr() if add is not None else None
-                b.pool_h, b.pool_w = st.h, st.w
             if st.bn:
                 b.gamma = P.p(st.bn, 'gamma').value
                 b.mean, b.invstd = self._bn(st, 'mean').value, self._bn(st, 'invstd').value
@@ -522,7 +514,7 @@ class Engine:
                 if st is last and self.fuse_head:
                     nr = L.rvip_bn_bwd_apply_head_rows(C.c_longlong(rows), st.cout, dt, hd['k'])
                 else:
-                    nr = L.rvip_bn_bwd_rows(C.c_longlong(rows // 4 if fuse_pool else rows), st.cout, dt)
+                    nr = L.rvip_bn_bwd_rows(C.c_longlong(rows), st.cout, dt)
                 rbuf = torch.empty(nr * st.cout, dtype=torch.float32, device=self.ws.device)
                 self._fold_bufs.append(rbuf)
                 b.bias_rows, b.bias_rows_bytes = rbuf.data_ptr(), rbuf.numel() * 4

@@ -250,12 +250,6 @@ typedef struct rvip_bnbwd_desc {
     /* bias_rows != NULL: rvip_bn_bwd_apply leaves the rvip_bn_bwd_rows(rows, c, dtype) partial rows [rows][C] of the
      * bias gradient there instead of folding them into dbias (fold later with rvip_fold_rows_batch, wide = 0). */
     float*       bias_rows; size_t bias_rows_bytes;
-    /* pool_dpooled != NULL: MaxPooling2D backward (KerasLayers.py:721 autodiff) folded into both stages.  dy is not read;
-     * the gradient reaching pixel p of the [N, pool_h, pool_w, C] tensor is pool_add[p] (the skip-connection gradient,
-     * may be NULL) plus pool_dpooled[window(p)] when p is the FIRST maximum of its 2x2 window of y = act(scale*z+shift)
-     * as stored by rvip_bn_apply.  Needs drop_rate == 0, even pool_h / pool_w, rows == N*pool_h*pool_w;
-     * rvip_bn_bwd_rows(rows / 4, ...) gives the partial-row count in this mode. */
-    const void*  pool_dpooled; const void* pool_add; int32_t pool_h, pool_w;
 } rvip_bnbwd_desc;
 int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);

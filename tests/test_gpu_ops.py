@@ -539,74 +539,6 @@ def test_batchnorm_dropout_pool_forward_backward(dtype, act_after):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
-@pytest.mark.parametrize('act_after', [0, 1])
-@pytest.mark.parametrize('with_skip', [0, 1])
-def test_bn_backward_with_fused_maxpool_backward(dtype, act_after, with_skip):
-    """MaxPooling2D backward (first maximum of each 2x2 window of the STORED y, + skip gradient) folded into both
-    BN-backward stages: no gy tensor; argmax recomputed from z exactly as rvip_bn_apply stored y."""
-    n, h, w, c = 3, 12, 20, 16
-    rows = n * h * w
-    rng = np.random.default_rng(8)
-    pre = np.round(rng.standard_normal((n, h, w, c)) * 3) / 2 + 0.25     # coarse values: many ties inside windows
-    z = rnd(pre if act_after else np.maximum(pre, 0), dtype)
-    gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
-    gamma[::5] *= -1                                                     # negative scale: the maximum of y is the minimum of z
-    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
-    L = N.lib()
-    wsb = L.rvip_reduce_workspace(rows, 16 * c)
-    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
-    zd, gd, bd = up(z, dtype), f32(gamma), f32(beta)
-    mm, mv = f32(np.zeros(c)), f32(np.ones(c))
-    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(4))
-    N.call('rvip_bn_train_stats', P(zd), C.c_longlong(rows), c, ndt(dtype), P(gd), P(bd), P(mm), P(mv), 0.99, 1e-3, 1,
-           P(mean), P(invstd), P(scale), P(shift), P(ws), C.c_size_t(wsb), stream())
-    state = torch.zeros(8, dtype=torch.int32, device=dev())
-    y = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
-    pooled = torch.empty((n, h // 2, w // 2, c), dtype=tdt(dtype), device=dev())
-    a = N.ApplyDesc()
-    a.z, a.y, a.pooled = zd.data_ptr(), y.data_ptr(), pooled.data_ptr()
-    a.scale, a.shift, a.act = scale.data_ptr(), shift.data_ptr(), (N.ACT['relu'] if act_after else 0)
-    a.drop_rate, a.mask, a.state, a.layer_id = 0.0, None, state.data_ptr(), 0
-    a.n, a.h, a.w, a.c, a.dtype = n, h, w, c, ndt(dtype)
-    N.call('rvip_bn_apply', C.byref(a), stream())
-    yq = down(y).astype(np.float64)
-    _, idx = O.maxpool2x2_fwd(yq)
-    dp = rnd(rng.standard_normal((n, h // 2, w // 2, c)), dtype)
-    addg = rnd(rng.standard_normal((n, h, w, c)), dtype) if with_skip else None
-    dpd = up(dp, dtype)
-    addd = up(addg, dtype) if with_skip else None
-    dz = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
-    dgamma, dbeta, dbias = (torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(3))
-    coef = torch.empty(3 * c, dtype=torch.float32, device=dev())
-    b = N.BnBwdDesc()
-    b.dy, b.z, b.dz = None, zd.data_ptr(), dz.data_ptr()
-    b.pool_dpooled, b.pool_add, b.pool_h, b.pool_w = dpd.data_ptr(), (addd.data_ptr() if with_skip else None), h, w
-    b.gamma, b.mean, b.invstd = gd.data_ptr(), mean.data_ptr(), invstd.data_ptr()
-    b.scale, b.shift = scale.data_ptr(), shift.data_ptr()
-    b.dgamma, b.dbeta, b.dbias, b.coef = dgamma.data_ptr(), dbeta.data_ptr(), dbias.data_ptr(), coef.data_ptr()
-    b.act, b.act_after_bn = N.ACT['relu'], act_after
-    b.drop_rate, b.mask, b.state, b.layer_id = 0.0, None, state.data_ptr(), 0
-    b.rows, b.c, b.dtype = rows, c, ndt(dtype)
-    b.workspace, b.workspace_bytes = ws.data_ptr(), wsb
-    N.call('rvip_bn_bwd_reduce', C.byref(b), stream())
-    N.call('rvip_bn_bwd_apply', C.byref(b), stream())
-    g = O.maxpool2x2_bwd(dp.astype(np.float64), idx, yq.shape) + (addg if with_skip else 0.0)
-    z64 = z.astype(np.float64)
-    ybn, cache = O.bn_train_fwd(z64, gamma.astype(np.float64), beta.astype(np.float64))
-    if act_after:
-        g = g * (ybn > 0)
-    dxr, dgr, dbr = O.bn_train_bwd(g, gamma.astype(np.float64), cache)
-    dconv = dxr if act_after else dxr * (z64 > 0)
-    tolr = 1e-2 if dtype != 'f32' else 1e-4
-    np.testing.assert_allclose(down(dgamma), dgr, atol=tolr * np.abs(dgr).max())
-    np.testing.assert_allclose(down(dbeta), dbr, atol=tolr * np.abs(dbr).max())
-    close(down(dz), dconv, dtype, 'bn bwd dz with fused pool bwd')
-    np.testing.assert_allclose(down(dbias), rnd(down(dz), dtype).astype(np.float64).sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
-    b.drop_rate = 0.3                                                    # dropout between BN and the pool is not supported in this mode
-    assert L.rvip_bn_bwd_apply(C.byref(b), stream()) == N.EINVAL if hasattr(N, 'EINVAL') else L.rvip_bn_bwd_apply(C.byref(b), stream()) != 0
-
-
-@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('loss', ['mse', 'bce_dice'])
 def test_head_loss_and_backward(dtype, loss):
     n, h, w, cin, k = 3, 16, 24, 16, 2
