@@ -281,6 +281,10 @@ class Model:
         if key not in self._engines:
             import torch
             kind, w_bce, w_dice, _ = self._loss_spec(required=False)
+            if kind == 'bce_dice' and self.plan.mask_classes == 4:
+                # Loss_and_metrics.py:222-224 / :240-242 drop the background channel of a 4-channel output before the loss; the head
+                # kernels sum over every channel, so this case would silently train another objective (the oracle restates it)
+                raise NotImplementedError('bce_dice loss with MASK_CLASSES=4 (background channel sliced off) is not built on the device path')
             masks = None
             if self._dropout_masks:
                 masks = {k: torch.from_numpy(np.ascontiguousarray(v[:batch], np.uint8)).to(P.device)
