@@ -340,6 +340,52 @@ def test_bf16_path_matches_bf16_storage_emulation():
         assert rel < 0.7 * rel_x + 0.02 and rel < 0.25, (lname, rel, rel_x)
 
 
+def test_bf16_path_at_the_real_channel_widths_matches_bf16_storage_emulation():
+    """The same comparison at config 2's channel schedule (F=32, depth 4: 32 ... 512 channels, the (256+256) -> 256 concat conv, the
+    512 -> 256 up-conv, split-K weight gradients with the real slab sizes) on 128 x 128 slices (8 x 8 bottleneck), where the float64 oracle is still
+    affordable: end to end, every kernel variant the benchmark launches takes part except the 256^2-only tile counts."""
+    cfg = _cfg(RVIP_PRECISION='bf16', FILTERS=32, DEPTH=4, DIM=[128, 128])
+    model = rvip.get_model(cfg, metrics=[])
+    _, layers = _oracle_from(model, cfg)
+    params = _oracle_from(model, cfg)[0].params
+    emu = O.OracleUNet(cfg, params, dtype=np.float64, quant=O.bf16_round)
+    exact = O.OracleUNet(cfg, params, dtype=np.float64)
+    B = 4
+    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=5)
+    eng = model._engine(B)
+    eng.load_input(x, y)
+    eng.forward(training=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    masks = _masks(layers, B, model.seed, 0)
+    lv, egrads, epred, _ = emu.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', masks)
+    _, xgrads, xpred, _ = exact.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', masks)
+    pred = eng.pred.cpu().numpy()
+    err_emu, err_exact = np.abs(pred - epred), np.abs(pred - xpred)
+    print('loss dev %.6f emu %.6f; |pred - emu| mean %.2e max %.2e; |pred - exact| mean %.2e max %.2e' % (
+        float(eng.loss.item()), lv, err_emu.mean(), err_emu.max(), err_exact.mean(), err_exact.max()))
+    # (4 x 4 bottleneck at batch 4: BN normalises over 64 values per channel there, which amplifies every 1-ulp bf16 flip)
+    assert abs(float(eng.loss.item()) - lv) < 1e-2 * lv
+    assert err_emu.mean() < 2e-2 and err_emu.max() < 0.3, (err_emu.mean(), err_emu.max())
+    assert err_emu.mean() < 0.8 * err_exact.mean(), (err_emu.mean(), err_exact.mean())
+    got = model._params.grads_host()
+    names = [l['name'] for l in layers if l['type'] == 'Conv2D']
+    rels = {}
+    for lname in names + ['unet']:
+        g = egrads[lname][0]
+        rel = np.linalg.norm(got[(lname, 'kernel')] - g) / np.linalg.norm(g)
+        rel_x = np.linalg.norm(got[(lname, 'kernel')] - xgrads[lname][0]) / np.linalg.norm(xgrads[lname][0])
+        rel_ex = np.linalg.norm(g - xgrads[lname][0]) / np.linalg.norm(xgrads[lname][0])
+        rels[lname] = (round(float(rel), 3), round(float(rel_x), 3), round(float(rel_ex), 3))
+    print('kernel-gradient relative errors (device vs emulation, device vs exact, emulation vs exact):', rels)
+    for lname, (rel, rel_x, rel_ex) in rels.items():
+        # At initialisation the loss gradient is almost common-mode (sigmoid outputs ~0.5 everywhere) and every BN backward cancels that
+        # part, so 8-bit-mantissa storage of the gradient tensors leaves an error as large as the gradient itself in the early layers
+        # (emulation vs exact ~1.0 from conv2d_1 to conv2d_13, 0.03 at the last conv).  What the kernels can be held to: the device
+        # sits closer to the emulation than the emulation's own rounding noise is large, and closer to it than to the exact oracle.
+        assert rel < 0.8 * rel_x + 0.03 and rel < 0.9 * rel_ex + 0.03, (lname, rel, rel_x, rel_ex)
+
+
 def test_full_size_step_is_deterministic_and_finite():
     """BASELINE.json configs[1] shape (256x256, F=32, depth 4, batch 32, bf16): size-independent properties --
     two identical steps from identical state give bit-identical loss, heat-maps and gradients; a further step
