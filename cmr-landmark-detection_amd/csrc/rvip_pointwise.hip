@@ -732,8 +732,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned char* __re
                 const float t = yt[(size_t)r * k + kk];
                 const float d = p - t;
                 s[0] = fmaf(d, d, s[0]);
-                s[1] += fmaxf(zl, 0.f) - zl * t + __logf(1.f + e);
-                s[2] = fmaf(t, p, s[2]); s[3] += t; s[4] += p;
+                if (kk >= k - 3) {           // [..., -3:]: BCE-Dice and dice_coef_labels drop the background channel of a 4-class head
+                    s[1] += fmaxf(zl, 0.f) - zl * t + __logf(1.f + e);
+                    s[2] = fmaf(t, p, s[2]); s[3] += t; s[4] += p;
+                }
                 if (kk == k - 2) { s[5] = fmaf(t, p, s[5]); s[6] += t; s[7] += p; }
                 if (kk == k - 1) { s[8] = fmaf(t, p, s[8]); s[9] += t; s[10] += p; }
             }
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned char* __re
 
 __global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ pred, const float* __restrict__ yt,
                                                         const float* __restrict__ sums, float* __restrict__ dlogit,
-                                                        float* __restrict__ loss_out, long long count, int loss_kind,
+                                                        float* __restrict__ loss_out, long long count, int k, int loss_kind,
                                                         float inv_count, float lg, float w_bce, float w_dice) {
     const long long i = blockIdx.x * 256LL + threadIdx.x;
     const float inter = sums[2], st = sums[3], sp = sums[4];
@@ -770,6 +772,7 @@ __global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict_
     } else {
         const float ddice = (2.f * t * den - (2.f * inter + 1.f)) / (den * den);
         d = w_bce * (p - t) * inv_count - w_dice * lg * ddice * p * (1.f - p);
+        if ((int)(i % k) < k - 3) d = 0.f;       // Loss_and_metrics.py:222-224 / :240-242: the background channel is sliced off
     }
     dlogit[i] = d;
 }
@@ -903,8 +906,10 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
                     const float t = kk == cgi ? tv[u] : yt[(size_t)r * k + kk];
                     const float d = pv - t;
                     s[0] = fmaf(d, d, s[0]);
-                    s[1] += fmaxf(zl, 0.f) - zl * t + __logf(1.f + e_);
-                    s[2] = fmaf(t, pv, s[2]); s[3] += t; s[4] += pv;
+                    if (kk >= k - 3) {
+                        s[1] += fmaxf(zl, 0.f) - zl * t + __logf(1.f + e_);
+                        s[2] = fmaf(t, pv, s[2]); s[3] += t; s[4] += pv;
+                    }
                     if (kk == k - 2) { s[5] = fmaf(t, pv, s[5]); s[6] += t; s[7] += pv; }
                     if (kk == k - 1) { s[8] = fmaf(t, pv, s[8]); s[9] += t; s[10] += pv; }
                 }
@@ -1558,7 +1563,7 @@ extern "C" int rvip_head_grad(const float* pred, const float* y_true, const floa
     if (!pred || !y_true || !sums || !dlogit || rows <= 0 || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
     if (loss_kind != RVIP_LOSS_MSE && loss_kind != RVIP_LOSS_BCE_DICE) return RVIP_EINVAL;
     const long long count = rows * k;
-    hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, pred, y_true, sums, dlogit, loss_out, count, loss_kind, inv_count, local_over_global, w_bce, w_dice);
+    hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, pred, y_true, sums, dlogit, loss_out, count, k, loss_kind, inv_count, local_over_global, w_bce, w_dice);
     return check_launch();
 }
 

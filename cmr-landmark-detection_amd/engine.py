@@ -430,7 +430,10 @@ class Engine:
 
         # ---------------- backward ----------------
         per_rank = float(n * hd['h'] * hd['w'] * hd['k'])
-        self._inv_count = 1.0 / (per_rank * self.world)
+        if self.loss_kind == N.LOSS_BCE_DICE:     # the background channel of a 4-class head is sliced off (Loss_and_metrics.py:240-242)
+            self._inv_count = 1.0 / (float(n * hd['h'] * hd['w'] * min(hd['k'], 3)) * self.world)
+        else:
+            self._inv_count = 1.0 / (per_rank * self.world)
         # f16 activations: the loss gradient 2(p - y) p(1-p) / count is ~1e-7 at the benchmark shapes, below the f16 normal
         # range.  Static loss scaling (the reference has no f16 path; this is the usual mixed-precision recipe): dlogit is
         # multiplied by a power of two ~ count (so |dlogit| <= 0.5), every gradient of the step carries the factor, and the

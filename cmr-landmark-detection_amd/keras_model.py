@@ -281,10 +281,6 @@ class Model:
         if key not in self._engines:
             import torch
             kind, w_bce, w_dice, _ = self._loss_spec(required=False)
-            if kind == 'bce_dice' and self.plan.mask_classes == 4:
-                # Loss_and_metrics.py:222-224 / :240-242 drop the background channel of a 4-channel output before the loss; the head
-                # kernels sum over every channel, so this case would silently train another objective (the oracle restates it)
-                raise NotImplementedError('bce_dice loss with MASK_CLASSES=4 (background channel sliced off) is not built on the device path')
             masks = None
             if self._dropout_masks:
                 masks = {k: torch.from_numpy(np.ascontiguousarray(v[:batch], np.uint8)).to(P.device)
@@ -326,6 +322,13 @@ class Model:
         sl = slice(rank * b, (rank + 1) * b)
         return x[sl], (None if y is None else y[sl])
 
+    @staticmethod
+    def _loss_count(eng, kind, world):
+        """Elements the loss is the mean of over the global batch: every output element for MSE; BCE-Dice slices a 4-class head to
+        its last three channels first (Loss_and_metrics.py:222-224, :240-242)."""
+        k = eng.pred.shape[-1]
+        return float(eng.pred.numel() // k * (min(k, 3) if kind == 'bce_dice' else k) * world)
+
     def _batch_logs(self, eng, kind, w_bce, w_dice):
         import torch
         s = eng.sums
@@ -334,7 +337,7 @@ class Model:
             import torch.distributed as dist
             s = s.clone()
             dist.all_reduce(s)
-        n = float(eng.pred.numel() * world)
+        n = self._loss_count(eng, kind, world)
         dice_all = (2 * s[2] + 1) / (s[3] + s[4] + 1)
         loss = s[0] / n if kind == 'mse' else w_bce * s[1] / n - w_dice * dice_all
         vals = [loss]
@@ -512,7 +515,7 @@ class Model:
                 if world > 1:
                     import torch.distributed as dist
                     dist.all_reduce(hist)
-                vals = self._values_from_sums(hist.cpu().numpy().astype(np.float64), float(eng.pred.numel() * world), kind, w_bce, w_dice)
+                vals = self._values_from_sums(hist.cpu().numpy().astype(np.float64), self._loss_count(eng, kind, world), kind, w_bce, w_dice)
                 for k, val in zip(names, vals.mean(0).tolist()):
                     logs[k] = val
             if validation_data is not None:

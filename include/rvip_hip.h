@@ -275,12 +275,15 @@ int rvip_upsample2x_bwd(const void* dy, void* dx, int n, int h, int w, int c, in
  * (Loss_and_metrics.py:134-171).
  *   rvip_head_fwd:   pred[rows][K] (fp32) = sigmoid(x[rows][Cin] . W[Cin][K] + b); if y_true != NULL
  *                    also folds the loss sums; `sums` (device, 16 floats) receives
- *                    [0] sum (p-t)^2  [1] sum bce  [2] sum t*p  [3] sum t  [4] sum p
+ *                    [0] sum (p-t)^2  [1] sum bce  [2] sum t*p  [3] sum t  [4] sum p   -- [1]..[4] over the LAST THREE
+ *                    channels only (all of them for K <= 3): bce_dice_loss / BceDiceLoss and dice_coef_labels slice
+ *                    [..., -3:] (Loss_and_metrics.py:158-159, :222-224, :240-242), [0] over every channel;
  *                    [5+2k],[6+2k]... per-class sum t*p is not needed by the reference metrics beyond
  *                    the last two channels: [5] sum t*p (ch K-2) [6] sum t (K-2) [7] sum p (K-2)
  *                    [8] sum t*p (ch K-1) [9] sum t (K-1) [10] sum p (K-1)
  *   rvip_head_grad:  dlogit[rows][K] (fp32) from pred, y_true, sums; loss scalar -> loss_out[0]
- *                    (Keras mean reduction with the GLOBAL batch: inv_count = 1/(global_rows*K);
+ *                    (Keras mean reduction with the GLOBAL batch: inv_count = 1/(global_rows*K) for MSE,
+ *                    1/(global_rows*min(K,3)) for BCE-Dice, whose dlogit of a sliced-off background channel is 0;
  *                    local_over_global = local batch / global batch scales the replica-local dice term;
  *                    w_bce/w_dice: 0.5/1 for bce_dice_loss, 1/1 for BceDiceLoss; ignored for MSE).
  *   rvip_head_bwd:   dx[rows][Cin] = dlogit . W^T ; dW[Cin][K], db[K].

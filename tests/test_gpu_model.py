@@ -64,6 +64,7 @@ VARIANTS = [
     dict(BATCH_NORMALISATION=False, ACTIVATION='elu'),
     dict(DEPTH=3, DIM=[48, 40], LOSS_FUNCTION=M.bce_dice_loss),
     dict(LOSS_FUNCTION=M.BceDiceLoss(), FILTERS=12),
+    dict(MASK_CLASSES=4, LOSS_FUNCTION=M.bce_dice_loss),   # 4-class head: loss and dice_coef_labels drop the background channel (Loss_and_metrics.py:240-242, :158-159)
     dict(USE_UPSAMPLE=False),                       # Conv2DTranspose decoder (KerasLayers.py:761-765)
     dict(DEPTH=5, DIM=[64, 64], FILTERS=4, RVIP_PRECISION='fp32'),   # cfg 4's depth (bottleneck 2x2), fp32: F % 4 == 0
     dict(DIM=[4, 32, 32], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32),   # cfg 5's graph (Conv3D, MaxPooling3D, UpSampling3D); 3-D runs on the LDS-DMA kernels only: concat halves must be whole 128-byte rows (F % 32 in fp32)
@@ -96,7 +97,7 @@ def test_fp32_training_steps_match_oracle(variant):
     model = rvip.get_model(cfg, metrics=[M.dice_coef_labels, M.dice_coef_lower, M.dice_coef_upper])
     ref, layers = _oracle_from(model, cfg)
     ref32, _ = _oracle_from(model, cfg, dtype=np.float32)     # conditioning probe: the same graph evaluated in float32
-    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=CLEAN_SEEDS.get(_variant_id(variant), 3))
+    x, y = O.synthetic_batch(B, cfg['DIM'], cfg['MASK_CLASSES'], seed=CLEAN_SEEDS.get(_variant_id(variant), 3))
     x64, y64 = x.astype(np.float64), y.astype(np.float64)
     eng = model._engine(B)
     wname = {0: 'kernel', 1: 'bias'}
@@ -176,7 +177,7 @@ def test_fp32_training_steps_match_oracle(variant):
     torch.cuda.synchronize()
     assert model._params.step_count() == 3
     # inference after training: heat-maps 1e-3, argmax bit-exact, >0.5 masks identical
-    xt, _ = O.synthetic_batch(6, cfg['DIM'], 2, seed=9)
+    xt, _ = O.synthetic_batch(6, cfg['DIM'], cfg['MASK_CLASSES'], seed=9)
     pg = model.predict(xt, batch_size=3)
     pr = ref.predict(xt.astype(np.float64))
     assert pg.dtype == np.float32 and pg.shape == pr.shape
@@ -194,11 +195,12 @@ def test_fp32_training_steps_match_oracle(variant):
         np.testing.assert_allclose(pts[~np.isnan(rp)], rp[~np.isnan(rp)], rtol=1e-6)
 
 
-def test_train_on_batch_logs_and_metrics():
-    cfg = _cfg(LOSS_FUNCTION=M.bce_dice_loss)
+@pytest.mark.parametrize('classes', [2, 4])
+def test_train_on_batch_logs_and_metrics(classes):
+    cfg = _cfg(LOSS_FUNCTION=M.bce_dice_loss, MASK_CLASSES=classes)
     model = rvip.get_model(cfg, metrics=[M.dice_coef_labels, M.dice_coef_lower, M.dice_coef_upper])
     ref, layers = _oracle_from(model, cfg)
-    x, y = O.synthetic_batch(4, cfg['DIM'], 2, seed=4)
+    x, y = O.synthetic_batch(4, cfg['DIM'], classes, seed=4)
     logs = model.train_on_batch(x, y, return_dict=True)
     rpred, cache = ref.forward(x.astype(np.float64), True, _masks(layers, 4, model.seed, 0))
     lv, _ = O.bce_dice_loss(y.astype(np.float64), rpred, logits=cache['logits'])

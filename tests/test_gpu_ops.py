@@ -540,8 +540,9 @@ def test_batchnorm_dropout_pool_forward_backward(dtype, act_after):
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('loss', ['mse', 'bce_dice'])
-def test_head_loss_and_backward(dtype, loss):
-    n, h, w, cin, k = 3, 16, 24, 16, 2
+@pytest.mark.parametrize('k', [2, 4])               # 4: the loss sums [1]..[4] and BCE-Dice drop the background channel (Loss_and_metrics.py:240-242)
+def test_head_loss_and_backward(dtype, loss, k):
+    n, h, w, cin = 3, 16, 24, 16
     rows = n * h * w
     rng = np.random.default_rng(6)
     x = rnd(rng.standard_normal((n, h, w, cin)), dtype)
@@ -562,14 +563,14 @@ def test_head_loss_and_backward(dtype, loss):
     s = down(sums).astype(np.float64)
     t64 = yt.astype(np.float64)
     np.testing.assert_allclose(s[0], ((pref - t64) ** 2).sum(), rtol=1e-4)
-    np.testing.assert_allclose(s[2:5], [(t64 * pref).sum(), t64.sum(), pref.sum()], rtol=1e-4)
+    np.testing.assert_allclose(s[2:5], [(t64[..., -3:] * pref[..., -3:]).sum(), t64[..., -3:].sum(), pref[..., -3:].sum()], rtol=1e-4)
     np.testing.assert_allclose(s[8:11], [(t64[..., -1] * pref[..., -1]).sum(), t64[..., -1].sum(), pref[..., -1].sum()], rtol=1e-4)
     world = 2.0                                                         # pretend 2 ranks: global-batch scaling
     dlogit = torch.empty((n, h, w, k), dtype=torch.float32, device=dev())
     lossd = torch.zeros(1, dtype=torch.float32, device=dev())
     kind = N.LOSS_MSE if loss == 'mse' else N.LOSS_BCE_DICE
     N.call('rvip_head_grad', P(pred), P(ytd), P(sums), P(dlogit), P(lossd), C.c_longlong(rows), k, kind,
-           1.0 / (rows * k * world), 1.0 / world, 0.5, 1.0, stream())
+           1.0 / (rows * (k if loss == 'mse' else min(k, 3)) * world), 1.0 / world, 0.5, 1.0, stream())
     if loss == 'mse':
         lv, dpred = O.mse_loss(t64, pref, global_batch=int(n * world))
         dl_ref = dpred * pref * (1 - pref)
@@ -577,6 +578,8 @@ def test_head_loss_and_backward(dtype, loss):
         lv, dl_ref = O.bce_dice_loss(t64, pref, logits=logits, global_batch=int(n * world))
     np.testing.assert_allclose(float(down(lossd)[0]), lv, rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(down(dlogit), dl_ref, atol=1e-4 * np.abs(dl_ref).max())
+    if loss != 'mse' and k == 4:
+        assert not down(dlogit)[..., 0].any()
     dx = torch.empty((n, h, w, cin), dtype=tdt(dtype), device=dev())
     dw = torch.empty((1, 1, cin, k), dtype=torch.float32, device=dev())
     db = torch.empty(k, dtype=torch.float32, device=dev())
