@@ -103,6 +103,8 @@ SIGNATURES = {
     'rvip_conv3x3_c1_wgrad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'rvip_conv3d_c1_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_conv3d_c1_wgrad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    'rvip_conv3x3_cn_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rvip_conv3x3_cn_wgrad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'rvip_reduce_workspace': (C.c_size_t, [C.c_longlong, C.c_int]),
     'rvip_bn_train_stats': (C.c_int, [vp, C.c_longlong, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int,
                                       vp, vp, vp, vp, vp, C.c_size_t, vp]),

@@ -1400,6 +1400,58 @@ __global__ __launch_bounds__(256) void conv3d_c1_tiled(const T* __restrict__ x, 
     }
 }
 
+// First layer with IMG_CHANNELS = 2..4 (Unets.py:77; the reference's configs all use 1): the halo of every input channel in LDS,
+// the [9][Cin][Cout] kernel in LDS; otherwise as conv3x3_c1_tiled.  x is NHWC [n][h][w][cin].
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_cn_tiled(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, unsigned char* y,
+                                                        int n, int h, int wd, int cin, int cout, int act, int tiles_x, int tiles_y) {
+    constexpr int VE = Vec<T>::VE;
+    __shared__ float xs[4][10 * 34];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    float* ws = reinterpret_cast<float*>(dyn);                  // [9][cin][cout]
+    const int tid = threadIdx.x, cg = cout / VE, cv = tid % cg, ps = tid / cg, pps = 256 / cg;
+    for (int i = tid; i < 9 * cin * cout; i += 256) ws[i] = w[i];
+    float br[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) br[e] = bias ? bias[cv * VE + e] : 0.f;
+    const int ntiles = n * tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int bx = tile;
+        const int tx0 = (bx % tiles_x) * 32; bx /= tiles_x;
+        const int ty0 = (bx % tiles_y) * 8;
+        const long long img = bx / tiles_y;
+        __syncthreads();
+        for (int i = tid; i < cin * 340; i += 256) {
+            const int r = i / cin, ci = i - r * cin;
+            const int gy = ty0 - 1 + r / 34, gx = tx0 - 1 + r % 34;
+            const bool ok = (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)wd;
+            xs[ci][r] = ok ? ld1<T>(x + ((img * h + gy) * wd + gx) * cin + ci) : 0.f;
+        }
+        __syncthreads();
+        if (ps >= pps) continue;                                // 256 % cg != 0: the last threads own no channel vector
+        for (int p = ps; p < 256; p += pps) {
+            const int py = p >> 5, px = p & 31;
+            const int gy = ty0 + py, gx = tx0 + px;
+            if (gy >= h || gx >= wd) continue;
+            float v[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = br[e];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float xv = xs[ci][(py + t / 3) * 34 + px + t % 3];
+                    const float* wt = ws + (t * cin + ci) * cout + cv * VE;
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) v[e] = fmaf(xv, wt[e], v[e]);
+                }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = act_fwd(v[e], act);
+            Vec<T>::store(y + ((((size_t)img * h + gy) * wd + gx) * cout + cv * VE) * sizeof(T), v);
+        }
+    }
+}
+
 // Phase kernels of the sub-pixel form: w_phase[2a+b][2u+v][co][ci] = sum of W[kh][kw][ci][co] over the taps that land on
 // low-resolution offset (u, v) for output phase (a, b): rows a=0: u=0 <- {0}, u=1 <- {1,2}; a=1: u=0 <- {0,1}, u=1 <- {2}
 // (columns alike).  Summed in fp32, rounded once.
@@ -1670,6 +1722,26 @@ extern "C" int rvip_conv3d_c1_fwd(const void* x, const float* w, const float* bi
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(conv3d_c1_tiled<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
     else if (dtype == RVIP_F16) hipLaunchKernelGGL(conv3d_c1_tiled<f16_t>, grid, dim3(256), lds, s, (const f16_t*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
     else hipLaunchKernelGGL(conv3d_c1_tiled<float>, grid, dim3(256), lds, s, (const float*)x, w, bias, (unsigned char*)y, n, depth, h, w_, cout, act, tx, ty);
+    return check_launch();
+}
+
+extern "C" int rvip_conv3x3_cn_fwd(const void* x, const float* w, const float* bias, void* y, int n, int h, int w_, int cin,
+                                   int cout, int act, int dtype, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !w || !y || n <= 0 || h <= 0 || w_ <= 0 || cin < 1 || cin > 4) return RVIP_EINVAL;
+    if (!RVIP_DT_OK(dtype)) return RVIP_EINVAL;
+    const int ve = RVIP_VE(dtype);
+    if (cout <= 0 || cout % ve || cout / ve > 256 || 9 * cin * cout * (int)sizeof(float) > 48 * 1024) return RVIP_EINVAL;
+    const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
+    long long nt = (long long)n * tx * ty;
+    dim3 grid((unsigned)(nt < 4096 ? nt : 4096));
+    const size_t lds = (size_t)9 * cin * cout * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    by_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(conv3x3_cn_tiled<T>, grid, dim3(256), lds, s, (const T*)x, w, bias, (unsigned char*)y, n, h, w_, cin, cout, act, tx, ty);
+        return 0;
+    });
     return check_launch();
 }
 

@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, const unsigned char* __restrict__ dy,
                                                       int n, int h, int w, int cout, int tiles_x, int tiles_y, float* __restrict__ ws,
-                                                      int depth, int dshift) {
+                                                      int depth, int dshift, int xstride, int xoff) {   // x element = pixel * xstride + xoff
     constexpr int VE = Vec<T>::VE;
     __shared__ float xs[10 * 34];
     __shared__ float lds[256 * VE];
@@ -1119,8 +1119,8 @@ __global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, c
             const int gy = ty0 - 1 + i / 34, gx = tx0 - 1 + i % 34;
             float xv = 0.f;
             if (dok && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) {
-                if constexpr (sizeof(T) == 4) xv = x[(ximg * h + gy) * w + gx];
-                else xv = Vec<T>::dec(x[(ximg * h + gy) * w + gx].bits);
+                if constexpr (sizeof(T) == 4) xv = x[((ximg * h + gy) * w + gx) * xstride + xoff];
+                else xv = Vec<T>::dec(x[((ximg * h + gy) * w + gx) * xstride + xoff].bits);
             }
             xs[i] = xv;
         }
@@ -1143,8 +1143,8 @@ __global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, c
 }
 
 struct PostC1Wgrad {
-    float* dw; int cout;
-    __device__ void run_k(int ch, int k, double t) const { dw[k * cout + ch] = (float)t; }
+    float* dw; int cout; int tstride;                          // tap stride of dw: cout for one input channel, cin * cout for HWIO with cin > 1
+    __device__ void run_k(int ch, int k, double t) const { dw[k * tstride + ch] = (float)t; }
 };
 
 // landmark = flat argmax over H*W per (slice, class), first maximum wins; optional > thr mask
@@ -1599,12 +1599,12 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
         long long nt = (long long)n * tx * ty;
         const int nb = (int)(nt < 1024 ? nt : 1024);
         if (workspace_bytes < (size_t)nb * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
-        if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0);
-        else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_tiled<f16_t>, dim3(nb), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0);
-        else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0);
+        if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, 1, 0);
+        else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_tiled<f16_t>, dim3(nb), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, 1, 0);
+        else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, 1, 0);
         int rc2 = check_launch();
         if (rc2) return rc2;
-        PostC1Wgrad p2{dw, cout};
+        PostC1Wgrad p2{dw, cout, cout};
         return launch_fold_k<PostC1Wgrad>(ws, nb, cout, 9, p2, s);
     }
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
@@ -1612,8 +1612,36 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
     else hipLaunchKernelGGL(c1_wgrad_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     int rc = check_launch();
     if (rc) return rc;
-    PostC1Wgrad p{dw, cout};
+    PostC1Wgrad p{dw, cout, cout};
     return launch_fold_k<PostC1Wgrad>(ws, g.nblk, cout, 9, p, s);
+}
+
+// First layer with 2..4 input channels (NHWC x): dw[9][Cin][Cout], one 9-tap pass per input channel
+extern "C" int rvip_conv3x3_cn_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cin, int cout, int dtype,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !dy || !dw || !workspace || !RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w_ <= 0 || cin < 1 || cin > 4) return RVIP_EINVAL;
+    const int ve = RVIP_VE(dtype);
+    if (cout <= 0 || cout % ve || 256 % (cout / ve)) return RVIP_EUNSUPPORTED;
+    const int tx = (int)cdiv(w_, 32), ty = (int)cdiv(h, 8);
+    long long nt = (long long)n * tx * ty;
+    const int nb = (int)(nt < 1024 ? nt : 1024);
+    if (workspace_bytes < (size_t)nb * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    for (int ci = 0; ci < cin; ++ci) {
+        by_dtype(dtype, [&](auto t) {
+            using T = decltype(t);
+            hipLaunchKernelGGL(c1_wgrad_tiled<T>, dim3(nb), dim3(256), 0, s, (const T*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, cin, ci);
+            return 0;
+        });
+        int rc = check_launch();
+        if (rc) return rc;
+        PostC1Wgrad p{dw + (size_t)ci * cout, cout, cin * cout};
+        rc = launch_fold_k<PostC1Wgrad>(ws, nb, cout, 9, p, s);
+        if (rc) return rc;
+    }
+    return RVIP_OK;
 }
 
 // Conv3D first layer (Cin = 1): dw[27][Cout], one 9-tap pass per depth tap with x shifted inside the volume
@@ -1630,12 +1658,12 @@ extern "C" int rvip_conv3d_c1_wgrad(const void* x, const void* dy, float* dw, in
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
     for (int kdi = 0; kdi < 3; ++kdi) {
-        if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1);
-        else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_tiled<f16_t>, dim3(nb), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1);
-        else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1);
+        if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1, 1, 0);
+        else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_tiled<f16_t>, dim3(nb), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1, 1, 0);
+        else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, depth, kdi - 1, 1, 0);
         int rc = check_launch();
         if (rc) return rc;
-        PostC1Wgrad p{dw + (size_t)kdi * 9 * cout, cout};
+        PostC1Wgrad p{dw + (size_t)kdi * 9 * cout, cout, cout};
         rc = launch_fold_k<PostC1Wgrad>(ws, nb, cout, 9, p, s);
         if (rc) return rc;
     }

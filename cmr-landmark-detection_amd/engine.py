@@ -216,8 +216,13 @@ class Engine:
             if st.cout % ve or (st.src0 != 'input_1' and (st.c0 % ve or st.c1 % ve)):
                 raise ValueError('channel counts must be multiples of %d for %s activations (layer %s: %d -> %d)'
                                  % (ve, '16-bit' if ve == 8 else 'f32', st.conv, st.cin, st.cout))
-        if plan.img_channels != 1:
-            raise NotImplementedError('IMG_CHANNELS != 1: the first-layer kernel is the Cin = 1 specialisation')
+        self.cimg = ci = int(plan.img_channels)
+        if ci != 1:
+            # IMG_CHANNELS = 2..4 (Unets.py:77; every config of the reference uses 1): rvip_conv3x3_cn_fwd / _wgrad, separate statistics pass
+            f0 = plan.stages[0].cout
+            cg0 = f0 // ve
+            if not (2 <= ci <= 4) or self.kd != 1 or cg0 & (cg0 - 1) or cg0 > 256 or 9 * ci * f0 * 4 > 48 * 1024:
+                raise NotImplementedError('IMG_CHANNELS = %d: built for 2..4 channels on 2-D graphs with FILTERS / %d a power of two' % (ci, ve))
         dev, T = P.device, P.tdtype
         self.world = world
         self.loss_kind = N.LOSS_MSE if loss_kind == 'mse' else N.LOSS_BCE_DICE
@@ -236,7 +241,7 @@ class Engine:
                 shape[name] = (h, w, c)
             return store[name]
 
-        alloc('input_1', H, W, 1, self.act)
+        alloc('input_1', H, W, self.cimg, self.act)
         skip_names = {st.src1 for st in plan.stages if st.src1}
         for st in plan.stages:
             alloc(st.z, st.h, st.w, st.cout, self.act)
@@ -268,7 +273,7 @@ class Engine:
         self.dlogit = torch.empty((n, H, W, K), **f32)
         self.sums = torch.zeros(16, **f32)
         self.loss = torch.zeros(1, **f32)
-        self.x_stage = torch.empty((n, H, W, 1), **f32)
+        self.x_stage = torch.empty((n, H, W, self.cimg), **f32)
         self.lm_idx = torch.zeros((n, K), dtype=torch.int64, device=dev)
         # per-BN scratch: mean, invstd, scale, shift, coef[3]  -> 7*C floats per stage
         cmax_tot = sum(7 * (-(-st.cout // ALIGN) * ALIGN) for st in plan.stages)
@@ -342,6 +347,9 @@ class Engine:
             if first and self.kd == 3:
                 call = (L.rvip_conv3d_c1_fwd, (_ptr(self.act['input_1']), P.p(st.conv, 'kernel'), bias, _ptr(z),
                                                n, self.depth, st.h, st.w, st.cout, act_conv, dt))
+            elif first and self.cimg > 1:
+                call = (L.rvip_conv3x3_cn_fwd, (_ptr(self.act['input_1']), P.p(st.conv, 'kernel'), bias, _ptr(z),
+                                                n, st.h, st.w, self.cimg, st.cout, act_conv, dt))
             elif first:
                 call = (L.rvip_conv3x3_c1_fwd, (_ptr(self.act['input_1']), P.p(st.conv, 'kernel'), bias, _ptr(z),
                                                 n, st.h, st.w, st.cout, act_conv, dt))
@@ -364,7 +372,7 @@ class Engine:
             fuse_stats = st.bn and os.environ.get('RVIP_FUSE_STATS', '1') != '0'
             if fuse_stats and not first:
                 fused_rows = L.rvip_conv3x3_fwd_stats_rows(C.byref(d))     # > 0: the LDS-DMA igemm folds them in its epilogue
-            elif fuse_stats and self.kd == 1:
+            elif fuse_stats and self.kd == 1 and self.cimg == 1:
                 fused_rows = L.rvip_conv3x3_c1_fwd_stats_rows(n, st.h, st.w, st.cout, dt)       # first layer (Cin = 1), tiled kernel
             if fused_rows > 0:
                 if first:
@@ -535,6 +543,10 @@ class Engine:
             if first and self.kd == 3:
                 bwd.append((L.rvip_conv3d_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, self.depth,
                                                      st.h, st.w, st.cout, dt, _ptr(self.ws_wg), C.c_size_t(self.ws_wg_bytes))))
+                continue
+            if first and self.cimg > 1:
+                bwd.append((L.rvip_conv3x3_cn_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, st.h, st.w,
+                                                      self.cimg, st.cout, dt, _ptr(self.ws_wg), C.c_size_t(self.ws_wg_bytes))))
                 continue
             if first:
                 bwd.append((L.rvip_conv3x3_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, st.h, st.w,

@@ -183,6 +183,13 @@ int rvip_conv3d_c1_fwd(const void* x, const float* w, const float* bias, void* y
                        int n, int depth, int h, int w_, int cout, int act, int dtype, void* stream);
 int rvip_conv3d_c1_wgrad(const void* x, const void* dy, float* dw, int n, int depth, int h, int w_, int cout,
                          int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* The first layer with IMG_CHANNELS = 2..4 (Unets.py:77 `Input((*dim, IMG_CHANNELS))`; every config of the reference uses 1):
+ * x NHWC [n][h][w][cin] in the activation dtype, weights fp32 HWIO [9][cin][Cout] (9 * cin * Cout * 4 <= 48 KiB), no fused
+ * statistics (follow with rvip_bn_train_stats); wgrad writes dw[9][cin][Cout], Cout/VE must divide 256. */
+int rvip_conv3x3_cn_fwd(const void* x, const float* w, const float* bias, void* y,
+                        int n, int h, int w_, int cin, int cout, int act, int dtype, void* stream);
+int rvip_conv3x3_cn_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cin, int cout,
+                          int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-channel reductions use a two-stage deterministic scheme: stage 1 writes one partial row per

@@ -44,6 +44,13 @@ def _masks(layers, batch, seed, step):
     return {l['name']: ds.keep_mask((batch,) + l['shape'], l['rate'], seed, step, i + 1) for i, l in enumerate(drops)}
 
 
+def _batch(B, cfg, seed):
+    """Synthetic (x, y) of the config's shapes; further image channels are further seeded draws."""
+    x, y = O.synthetic_batch(B, cfg['DIM'], cfg['MASK_CLASSES'], seed=seed)
+    extra = [O.synthetic_batch(B, cfg['DIM'], 1, seed=1000 * c + seed)[0] for c in range(1, cfg.get('IMG_CHANNELS', 1))]
+    return (np.concatenate([x] + extra, -1) if extra else x), y
+
+
 def _flat_grads(grads):
     return {(k, i): g for k, gs in grads.items() for i, g in enumerate(gs)}
 
@@ -66,6 +73,7 @@ VARIANTS = [
     dict(LOSS_FUNCTION=M.BceDiceLoss(), FILTERS=12),
     dict(MASK_CLASSES=4, LOSS_FUNCTION=M.bce_dice_loss),   # 4-class head: loss and dice_coef_labels drop the background channel (Loss_and_metrics.py:240-242, :158-159)
     dict(USE_UPSAMPLE=False),                       # Conv2DTranspose decoder (KerasLayers.py:761-765)
+    dict(IMG_CHANNELS=3),                           # Input((*dim, IMG_CHANNELS)), Unets.py:77
     dict(DEPTH=5, DIM=[64, 64], FILTERS=4, RVIP_PRECISION='fp32'),   # cfg 4's depth (bottleneck 2x2), fp32: F % 4 == 0
     dict(DIM=[4, 32, 32], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32),   # cfg 5's graph (Conv3D, MaxPooling3D, UpSampling3D); 3-D runs on the LDS-DMA kernels only: concat halves must be whole 128-byte rows (F % 32 in fp32)
 ]
@@ -97,7 +105,7 @@ def test_fp32_training_steps_match_oracle(variant):
     model = rvip.get_model(cfg, metrics=[M.dice_coef_labels, M.dice_coef_lower, M.dice_coef_upper])
     ref, layers = _oracle_from(model, cfg)
     ref32, _ = _oracle_from(model, cfg, dtype=np.float32)     # conditioning probe: the same graph evaluated in float32
-    x, y = O.synthetic_batch(B, cfg['DIM'], cfg['MASK_CLASSES'], seed=CLEAN_SEEDS.get(_variant_id(variant), 3))
+    x, y = _batch(B, cfg, CLEAN_SEEDS.get(_variant_id(variant), 3))
     x64, y64 = x.astype(np.float64), y.astype(np.float64)
     eng = model._engine(B)
     wname = {0: 'kernel', 1: 'bias'}
@@ -177,7 +185,7 @@ def test_fp32_training_steps_match_oracle(variant):
     torch.cuda.synchronize()
     assert model._params.step_count() == 3
     # inference after training: heat-maps 1e-3, argmax bit-exact, >0.5 masks identical
-    xt, _ = O.synthetic_batch(6, cfg['DIM'], cfg['MASK_CLASSES'], seed=9)
+    xt, _ = _batch(6, cfg, 9)
     pg = model.predict(xt, batch_size=3)
     pr = ref.predict(xt.astype(np.float64))
     assert pg.dtype == np.float32 and pg.shape == pr.shape

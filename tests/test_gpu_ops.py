@@ -191,6 +191,31 @@ def test_conv3d_fwd_dgrad_wgrad(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('ci', [2, 3, 4])
+def test_first_layer_with_several_image_channels(dtype, ci):
+    """IMG_CHANNELS > 1 (Unets.py:77): rvip_conv3x3_cn_fwd / rvip_conv3x3_cn_wgrad against the oracle's conv (ragged tile edges)."""
+    n, h, w, co = 3, 20, 40, 16
+    rng = np.random.default_rng(50 + ci)
+    x = rnd(rng.random((n, h, w, ci)), dtype)
+    wt = (rng.standard_normal((3, 3, ci, co)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
+    xd, dyd, wdv, bd = up(x, dtype), up(dy, dtype), f32(wt), f32(b)
+    y = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    N.call('rvip_conv3x3_cn_fwd', P(xd), P(wdv), P(bd), P(y), n, h, w, ci, co, N.ACT['relu'], ndt(dtype), stream())
+    ref = O.act_fwd(O.conv2d_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), 'relu')
+    close(down(y), ref, dtype, 'cn fwd')
+    L = N.lib()
+    wsb = L.rvip_reduce_workspace(n * h * w, 16 * co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.full((3, 3, ci, co), 7.0, dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_cn_wgrad', P(xd), P(dyd), P(dw), n, h, w, ci, co, ndt(dtype), P(ws), C.c_size_t(wsb), stream())
+    _, rdw, _ = O.conv2d_same_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64))
+    assert np.abs(down(dw) - rdw).max() <= 2e-5 * float(np.abs(rdw).max())
+    assert L.rvip_conv3x3_cn_fwd(P(xd), P(wdv), P(bd), P(y), n, h, w, 5, co, N.ACT['relu'], ndt(dtype), stream()) == -1
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_conv3d_first_layer(dtype):
     nb, dep, h, w, co = 2, 3, 20, 40, 16
     n = nb * dep
