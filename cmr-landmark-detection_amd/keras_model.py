@@ -41,7 +41,31 @@ def _glorot_uniform(rng, shape):
     return rng.uniform(-lim, lim, shape).astype(np.float32)
 
 
+def _variance_scaling(scale, mode, distribution):
+    """Keras VarianceScaling (the named initialisers a KERNEL_INIT string can select, Unets.py:88): fan_in = receptive field x Cin,
+    fan_out = receptive field x Cout; truncated normal (+-2 sigma, sigma corrected by 0.8796...) or uniform(+-sqrt(3 scale / n))."""
+    def init(rng, shape):
+        rf = int(np.prod(shape[:-2]))
+        fan_in, fan_out = rf * shape[-2], rf * shape[-1]
+        n = {'fan_in': fan_in, 'fan_out': fan_out, 'fan_avg': 0.5 * (fan_in + fan_out)}[mode]
+        if distribution == 'uniform':
+            lim = math.sqrt(3.0 * scale / n)
+            return rng.uniform(-lim, lim, shape).astype(np.float32)
+        std = math.sqrt(scale / n) / 0.87962566103423978
+        a = rng.standard_normal(shape)
+        bad = np.abs(a) > 2.0
+        while bad.any():
+            a[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(a) > 2.0
+        return (a * std).astype(np.float32)
+    return init
+
+
 _INIT = {'he_normal': _he_normal, 'glorot_uniform': _glorot_uniform,
+         'he_uniform': _variance_scaling(2.0, 'fan_in', 'uniform'), 'glorot_normal': _variance_scaling(1.0, 'fan_avg', 'normal'),
+         'lecun_normal': _variance_scaling(1.0, 'fan_in', 'normal'), 'lecun_uniform': _variance_scaling(1.0, 'fan_in', 'uniform'),
+         'random_normal': lambda rng, s: (0.05 * rng.standard_normal(s)).astype(np.float32),
+         'random_uniform': lambda rng, s: rng.uniform(-0.05, 0.05, s).astype(np.float32),
          'zeros': lambda rng, s: np.zeros(s, np.float32), 'ones': lambda rng, s: np.ones(s, np.float32)}
 
 

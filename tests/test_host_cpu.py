@@ -68,6 +68,20 @@ def test_config_defaults_and_quirks():
     assert float(opt.lr) == 1e-4 and (opt.beta_1, opt.beta_2, opt.epsilon) == (0.9, 0.999, 1e-7)
     opt.lr = 5e-5
     assert float(opt.lr) == 5e-5
+    # KERNEL_INIT names Keras resolves (Unets.py:88): variance and range of the VarianceScaling family
+    for name, (scale, mode, dist_) in dict(he_normal=(2.0, 'fan_in', 'normal'), he_uniform=(2.0, 'fan_in', 'uniform'),
+                                           glorot_normal=(1.0, 'fan_avg', 'normal'), lecun_uniform=(1.0, 'fan_in', 'uniform')).items():
+        m = rvip.create_unet(_cfg(KERNEL_INIT=name, FILTERS=16))
+        w = m.get_layer_weights('conv2d_1')[0] if hasattr(m, 'get_layer_weights') else m._weights[[s[:2] for s in m.plan.weight_specs()].index(('conv2d_1', 'kernel'))]
+        fan_in, fan_out = 9 * w.shape[-2], 9 * w.shape[-1]
+        n = dict(fan_in=fan_in, fan_avg=0.5 * (fan_in + fan_out))[mode]
+        assert abs(w.var() * n / scale - 1.0) < 0.12, (name, w.var() * n / scale)
+        if dist_ == 'uniform':
+            assert np.abs(w).max() <= np.sqrt(3.0 * scale / n) + 1e-7
+        else:
+            assert np.abs(w).max() <= 2.0 * np.sqrt(scale / n) / 0.87962566103423978 + 1e-7
+    with pytest.raises(NotImplementedError):
+        rvip.create_unet(_cfg(KERNEL_INIT='orthogonal'))
 
 
 def test_flops_and_bytes_match_baseline_table():
