@@ -2,7 +2,7 @@
 the 256x256 4-level U-Net with 2 heat-maps, bf16 activations / fp32 accumulate, batch 32 per GPU
 (BASELINE.json configs[1]; configs[2] = the same per GPU on N GPUs, weak scaling).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20          (the defaults)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
            bench.py --gpus N --steps K --warmup W
 
@@ -47,8 +47,8 @@ def workload_key(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200, help='timed steps (default: ~1.1 s of device time at cfg 2)')
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=32, help='slices per GPU (BASELINE.json: 32)')
     ap.add_argument('--dim', type=int, default=256)
     ap.add_argument('--filters', type=int, default=32, help='base filters (BASELINE.json headline: 32; cfg 4: 64)')
