@@ -580,6 +580,52 @@ def test_fit_with_generator_and_callbacks(tmp_path):
     assert m2.predict(xb).shape == (8, 64, 64, 2)
 
 
+class _MarkedSlices(rvip.Generators.SyntheticSAXGenerator):
+    """A task the network can learn: the two landmarks of a slice are where the image carries a bright and a dark disc."""
+
+    def _slice(self, rng, h, w):
+        img, mask = super()._slice(rng, h, w)
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = 0.5 * img[..., 0]
+        for c, sign in ((0, 1.0), (1, -1.0)):
+            cy, cx = np.unravel_index(int(mask[..., c].argmax()), (h, w))
+            img = img + sign * 0.5 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 3.0 ** 2))
+        img = (img - img.min()) / (img.max() - img.min())
+        return img[..., None].astype(np.float32), mask
+
+
+@pytest.mark.parametrize('precision,loss,extra', [
+    ('bf16', 'mse', dict(DROPOUT_MIN=0.1, DROPOUT_MAX=0.1)),
+    ('fp16', 'bce_dice_loss', {}),                                   # default dropout schedule 0.3 .. 0.5 (Unets.py:105-106)
+    ('bf16', 'BceDiceLoss', {}),                                     # the class form (sum-reduction gradient)
+], ids=['bf16-mse', 'fp16-bce_dice', 'bf16-BceDiceLoss'])
+def test_fit_learns_a_landmark_task_end_to_end(tmp_path, precision, loss, extra):
+    """The whole product path on a learnable task: generator -> Model.fit (captured step, pinned input ring) with the reference's
+    callback list -> best-only model.h5 -> a fresh model restores it -> predict -> landmarks.  The held-out landmarks must be
+    found (tools/diag_learn.py: median error 0 px with BCE-Dice, 1.0-1.4 px with MSE after 30 epochs of 30 steps)."""
+    lf = dict(mse=M.mse, bce_dice_loss=M.bce_dice_loss, BceDiceLoss=M.BceDiceLoss())[loss]
+    cfg = _cfg(RVIP_PRECISION=precision, DIM=[64, 64], FILTERS=8, DEPTH=3, LEARNING_RATE=3e-3, MODEL_PATH=str(tmp_path), SEED=5,
+               LOSS_FUNCTION=lf, **extra)
+    gcfg = dict(DIM=[64, 64], BATCHSIZE=16, GAUS=True, SIGMA=2, SHUFFLE=True, SEED=7)
+    train = _MarkedSlices(480, gcfg, in_memory=True)
+    val = _MarkedSlices(64, dict(gcfg, SHUFFLE=False, SEED=8), in_memory=True)
+    model = rvip.get_model(cfg, metrics=[])
+    hist = model.fit(x=train, validation_data=val, epochs=30, callbacks=rvip.KerasCallbacks.get_callbacks(cfg, train, val), verbose=0, workers=2)
+    h = hist.history
+    assert np.isfinite(h['loss']).all() and h['loss'][-1] < h['loss'][0] and h['val_loss'][-1] < h['val_loss'][0], h
+    assert model._engine(16).launch_mode == 'hipGraph'
+    best = rvip.get_model(cfg)
+    best.load_weights(str(tmp_path / 'model.h5'))
+    err = []
+    for i in range(len(val)):
+        xb, yb = val[i]
+        idx, _ = best.predict_landmarks(xb)
+        ti = yb.reshape(yb.shape[0], -1, 2).argmax(1)
+        err.append(np.hypot(idx // 64 - ti // 64, idx % 64 - ti % 64))
+    err = np.concatenate(err).ravel()
+    assert np.median(err) <= (1.5 if loss == 'mse' else 1.0) and (err <= 2.0).mean() >= 0.9, (np.median(err), (err <= 2.0).mean())
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_graph_replay_equals_eager_launches(precision, monkeypatch):
     """Engine.train_step: step 1 eager, step 2 captures, steps 3.. replay.  The replayed step must be the eager step bit for bit
