@@ -21,6 +21,16 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_
 __device__ __forceinline__ float f16_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
 __device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // RNE, overflow -> inf
 
+// two fp32 -> one packed 32-bit word (lo = a, hi = b), RNE: ONE v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32.  Converting the halves one by
+// one and OR-ing them (the obvious form) is four instructions on gfx950: cvt, cvt, shift, or.
+typedef float rvip_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rvip_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 rvip_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+    const rvip_f32x2 v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rvip_bf16x2)); }
+__device__ __forceinline__ uint32_t pack2_f16(float a, float b) {
+    const rvip_f32x2 v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rvip_f16x2)); }
+
 // 16-byte channel vector: VE elements of T
 typedef unsigned rvip_u32x4 __attribute__((ext_vector_type(4)));
 typedef float rvip_f32x4 __attribute__((ext_vector_type(4)));
@@ -51,10 +61,13 @@ template <> struct Vec<bf16_t> {
     __device__ static __forceinline__ void store(void* p, const float (&v)[8]) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack2_bf16(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]); }
     __device__ static __forceinline__ float round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
     __device__ static __forceinline__ uint16_t enc(float x) { return f32_to_bf16(x); }
+    __device__ static __forceinline__ uint32_t pack2(float a, float b) { return pack2_bf16(a, b); }
+    __device__ static __forceinline__ float lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }           // halves of a packed word, widened
+    __device__ static __forceinline__ float hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
     __device__ static __forceinline__ float dec(uint16_t b) { return bf16_to_f32(b); }
 };
 template <> struct Vec<f16_t> {
@@ -73,10 +86,13 @@ template <> struct Vec<f16_t> {
     __device__ static __forceinline__ void store(void* p, const float (&v)[8]) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_f16(v[2 * i]) | ((uint32_t)f32_to_f16(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack2_f16(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]); }
     __device__ static __forceinline__ float round(float x) { return f16_to_f32(f32_to_f16(x)); }
     __device__ static __forceinline__ uint16_t enc(float x) { return f32_to_f16(x); }
+    __device__ static __forceinline__ uint32_t pack2(float a, float b) { return pack2_f16(a, b); }
+    __device__ static __forceinline__ float lo(uint32_t p) { return (float)__builtin_bit_cast(rvip_f16x2, p)[0]; }
+    __device__ static __forceinline__ float hi(uint32_t p) { return (float)__builtin_bit_cast(rvip_f16x2, p)[1]; }
     __device__ static __forceinline__ float dec(uint16_t b) { return f16_to_f32(b); }
 };
 // MFMA on eight 16-bit K elements per lane (one uint4 fragment of each operand)

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(ConvArgs a) {
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     uint2 o;
-                    o.x = (uint32_t)Vec<T>::enc(v[0]) | ((uint32_t)Vec<T>::enc(v[1]) << 16);
-                    o.y = (uint32_t)Vec<T>::enc(v[2]) | ((uint32_t)Vec<T>::enc(v[3]) << 16);
+                    o.x = Vec<T>::pack2(v[0], v[1]);
+                    o.y = Vec<T>::pack2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(dst) = o;
                 }
             }
@@ -327,10 +327,10 @@ __device__ __forceinline__ void epilogue_down2(f32x16 (&acc)[NCT][NPT], int pbas
             } else {
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
-                    unsigned ax = (uint32_t)Vec<T>::enc(v[8 * qq + 0]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 1]) << 16);
-                    unsigned ay = (uint32_t)Vec<T>::enc(v[8 * qq + 2]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 3]) << 16);
-                    unsigned bxx = (uint32_t)Vec<T>::enc(v[8 * qq + 4]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 5]) << 16);
-                    unsigned byy = (uint32_t)Vec<T>::enc(v[8 * qq + 6]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 7]) << 16);
+                    unsigned ax = Vec<T>::pack2(v[8 * qq + 0], v[8 * qq + 1]);
+                    unsigned ay = Vec<T>::pack2(v[8 * qq + 2], v[8 * qq + 3]);
+                    unsigned bxx = Vec<T>::pack2(v[8 * qq + 4], v[8 * qq + 5]);
+                    unsigned byy = Vec<T>::pack2(v[8 * qq + 6], v[8 * qq + 7]);
                     auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
                     auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
                     const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
@@ -638,10 +638,10 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
             } else {
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
-                    unsigned ax = (uint32_t)Vec<T>::enc(v[8 * qq + 0]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 1]) << 16);
-                    unsigned ay = (uint32_t)Vec<T>::enc(v[8 * qq + 2]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 3]) << 16);
-                    unsigned bxx = (uint32_t)Vec<T>::enc(v[8 * qq + 4]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 5]) << 16);
-                    unsigned byy = (uint32_t)Vec<T>::enc(v[8 * qq + 6]) | ((uint32_t)Vec<T>::enc(v[8 * qq + 7]) << 16);
+                    unsigned ax = Vec<T>::pack2(v[8 * qq + 0], v[8 * qq + 1]);
+                    unsigned ay = Vec<T>::pack2(v[8 * qq + 2], v[8 * qq + 3]);
+                    unsigned bxx = Vec<T>::pack2(v[8 * qq + 4], v[8 * qq + 5]);
+                    unsigned byy = Vec<T>::pack2(v[8 * qq + 6], v[8 * qq + 7]);
                     auto r0s = __builtin_amdgcn_permlane32_swap(ax, bxx, false, false);
                     auto r1s = __builtin_amdgcn_permlane32_swap(ay, byy, false, false);
                     const u32x4v dta = {r0s[0], r1s[0], r0s[1], r1s[1]};
@@ -778,8 +778,6 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     const bool resident = a.wres > 0;
     const int first_tile = blockIdx.x;
     if (first_tile >= a.ntiles) return;
-    float* lbias = reinterpret_cast<float*>(smem + a.lds_bias_off);        // [BN] bias of this output-channel tile
-    if (tid < BN) lbias[tid] = (a.bias && co0 + tid < a.cout) ? a.bias[co0 + tid] : 0.f;
 
     if (wv >= NCW) {
         // ------------------------------------------------ loader waves ------------------------------------------------
@@ -941,11 +939,20 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
         in_base[tx] = (row0 * HWD + hx) * 64 + ((kq ^ slot_swz(hx)) << 4);
     }
     const int w_addr = i16 * 64 + ((kq ^ slot_swz(i16)) << 4);
+    // The accumulators START at the bias (and return to it in the epilogue) instead of having it added to every value there: the
+    // epilogue is VALU-issue bound (two waves per SIMD), every instruction it loses shortens the tile.  Zero for the 2x2-sum form.
+    f32x4 bias_r[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int c = co0 + cb * 16 + 4 * kq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_r[cb][r] = (a.bias && !a.down2 && c + r < a.cout) ? a.bias[c + r] : 0.f;
+    }
     f32x4 acc[NCB][NPB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int p = 0; p < NPB; ++p) acc[cb][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < NPB; ++p) acc[cb][p] = bias_r[cb];
     // fused BatchNormalization statistics: lane (kq, i16) ends up with the sums of channel 4 kq + 2 bit3(i16) + bit2(i16) of every
     // 16-channel block over the wave's pixels (lane16_channel_sum), two registers per block
     float st_sum[NCB], st_sq[NCB];
@@ -996,13 +1003,12 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
         // ---- epilogue of this tile; compute waves never wait on their stores ----
         // Two pixel blocks (X, Y) of one channel block at a time: after v_permlane16_swap of the packed pairs a lane with even kq
         // holds 8 consecutive channels of X's pixel, a lane with odd kq those of Y's pixel -> one 16-byte store per lane.
-        auto store_pair = [&](int cb, const float (&x)[4], const float (&y)[4], unsigned pix, bool pix_ok) __attribute__((always_inline)) {
+        // x0, x1 / y0, y1: the four channels of pixel block X / Y, packed (Vec<T>::pack2)
+        auto store_pair = [&](int cb, unsigned x0, unsigned x1, unsigned y0, unsigned y1, unsigned pix, bool pix_ok) __attribute__((always_inline)) {
             const int cbase = co0 + cb * 16;                                   // wave-uniform
             const bool second = a.y1 && cbase >= a.csplit;                     // csplit % 32 == 0 (host)
             const int cstride = a.y1 ? (second ? a.cout - a.csplit : a.csplit) : a.cout;
             const int cshift = second ? a.csplit : 0;
-            const unsigned x0 = (uint32_t)Vec<T>::enc(x[0]) | ((uint32_t)Vec<T>::enc(x[1]) << 16), x1 = (uint32_t)Vec<T>::enc(x[2]) | ((uint32_t)Vec<T>::enc(x[3]) << 16);
-            const unsigned y0 = (uint32_t)Vec<T>::enc(y[0]) | ((uint32_t)Vec<T>::enc(y[1]) << 16), y1 = (uint32_t)Vec<T>::enc(y[2]) | ((uint32_t)Vec<T>::enc(y[3]) << 16);
             auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
             auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
             const u32x4v dta = {s0[0], s1[0], s0[1], s1[1]};
@@ -1030,13 +1036,19 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                     float x[4], y[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float bias = lbias[cb * 16 + 4 * kq + r];
-                        x[r] = actf(acc[cb][2 * q][r] + bias);
-                        y[r] = actf(acc[cb][2 * q + 1][r] + bias);
-                        acc[cb][2 * q][r] = 0.f;
-                        acc[cb][2 * q + 1][r] = 0.f;
-                        if constexpr (STATS) {                                  // statistics of what is stored
-                            const float u0 = ok0 ? Vec<T>::round(x[r]) : 0.f, u1 = ok1 ? Vec<T>::round(y[r]) : 0.f;
+                        x[r] = actf(acc[cb][2 * q][r]);
+                        y[r] = actf(acc[cb][2 * q + 1][r]);
+                        acc[cb][2 * q][r] = bias_r[cb][r];
+                        acc[cb][2 * q + 1][r] = bias_r[cb][r];
+                    }
+                    const unsigned x0 = Vec<T>::pack2(x[0], x[1]), x1 = Vec<T>::pack2(x[2], x[3]);
+                    const unsigned y0 = Vec<T>::pack2(y[0], y[1]), y1 = Vec<T>::pack2(y[2], y[3]);
+                    if constexpr (STATS) {                                      // statistics of what is stored: the packed words, widened
+                        const float ux[4] = {Vec<T>::lo(x0), Vec<T>::hi(x0), Vec<T>::lo(x1), Vec<T>::hi(x1)};
+                        const float uy[4] = {Vec<T>::lo(y0), Vec<T>::hi(y0), Vec<T>::lo(y1), Vec<T>::hi(y1)};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float u0 = ok0 ? ux[r] : 0.f, u1 = ok1 ? uy[r] : 0.f;
                             qs[r] += u0 + u1;
                             qq[r] = fmaf(u0, u0, fmaf(u1, u1, qq[r]));
                         }
@@ -1046,7 +1058,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                     const bool okm = (kq & 1) ? ok1 : ok0;
                     const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gym + pa) * 2 * a.w + 2 * gxm + pb)
                                                    : (unsigned)((n * a.h + gym) * a.w + gxm);
-                    store_pair(cb, x, y, pix, okm);
+                    store_pair(cb, x0, x1, y0, y1, pix, okm);
                 }
                 if constexpr (STATS) {
                     st_sum[cb] += lane16_channel_sum(qs, i16);
@@ -1084,7 +1096,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                     const int gym = (kq & 1) ? gyu[1] : gyu[0], gxm = (kq & 1) ? gxu[1] : gxu[0];
                     const bool keep = gym < a.h && gxm < a.w && !(i16 & 1);
                     const unsigned pix = (unsigned)((n * hl + (gym >> 1)) * wl + (gxm >> 1));
-                    store_pair(cb, v[0], v[1], pix, keep);
+                    store_pair(cb, Vec<T>::pack2(v[0][0], v[0][1]), Vec<T>::pack2(v[0][2], v[0][3]), Vec<T>::pack2(v[1][0], v[1][1]),
+                               Vec<T>::pack2(v[1][2], v[1][3]), pix, keep);
                 }
             }
         };
@@ -1520,8 +1533,8 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
                 if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = v;
                 else {
                     uint2 pk;
-                    pk.x = (uint32_t)Vec<T>::enc(v.x) | ((uint32_t)Vec<T>::enc(v.y) << 16);
-                    pk.y = (uint32_t)Vec<T>::enc(v.z) | ((uint32_t)Vec<T>::enc(v.w) << 16);
+                    pk.x = Vec<T>::pack2(v.x, v.y);
+                    pk.y = Vec<T>::pack2(v.z, v.w);
                     *reinterpret_cast<uint2*>(dst) = pk;
                 }
             }
@@ -1544,10 +1557,10 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
                 *reinterpret_cast<float4*>(dst + 4) = float4{v[4], v[5], v[6], v[7]};
             } else {
                 uint4 pk;
-                pk.x = (uint32_t)Vec<T>::enc(v[0]) | ((uint32_t)Vec<T>::enc(v[1]) << 16);
-                pk.y = (uint32_t)Vec<T>::enc(v[2]) | ((uint32_t)Vec<T>::enc(v[3]) << 16);
-                pk.z = (uint32_t)Vec<T>::enc(v[4]) | ((uint32_t)Vec<T>::enc(v[5]) << 16);
-                pk.w = (uint32_t)Vec<T>::enc(v[6]) | ((uint32_t)Vec<T>::enc(v[7]) << 16);
+                pk.x = Vec<T>::pack2(v[0], v[1]);
+                pk.y = Vec<T>::pack2(v[2], v[3]);
+                pk.z = Vec<T>::pack2(v[4], v[5]);
+                pk.w = Vec<T>::pack2(v[6], v[7]);
                 *reinterpret_cast<uint4*>(dst) = pk;
             }
         }
