@@ -235,7 +235,7 @@ def main():
     # train_model.py:199-203): generator -> rank shard -> pinned ring -> copy stream -> replayed step, per-epoch logs.  Reported
     # beside `value`, never as it (the contract times resident inputs).  Runs last: it trains on other batches.
     if rank == 0 and world == 1 and not args.no_fit:
-        nb, ep = 32, max(2, min(4, args.steps // 5))             # 32 steps per epoch (the reference's fold has 44: 1 426 slices / 32)
+        nb, ep = 44, max(2, min(4, args.steps // 5))             # 44 steps per epoch: the reference's fold, 1 426 slices / 32
         fgen = rvip.Generators.SyntheticSAXGenerator(nb * B, dict(DIM=cfg['DIM'], BATCHSIZE=B, GAUS=True, SIGMA=2, SHUFFLE=True, SEED=1), in_memory=True)
         model.fit(fgen, epochs=1, verbose=0, max_queue_size=4, workers=4)          # fills the generator's sample cache (untimed)
         torch.cuda.synchronize()
