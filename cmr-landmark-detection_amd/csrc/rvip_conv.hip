@@ -1001,18 +1001,21 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             }
         }
         // ---- epilogue of this tile; compute waves never wait on their stores ----
-        // Two pixel blocks (X, Y) of one channel block at a time: after v_permlane16_swap of the packed pairs a lane with even kq
-        // holds 8 consecutive channels of X's pixel, a lane with odd kq those of Y's pixel -> one 16-byte store per lane.
-        // x0, x1 / y0, y1: the four channels of pixel block X / Y, packed (Vec<T>::pack2)
-        auto store_pair = [&](int cb, unsigned x0, unsigned x1, unsigned y0, unsigned y1, unsigned pix, bool pix_ok) __attribute__((always_inline)) {
-            const int cbase = co0 + cb * 16;                                   // wave-uniform
+        // Two CHANNEL blocks (A, B = 2 cp, 2 cp + 1) of one pixel block at a time: after v_permlane16_swap of the packed pairs a lane
+        // with even kq holds 8 consecutive channels of block A, a lane with odd kq 8 of block B, all of the lane's own pixel -> one
+        // 16-byte store per lane, and the four lanes of a pixel cover 32 consecutive channels = 64 contiguous bytes (a whole pixel
+        // row for Cout = 32, where a store instruction is then 1 KiB contiguous).  Pairing two PIXEL blocks of one channel block
+        // (the first form) left every instruction writing 32-byte pieces 64 / 128 bytes apart.
+        // a0, a1 / b0, b1: the four channels of block A / B of the lane's pixel, packed (Vec<T>::pack2)
+        auto store_cbpair = [&](int cp, unsigned a0, unsigned a1, unsigned b0, unsigned b1, unsigned pix, bool pix_ok) __attribute__((always_inline)) {
+            const int cbase = co0 + cp * 32;                                   // wave-uniform
             const bool second = a.y1 && cbase >= a.csplit;                     // csplit % 32 == 0 (host)
             const int cstride = a.y1 ? (second ? a.cout - a.csplit : a.csplit) : a.cout;
             const int cshift = second ? a.csplit : 0;
-            auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-            auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+            auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+            auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
             const u32x4v dta = {s0[0], s1[0], s0[1], s1[1]};
-            const int co = cbase + 8 * (kq >> 1);
+            const int co = cbase + 16 * (kq & 1) + 8 * (kq >> 1);
             const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
             if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
@@ -1023,46 +1026,53 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
         };
         auto epilogue = [&](auto actf) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                float qs[4], qq[4];
+            for (int cp = 0; cp < NCB / 2; ++cp) {
+                float qs[2][4], qq[2][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qs[r] = qq[r] = 0.f;
+                for (int r = 0; r < 4; ++r) qs[0][r] = qs[1][r] = qq[0][r] = qq[1][r] = 0.f;
 #pragma unroll
                 for (int q = 0; q < NPB / 2; ++q) {
-                    int gy0, gx0, gy1, gx1;
-                    block_pixel(2 * q, gy0, gx0);
-                    block_pixel(2 * q + 1, gy1, gx1);
-                    const bool ok0 = gy0 < a.h && gx0 < a.w, ok1 = gy1 < a.h && gx1 < a.w;
-                    float x[4], y[4];
+                    unsigned pk[2][2][2];                                       // [pixel block of the pair][channel block A / B][word]
+                    bool ok[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        x[r] = actf(acc[cb][2 * q][r]);
-                        y[r] = actf(acc[cb][2 * q + 1][r]);
-                        acc[cb][2 * q][r] = bias_r[cb][r];
-                        acc[cb][2 * q + 1][r] = bias_r[cb][r];
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int blk = 2 * q + s2;
+                        int gy, gx;
+                        block_pixel(blk, gy, gx);
+                        ok[s2] = gy < a.h && gx < a.w;
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            const int cb = 2 * cp + c2;
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { v[r] = actf(acc[cb][blk][r]); acc[cb][blk][r] = bias_r[cb][r]; }
+                            pk[s2][c2][0] = Vec<T>::pack2(v[0], v[1]);
+                            pk[s2][c2][1] = Vec<T>::pack2(v[2], v[3]);
+                        }
+                        const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gy + pa) * 2 * a.w + 2 * gx + pb)
+                                                       : (unsigned)((n * a.h + gy) * a.w + gx);
+                        store_cbpair(cp, pk[s2][0][0], pk[s2][0][1], pk[s2][1][0], pk[s2][1][1], pix, ok[s2]);
                     }
-                    const unsigned x0 = Vec<T>::pack2(x[0], x[1]), x1 = Vec<T>::pack2(x[2], x[3]);
-                    const unsigned y0 = Vec<T>::pack2(y[0], y[1]), y1 = Vec<T>::pack2(y[2], y[3]);
                     if constexpr (STATS) {                                      // statistics of what is stored: the packed words, widened
-                        const float ux[4] = {Vec<T>::lo(x0), Vec<T>::hi(x0), Vec<T>::lo(x1), Vec<T>::hi(x1)};
-                        const float uy[4] = {Vec<T>::lo(y0), Vec<T>::hi(y0), Vec<T>::lo(y1), Vec<T>::hi(y1)};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float u0 = ok0 ? ux[r] : 0.f, u1 = ok1 ? uy[r] : 0.f;
-                            qs[r] += u0 + u1;
-                            qq[r] = fmaf(u0, u0, fmaf(u1, u1, qq[r]));
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            const float ux[4] = {Vec<T>::lo(pk[0][c2][0]), Vec<T>::hi(pk[0][c2][0]), Vec<T>::lo(pk[0][c2][1]), Vec<T>::hi(pk[0][c2][1])};
+                            const float uy[4] = {Vec<T>::lo(pk[1][c2][0]), Vec<T>::hi(pk[1][c2][0]), Vec<T>::lo(pk[1][c2][1]), Vec<T>::hi(pk[1][c2][1])};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float u0 = ok[0] ? ux[r] : 0.f, u1 = ok[1] ? uy[r] : 0.f;
+                                qs[c2][r] += u0 + u1;
+                                qq[c2][r] = fmaf(u0, u0, fmaf(u1, u1, qq[c2][r]));
+                            }
                         }
                     }
-                    // the pixel this lane stores after the swap: X's for even kq, Y's for odd kq
-                    const int gym = (kq & 1) ? gy1 : gy0, gxm = (kq & 1) ? gx1 : gx0;
-                    const bool okm = (kq & 1) ? ok1 : ok0;
-                    const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gym + pa) * 2 * a.w + 2 * gxm + pb)
-                                                   : (unsigned)((n * a.h + gym) * a.w + gxm);
-                    store_pair(cb, x0, x1, y0, y1, pix, okm);
                 }
                 if constexpr (STATS) {
-                    st_sum[cb] += lane16_channel_sum(qs, i16);
-                    st_sq[cb] += lane16_channel_sum(qq, i16);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        st_sum[2 * cp + c2] += lane16_channel_sum(qs[c2], i16);
+                        st_sq[2 * cp + c2] += lane16_channel_sum(qq[c2], i16);
+                    }
                 }
             }
         };
@@ -1072,32 +1082,29 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             constexpr int NU = NPB / 2;                                        // 2-row units per wave
             const int hl = a.h >> 1, wl = a.w >> 1;
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
+            for (int cp = 0; cp < NCB / 2; ++cp) {
 #pragma unroll
-                for (int w2 = 0; w2 < NU / 2; ++w2) {
+                for (int u = 0; u < NU; ++u) {
+                    // TW = 32: unit = (row pair m, column block cx); TW = 16: unit = row pair m
+                    const int m = BPR == 2 ? (u >> 1) : u, cx = BPR == 2 ? (u & 1) : 0;
+                    const int top = (2 * m) * BPR + cx, bot = (2 * m + 1) * BPR + cx;
+                    const int gyu = ty0 + row0 + 2 * m, gxu = tx0 + cx * 16 + i16;
                     float v[2][4];
-                    int gyu[2], gxu[2];
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const int u = 2 * w2 + s2;
-                        // TW = 32: unit = (row pair m, column block cx); TW = 16: unit = row pair m
-                        const int m = BPR == 2 ? (u >> 1) : u, cx = BPR == 2 ? (u & 1) : 0;
-                        const int top = (2 * m) * BPR + cx, bot = (2 * m + 1) * BPR + cx;
-                        gyu[s2] = ty0 + row0 + 2 * m;
-                        gxu[s2] = tx0 + cx * 16 + i16;
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        const int cb = 2 * cp + c2;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float t = acc[cb][top][r] + acc[cb][bot][r];
                             acc[cb][top][r] = 0.f;
                             acc[cb][bot][r] = 0.f;
-                            v[s2][r] = t + lane_xor1(t);
+                            v[c2][r] = t + lane_xor1(t);
                         }
                     }
-                    const int gym = (kq & 1) ? gyu[1] : gyu[0], gxm = (kq & 1) ? gxu[1] : gxu[0];
-                    const bool keep = gym < a.h && gxm < a.w && !(i16 & 1);
-                    const unsigned pix = (unsigned)((n * hl + (gym >> 1)) * wl + (gxm >> 1));
-                    store_pair(cb, Vec<T>::pack2(v[0][0], v[0][1]), Vec<T>::pack2(v[0][2], v[0][3]), Vec<T>::pack2(v[1][0], v[1][1]),
-                               Vec<T>::pack2(v[1][2], v[1][3]), pix, keep);
+                    const bool keep = gyu < a.h && gxu < a.w && !(i16 & 1);
+                    const unsigned pix = (unsigned)((n * hl + (gyu >> 1)) * wl + (gxu >> 1));
+                    store_cbpair(cp, Vec<T>::pack2(v[0][0], v[0][1]), Vec<T>::pack2(v[0][2], v[0][3]), Vec<T>::pack2(v[1][0], v[1][1]),
+                                 Vec<T>::pack2(v[1][2], v[1][3]), pix, keep);
                 }
             }
         };
