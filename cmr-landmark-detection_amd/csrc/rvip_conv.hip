@@ -1216,7 +1216,11 @@ static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float
         if (ntiles * cdiv(a.cout, 64) <= 128) two = false;
     }
     if (a.subpix) {                     // a.h, a.w = the low-resolution grid
-        if (a.w > 16 && a.h >= 16) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry);
+        if (a.w > 16 && a.h >= 16) {
+            // 16-bit types: eight compute waves (the 16x16x32 kernel; its four-wave form would hold 128 accumulators per lane): +0.4 % of the step
+            if (sizeof(T) == 2) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 4, 8>(a, s, used, stats, rows_out, dry);
+            return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry);
+        }
         if (a.w > 16) return two ? launch_igemm_ws<T, V5, 32, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 256, 4>(a, s, used, stats, rows_out, dry);
         return two ? launch_igemm_ws<T, V5, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry);
     }
