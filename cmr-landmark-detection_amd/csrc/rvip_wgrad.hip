@@ -515,9 +515,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
             }
         }
         asm volatile("s_barrier" ::: "memory");                       // matches the compute waves' barrier before the fold
-        if constexpr (PSPLIT > 1) {
-            for (int psel = 0; psel < PSPLIT; ++psel) __syncthreads();
-        }
+        if constexpr (PSPLIT > 1) __syncthreads();                     // the compute waves' blocks are in LDS
         return;
     }
 
@@ -605,24 +603,28 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
                 if (ci < a.cin && co < a.cout) __builtin_nontemporal_store(acc[t][r], &out[((size_t)t * a.cin + ci) * a.cout + co]);
             }
     } else {
-        float* red = reinterpret_cast<float*>(smem) + pair * 9 * 32 * 32;   // [PAIRS][9][32][32]
-        for (int psel = 0; psel < PSPLIT; ++psel) {
-            if (part == psel) {
+        // every compute wave parks its block in LDS (the stages are free), one barrier, then 256 threads add the PSPLIT copies in
+        // a fixed order and write 16 bytes each (the first form took turns: PSPLIT read-modify-write rounds behind barriers and
+        // 4-byte stores -- 10-20 us at the end of the 32-channel launches, with nothing to overlap them)
+        constexpr int BLK = 9 * 32 * 32, N4 = PAIRS * BLK / 4;
+        float* red = reinterpret_cast<float*>(smem) + (part * PAIRS + pair) * BLK;   // [PSPLIT][PAIRS][9][32][32]
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int idx = (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j;
-                        red[idx] = (psel == 0 ? 0.f : red[idx]) + acc[t][r];
-                    }
-            }
-            __syncthreads();
-        }
-        const float* redall = reinterpret_cast<const float*>(smem);
-        for (int e = tid; e < PAIRS * 9 * 32 * 32; e += 256) {
-            const int pr = e / (9 * 32 * 32), rem = e % (9 * 32 * 32);
+            for (int r = 0; r < 16; ++r) red[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j] = acc[t][r];
+        __syncthreads();
+        const f32x4* r4 = reinterpret_cast<const f32x4*>(smem);
+        for (int e4 = tid; e4 < N4; e4 += 256) {
+            f32x4 sum = r4[e4];
+#pragma unroll
+            for (int p = 1; p < PSPLIT; ++p) sum += r4[p * N4 + e4];
+            const int e = 4 * e4, pr = e / BLK, rem = e % BLK;
             const int t = rem >> 10, ci = ci0 + (pr % NCI) * 32 + ((rem >> 5) & 31), co = co0 + (pr / NCI) * 32 + (rem & 31);
-            if (ci < a.cin && co < a.cout) __builtin_nontemporal_store(redall[e], &out[((size_t)t * a.cin + ci) * a.cout + co]);
+            if (ci < a.cin && co + 3 < a.cout) {
+                __builtin_nontemporal_store(sum, reinterpret_cast<f32x4*>(&out[((size_t)t * a.cin + ci) * a.cout + co]));
+            } else if (ci < a.cin) {
+                for (int q = 0; q < 4; ++q) if (co + q < a.cout) __builtin_nontemporal_store(sum[q], &out[((size_t)t * a.cin + ci) * a.cout + co + q]);
+            }
         }
     }
 }
@@ -720,9 +722,10 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
 #else
     constexpr int NST = (WS && 3 * ST <= 160 * 1024) ? 3 : 2;
 #endif
-    constexpr int lds = NST * ST;
+    // the wave-specialised kernel folds the pixel-split copies of a block through LDS: 4 x [9][32][32] floats
+    constexpr int FOLD = (WS && (ESZ == 4 || (CIB / 32) * (COB / 32) < 4)) ? 4 * 9 * 32 * 32 * 4 : 0;
+    constexpr int lds = NST * ST > FOLD ? NST * ST : FOLD;
     static_assert(lds <= 160 * 1024, "LDS");
-    static_assert(2 * ST >= 4 * 9 * 32 * 32 * 4 || true, "fold buffer");
     static std::atomic<bool> attr_done{false};      // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!attr_done) {
         hipError_t e = WS ? hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
