@@ -313,13 +313,19 @@ struct ApplyArgs {
     int n, h, w, c;
 };
 
-template <typename T, int VE>
+// ACT / DROP: compile-time activation (RVIP_ACT_*) and dropout mode (0 none, 1 counter stream, 2 mask array) of the hot
+// configurations; -1 = read the descriptor.  With the descriptor's values the compiler keeps the `switch (act)` and the mode tests
+// inside the element loop (a chain of scalar compares and branches per value -- these kernels sit at the VALU / issue limit of an
+// HBM stream); the launchers pick a specialised instantiation for what the reference's default graph uses and the generic one otherwise.
+template <typename T, int VE, int ACT = -1, int DROP = -1>
 __device__ __forceinline__ void apply_xform(const ApplyArgs& a, size_t e0, const float (&sc)[VE], const float (&sh)[VE],
                                             uint32_t key, float (&v)[VE]) {
+    const int act = ACT < 0 ? a.act : ACT;
+    const bool drop = DROP < 0 ? a.drop != 0 : DROP > 0, has_mask = DROP < 0 ? a.mask != nullptr : DROP == 2;
 #pragma unroll
-    for (int e = 0; e < VE; ++e) v[e] = act_fwd(fmaf(v[e], sc[e], sh[e]), a.act);
-    if (a.drop) {
-        if (a.mask) {
+    for (int e = 0; e < VE; ++e) v[e] = act_fwd(fmaf(v[e], sc[e], sh[e]), act);
+    if (drop) {
+        if (has_mask) {
 #pragma unroll
             for (int e = 0; e < VE; ++e) v[e] = a.mask[e0 + e] ? v[e] * a.inv_keep : 0.f;
         } else {
@@ -333,7 +339,7 @@ __device__ __forceinline__ void apply_xform(const ApplyArgs& a, size_t e0, const
 
 // thread = (row slot, channel vector): the channel vector is fixed per thread, so scale/shift live in registers;
 // every thread keeps UNR independent 16-byte loads in flight (the kernel is a pure HBM stream).
-template <typename T, bool POOL>
+template <typename T, bool POOL, int ACT = -1, int DROP = -1>
 __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int rpi, long long ngroups) {
     constexpr int VE = Vec<T>::VE;
 #ifndef RVIP_APPLY_UNR
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 if (!ok[u]) continue;
-                apply_xform<T, VE>(a, e0[u], sc, sh, key, v[u]);
+                apply_xform<T, VE, ACT, DROP>(a, e0[u], sc, sh, key, v[u]);
                 Vec<T>::store(a.y + e0[u] * sizeof(T), v[u]);
             }
         }
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
                 float best[VE];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    apply_xform<T, VE>(a, e0[u][k], sc, sh, key, v[u][k]);
+                    apply_xform<T, VE, ACT, DROP>(a, e0[u][k], sc, sh, key, v[u][k]);
                     Vec<T>::store(a.y + e0[u][k] * sizeof(T), v[u][k]);
 #pragma unroll
                     for (int e = 0; e < VE; ++e) {
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
 // loads and stores per round (the window-per-thread form issues 8 + 10: its stores, not its loads or its index arithmetic, hold
 // it at 3.5 TB/s -- tools/probe_apply_pool.py).  The window maximum is completed with one lane exchange.  cg must be a power of
 // two <= 32 (the two lanes share a wave).
-template <typename T>
+template <typename T, int ACT = -1, int DROP = -1>
 __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(ApplyArgs a, int cg, int wpi, long long ngroups) {
     constexpr int VE = Vec<T>::VE;
 #ifndef RVIP_POOL2_UNR
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(ApplyArgs a, int cg
             float best[VE];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                apply_xform<T, VE>(a, e0[u][r], sc, sh, key, v[u][r]);
+                apply_xform<T, VE, ACT, DROP>(a, e0[u][r], sc, sh, key, v[u][r]);
                 Vec<T>::store(a.y + e0[u][r] * sizeof(T), v[u][r]);
 #pragma unroll
                 for (int e = 0; e < VE; ++e) {
@@ -477,10 +483,13 @@ struct BnBwdArgs {
 };
 
 // g = dL/d(BN-side output before dropout) [times act'(y) when the activation follows BN]
-template <typename T, int VE>
+template <typename T, int VE, int ACT = -1, int DROP = -1, int AFTER = -1>
 __device__ __forceinline__ void xform_g(const BnBwdArgs& a, size_t e0, int cbase, uint32_t key, const float (&z)[VE], float (&g)[VE]) {
-    if (a.drop) {
-        if (a.mask) {
+    const int act = ACT < 0 ? a.act : ACT;
+    const bool drop = DROP < 0 ? a.drop != 0 : DROP > 0, has_mask = DROP < 0 ? a.mask != nullptr : DROP == 2;
+    const bool after = AFTER < 0 ? a.act_after_bn != 0 : AFTER > 0;
+    if (drop) {
+        if (has_mask) {
 #pragma unroll
             for (int e = 0; e < VE; ++e) g[e] = a.mask[e0 + e] ? g[e] * a.inv_keep : 0.f;
         } else {
@@ -490,16 +499,16 @@ __device__ __forceinline__ void xform_g(const BnBwdArgs& a, size_t e0, int cbase
             for (int e = 0; e < VE; ++e) g[e] = keep[e] ? g[e] * a.inv_keep : 0.f;
         }
     }
-    if (a.act_after_bn) {
+    if (after) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
             const float sc = a.scale ? a.scale[cbase + e] : 1.f, sh = a.shift ? a.shift[cbase + e] : 0.f;
-            g[e] *= act_bwd(act_fwd(fmaf(z[e], sc, sh), a.act), a.act);
+            g[e] *= act_bwd(act_fwd(fmaf(z[e], sc, sh), act), act);
         }
     }
 }
 
-template <typename T>
+template <typename T, int ACT = -1, int DROP = -1, int AFTER = -1>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom
 #pragma unroll
             for (int u = 0; u < RVIP_BWD_U; ++u) {
                 if (!ok[u]) continue;
-                xform_g<T, VE>(a, e0[u], cgi * VE, key, z[u], g[u]);
+                xform_g<T, VE, ACT, DROP, AFTER>(a, e0[u], cgi * VE, key, z[u], g[u]);
 #pragma unroll
                 for (int e = 0; e < VE; ++e) { part[0][e] += g[u][e]; part[1][e] = fmaf(g[u][e], (z[u][e] - mu[e]) * is[e], part[1][e]); }
             }
@@ -551,7 +560,7 @@ struct PostBnBwd {
     }
 };
 
-template <typename T>
+template <typename T, int ACT = -1, int DROP = -1, int AFTER = -1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
@@ -583,12 +592,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
 #pragma unroll
             for (int u = 0; u < RVIP_BWD_U_APPLY; ++u) {
                 if (!ok[u]) continue;
-                xform_g<T, VE>(a, e0[u], cgi * VE, key, z[u], g[u]);
+                xform_g<T, VE, ACT, DROP, AFTER>(a, e0[u], cgi * VE, key, z[u], g[u]);
                 float d[VE];
 #pragma unroll
                 for (int e = 0; e < VE; ++e) {
                     float t = fmaf(c1[e], g[u][e], fmaf(c2[e], z[u][e], c3[e]));
-                    if (!a.act_after_bn) t *= act_bwd(z[u][e], a.act);   // z is the activation output here
+                    if (!(AFTER < 0 ? a.act_after_bn != 0 : AFTER > 0)) t *= act_bwd(z[u][e], ACT < 0 ? a.act : ACT);   // z is the activation output here
                     d[e] = t;
                     part[0][e] += Vec<T>::round(t);                    // bias grad of what the wgrad kernels read
                 }
@@ -1279,23 +1288,34 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     if (nb > nb_cap) nb = nb_cap;
     dim3 grid((unsigned)nb);
     static const bool pool2 = [] { const char* e = getenv("RVIP_POOL_SPLIT"); return !(e && e[0] == '0'); }();
+    // specialised instantiations of the reference's default graph (conv + ReLU -> BN: no activation in this pass): 1 = no dropout, 2 = stream
+    static const bool spec = [] { const char* e = getenv("RVIP_SPECIALISE"); return !(e && e[0] == '0'); }();
+    const int fast = (spec && d->act == RVIP_ACT_NONE) ? (!drop ? 1 : (!d->mask ? 2 : 0)) : 0;
     if (d->pooled && pool2 && cg <= 32 && (cg & (cg - 1)) == 0) {        // column-split form: both lanes of a window in one wave
         const int wpi = 128 / cg;
         const long long ng2 = cdiv(units, wpi);
         long long nb2 = cdiv(ng2, RVIP_POOL2_UNR);
         if (nb2 > nb_cap) nb2 = nb_cap;
         by_dtype(d->dtype, [&](auto t) {
-            hipLaunchKernelGGL((bn_apply_pool2_kernel<decltype(t)>), dim3((unsigned)nb2), dim3(256), 0, s, a, cg, wpi, ng2);
+            using T = decltype(t);
+            if (fast == 1) hipLaunchKernelGGL((bn_apply_pool2_kernel<T, RVIP_ACT_NONE, 0>), dim3((unsigned)nb2), dim3(256), 0, s, a, cg, wpi, ng2);
+            else if (fast == 2) hipLaunchKernelGGL((bn_apply_pool2_kernel<T, RVIP_ACT_NONE, 1>), dim3((unsigned)nb2), dim3(256), 0, s, a, cg, wpi, ng2);
+            else hipLaunchKernelGGL((bn_apply_pool2_kernel<T>), dim3((unsigned)nb2), dim3(256), 0, s, a, cg, wpi, ng2);
             return 0;
         });
     } else if (d->pooled) {
-        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
-        else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_apply_kernel<f16_t, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
-        else hipLaunchKernelGGL((bn_apply_kernel<float, true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+        by_dtype(d->dtype, [&](auto t) {
+            hipLaunchKernelGGL((bn_apply_kernel<decltype(t), true>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+            return 0;
+        });
     } else {
-        if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
-        else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_apply_kernel<f16_t, false>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
-        else hipLaunchKernelGGL((bn_apply_kernel<float, false>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+        by_dtype(d->dtype, [&](auto t) {
+            using T = decltype(t);
+            if (fast == 1) hipLaunchKernelGGL((bn_apply_kernel<T, false, RVIP_ACT_NONE, 0>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+            else if (fast == 2) hipLaunchKernelGGL((bn_apply_kernel<T, false, RVIP_ACT_NONE, 1>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+            else hipLaunchKernelGGL((bn_apply_kernel<T, false>), grid, dim3(256), 0, s, a, cg, rpi, ngroups);
+            return 0;
+        });
     }
     return check_launch();
 }
@@ -1316,6 +1336,14 @@ static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
     return RVIP_OK;
 }
 
+// specialised instantiations of the BN-backward passes for the reference's default graph (conv + ReLU -> BN [-> dropout]):
+// 1 = no dropout, 2 = counter-stream dropout, 0 = the generic kernel
+static int bnbwd_fast(const BnBwdArgs& a) {
+    static const bool spec = [] { const char* e = getenv("RVIP_SPECIALISE"); return !(e && e[0] == '0'); }();
+    if (!spec || a.act != RVIP_ACT_RELU || a.act_after_bn) return 0;
+    return !a.drop ? 1 : (!a.mask ? 2 : 0);
+}
+
 extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     (void)hipGetLastError();
     BnBwdArgs a; RedGeom g;
@@ -1325,9 +1353,14 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     if (d->workspace_bytes < (size_t)g.nblk * 2 * d->c * sizeof(float)) return RVIP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)d->workspace;
-    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16_t>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    const int fast = bnbwd_fast(a);
+    by_dtype(d->dtype, [&](auto t) {
+        using T = decltype(t);
+        if (fast == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, RVIP_ACT_RELU, 0, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else if (fast == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, RVIP_ACT_RELU, 1, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        return 0;
+    });
     rc = check_launch();
     if (rc) return rc;
     PostBnBwd p{d->gamma, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef, (double)d->rows, d->c};
@@ -1345,9 +1378,14 @@ extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
     if ((defer ? d->bias_rows_bytes : d->workspace_bytes) < (size_t)g.nblk * d->c * sizeof(float)) return RVIP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* ws = defer ? d->bias_rows : (float*)d->workspace;
-    if (d->dtype == RVIP_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    else if (d->dtype == RVIP_F16) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16_t>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+    const int fast = bnbwd_fast(a);
+    by_dtype(d->dtype, [&](auto t) {
+        using T = decltype(t);
+        if (fast == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RVIP_ACT_RELU, 0, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else if (fast == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RVIP_ACT_RELU, 1, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        return 0;
+    });
     rc = check_launch();
     if (rc || defer) return rc;
     PostSum p{d->dbias};
