@@ -19,7 +19,10 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __builtin_bit_
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }   // RNE, NaN kept
 
 __device__ __forceinline__ float f16_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
-__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // RNE, overflow -> inf
+// RNE of the FP32 VALUE, overflow -> inf.  The empty asm pins that value: without it the compiler may fold a preceding fma into
+// v_fma_mixlo_f16, which rounds the exact product-sum ONCE -- a different result in rare double-rounding cases, and then the
+// fused and the separate kernels (and the storage-rounding emulation in tests/) no longer store the same bits.
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { asm volatile("" : "+v"(f)); return __builtin_bit_cast(uint16_t, (_Float16)f); }
 
 // two fp32 -> one packed 32-bit word (lo = a, hi = b), RNE: ONE v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32.  Converting the halves one by
 // one and OR-ing them (the obvious form) is four instructions on gfx950: cvt, cvt, shift, or.
@@ -29,6 +32,7 @@ typedef _Float16 rvip_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
     const rvip_f32x2 v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rvip_bf16x2)); }
 __device__ __forceinline__ uint32_t pack2_f16(float a, float b) {
+    asm volatile("" : "+v"(a), "+v"(b));              // see f32_to_f16
     const rvip_f32x2 v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rvip_f16x2)); }
 
 // 16-byte channel vector: VE elements of T

@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const T* __restrict__ x
 // STATS: the BatchNormalization statistics of the stored output ride along -- every thread keeps the sum and the sum of squares
 // of its channel vector over the pixels it produced, the workgroup folds its pixel slots through LDS and writes one partial
 // row stats[blockIdx.x][2][cout] (finish with rvip_bn_stats_finalize): saves the 134 MB re-read of rvip_bn_train_stats.
-template <typename T, bool STATS = false>
+template <typename T, bool STATS = false, int ACT = -1>      // ACT: compile-time activation (-1: the argument), as in the BN passes
 __global__ __launch_bounds__(256) void conv3x3_c1_tiled(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, unsigned char* y,
                                                         int n, int h, int wd, int cout, int act, int tiles_x, int tiles_y,
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_tiled(const T* __restrict__ x,
                 float acc = br[e];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc = fmaf(xin[t], wr[t][e], acc);
-                v[e] = act_fwd(acc, act);
+                v[e] = act_fwd(acc, ACT < 0 ? act : ACT);
                 if constexpr (STATS) {
                     const float q = Vec<T>::round(v[e]);          // statistics of what is stored
                     ssum[e] += q;
@@ -1725,7 +1725,8 @@ extern "C" int rvip_conv3x3_c1_fwd_stats(const void* x, const float* w, const fl
     hipStream_t s = (hipStream_t)stream;
     by_dtype(dtype, [&](auto t) {
         using T = decltype(t);
-        hipLaunchKernelGGL((conv3x3_c1_tiled<T, true>), dim3((unsigned)rows), dim3(256), 0, s, (const T*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty, stats_ws);
+        if (act == RVIP_ACT_RELU) hipLaunchKernelGGL((conv3x3_c1_tiled<T, true, RVIP_ACT_RELU>), dim3((unsigned)rows), dim3(256), 0, s, (const T*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty, stats_ws);
+        else hipLaunchKernelGGL((conv3x3_c1_tiled<T, true>), dim3((unsigned)rows), dim3(256), 0, s, (const T*)x, w, bias, (unsigned char*)y, n, h, w_, cout, act, tx, ty, stats_ws);
         return 0;
     });
     return check_launch();

@@ -848,7 +848,7 @@ struct HeadFuse { const float* w; const float* b; const float* dlogit; int k; };
 
 // KK = class capacity of the instantiation (2 for the reference's two heat-maps): half the shuffles and logit registers of the
 // MAXK-sized form; the target values of the round are loaded with its z rows, not after the arithmetic that depends on them.
-template <typename T, int KK>
+template <typename T, int KK, int SPEC = 0>
 __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFuse hd, float* __restrict__ pred, const float* __restrict__ yt,
                                                             long long rows, long long chunk, int reduce, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE, U = 2;
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
             for (int kk = 0; kk < KK; ++kk) lg[kk] = 0.f;
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
-                const float y = Vec<T>::round(act_fwd(fmaf(v[u][e], sc[e], sh[e]), a.act));   // what rvip_bn_apply would have stored
+                const float y = Vec<T>::round(act_fwd(fmaf(v[u][e], sc[e], sh[e]), SPEC ? RVIP_ACT_NONE : a.act));   // what rvip_bn_apply would have stored
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) lg[kk] = fmaf(y, wr[e][kk], lg[kk]);
             }
@@ -954,7 +954,7 @@ __device__ __forceinline__ void head_grad_vec(const HeadFuse& hd, long long r, c
 // KK = class capacity of this instantiation (2 for the reference's two heat-maps, RVIP_MAXK otherwise): the per-class partials are
 // KK x VE registers each way, and with the MAXK-sized arrays the kernel had one 16-byte load in flight per thread at ~170 VGPRs --
 // latency-bound at 1.7 TB/s.  U rows in flight per thread.
-template <typename T, int KK>
+template <typename T, int KK, int SPEC = 0>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(BnBwdArgs a, HeadFuse hd, RedGeom gm, float* __restrict__ ws_bn, float* __restrict__ ws_hd) {
     constexpr int VE = Vec<T>::VE, U = 2;
     __shared__ float lds[256 * VE];
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(BnBwdArgs a, He
 #pragma unroll
                     for (int kk = 0; kk < KK; ++kk) acc = fmaf(d[u][kk], wr[e][kk], acc);
                     g[e] = Vec<T>::round(acc);                    // the gy tensor the unfused path stores in the activation dtype
-                    const float y = Vec<T>::round(act_fwd(fmaf(z[u][e], sc[e], sh[e]), a.act_after_bn ? a.act : RVIP_ACT_NONE));
+                    const float y = Vec<T>::round(act_fwd(fmaf(z[u][e], sc[e], sh[e]), (!SPEC && a.act_after_bn) ? a.act : RVIP_ACT_NONE));
 #pragma unroll
                     for (int kk = 0; kk < KK; ++kk) hpart[kk][e] = fmaf(y, d[u][kk], hpart[kk][e]);     // dW_h
                 }
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(BnBwdArgs a, He
 #pragma unroll
                     for (int kk = 0; kk < KK; ++kk) hpart[KK + kk][0] += d[u][kk];                       // db_h
                 }
-                xform_g<T, VE>(a, e0, cgi * VE, 0u, z[u], g);
+                if constexpr (!SPEC) xform_g<T, VE>(a, e0, cgi * VE, 0u, z[u], g);      // SPEC: no dropout, no activation after BN
 #pragma unroll
                 for (int e = 0; e < VE; ++e) { part[0][e] += g[e]; part[1][e] = fmaf(g[e], (z[u][e] - mu[e]) * is[e], part[1][e]); }
             }
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(BnBwdArgs a, He
     block_fold<2 * KK, VE>(hpart, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws_hd + (size_t)blockIdx.x * 2 * KK * a.c);
 }
 
-template <typename T, int KK>
+template <typename T, int KK, int SPEC = 0>
 __global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(BnBwdArgs a, HeadFuse hd, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
@@ -1048,12 +1048,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(BnBwdArgs a, Hea
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (!ok[u]) continue;
-                xform_g<T, VE>(a, e0[u], cgi * VE, 0u, z[u], g[u]);
+                if constexpr (!SPEC) xform_g<T, VE>(a, e0[u], cgi * VE, 0u, z[u], g[u]);
                 float dd[VE];
 #pragma unroll
                 for (int e = 0; e < VE; ++e) {
                     float t = fmaf(c1[e], g[u][e], fmaf(c2[e], z[u][e], c3[e]));
-                    if (!a.act_after_bn) t *= act_bwd(z[u][e], a.act);
+                    if (SPEC || !a.act_after_bn) t *= act_bwd(z[u][e], SPEC ? RVIP_ACT_RELU : a.act);
                     dd[e] = t;
                     part[0][e] += Vec<T>::round(t);
                 }
@@ -1518,7 +1518,8 @@ extern "C" int rvip_bn_apply_head(const rvip_apply_desc* d, const float* head_w,
     HeadFuse hd{head_w, head_b, nullptr, k};
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
-        if (k <= 2) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
+        if (k <= 2 && a.act == RVIP_ACT_NONE) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
+        else if (k <= 2) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
         else hipLaunchKernelGGL((bn_apply_head_kernel<T, RVIP_MAXK>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
         return 0;
     });
@@ -1552,7 +1553,8 @@ extern "C" int rvip_bn_bwd_reduce_head(const rvip_bnbwd_desc* d, const float* he
     HeadFuse hd{head_w, nullptr, dlogit, k};
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
-        if (kcap == 2) hipLaunchKernelGGL((bn_bwd_reduce_head_kernel<T, 2>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
+        if (kcap == 2 && a.act == RVIP_ACT_RELU && !a.act_after_bn) hipLaunchKernelGGL((bn_bwd_reduce_head_kernel<T, 2, 1>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
+        else if (kcap == 2) hipLaunchKernelGGL((bn_bwd_reduce_head_kernel<T, 2>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
         else hipLaunchKernelGGL((bn_bwd_reduce_head_kernel<T, RVIP_MAXK>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws_bn, ws_hd);
         return 0;
     });
@@ -1584,7 +1586,8 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     HeadFuse hd{head_w, nullptr, dlogit, k};
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
-        if (k <= 2) hipLaunchKernelGGL((bn_bwd_apply_head_kernel<T, 2>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
+        if (k <= 2 && a.act == RVIP_ACT_RELU && !a.act_after_bn) hipLaunchKernelGGL((bn_bwd_apply_head_kernel<T, 2, 1>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
+        else if (k <= 2) hipLaunchKernelGGL((bn_bwd_apply_head_kernel<T, 2>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
         else hipLaunchKernelGGL((bn_bwd_apply_head_kernel<T, RVIP_MAXK>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
         return 0;
     });
