@@ -144,13 +144,18 @@ class ParamStore:
         return out
 
     @staticmethod
-    def _to_equivalent(w_hwoi):
-        return np.ascontiguousarray(w_hwoi[::-1, ::-1].transpose(0, 1, 3, 2))
+    def _to_equivalent(w):
+        """[k.., Cout, Cin] of a transposed conv -> [k.., Cin, Cout] of the forward conv over the zero-stuffed input: every spatial
+        axis reversed (also the stride-1 depth axis of Conv3DTranspose), last two axes swapped."""
+        nd = w.ndim - 2
+        flip = (slice(None, None, -1),) * nd
+        return np.ascontiguousarray(np.swapaxes(w[flip], -1, -2))
 
     def _from_device(self, lname, wname, flat, shape):
         if wname == 'kernel' and lname in self.transposed:
-            kh, kw, co, ci = shape
-            return np.ascontiguousarray(flat.reshape(kh, kw, ci, co).transpose(0, 1, 3, 2)[::-1, ::-1])
+            k, (co, ci) = tuple(shape[:-2]), shape[-2:]
+            flip = (slice(None, None, -1),) * len(k)
+            return np.ascontiguousarray(np.swapaxes(flat.reshape(k + (ci, co)), -1, -2)[flip])
         return flat.reshape(shape).copy()
 
     def grads_host(self):
@@ -206,8 +211,6 @@ class Engine:
         if plan.ndims == 3:
             if tuple(plan.f_size) != (3, 3, 3) or tuple(plan.m_pool)[0] != 1 or tuple(plan.m_pool)[1:] != (2, 2):
                 raise NotImplementedError('3-D graphs: F_SIZE (3,3,3) and M_POOL (1,2,2) (the reference template) are built')
-            if any(st.transpose for st in plan.stages):
-                raise NotImplementedError('3-D graphs: Conv3DTranspose (USE_UPSAMPLE false) is not built')
         elif tuple(plan.f_size) != (3, 3) or tuple(plan.m_pool) != (2, 2):
             raise NotImplementedError('2-D graphs: F_SIZE (3,3) and M_POOL (2,2) are built')
         self.n = n = self.batch * self.depth

@@ -328,6 +328,53 @@ def conv2d_transpose_same_bwd(x, w, dy, stride=2):
     return dx, dw, dy.reshape(-1, co).sum(0)
 
 
+def conv3d_transpose_same_fwd(x, w, b=None, strides=(1, 2, 2)):
+    """Conv3DTranspose(k, strides=M_POOL, padding='same') (KerasLayers.py:762-765 with ndims = 3; the 3-D template pools (1, 2, 2)):
+    per axis the input-gradient of a SAME stride-s conv, out[s*i + k] += in[i] . W[k] cropped to s*N from pad_before =
+    max((N-1)*s + k - s*N, 0) // 2 (1 for k=3, s=1; 0 for k=3, s=2).  Kernel DHWOI, x NDHWC."""
+    kd, kh, kw, co, ci = w.shape
+    n, d, h, wd, _ = x.shape
+    ks, dims = (kd, kh, kw), (d, h, wd)
+    outs = [dims[a] * strides[a] for a in range(3)]
+    fulls = [(dims[a] - 1) * strides[a] + ks[a] for a in range(3)]
+    pads = [max(fulls[a] - outs[a], 0) // 2 for a in range(3)]
+    full = np.zeros((n,) + tuple(fulls) + (co,), dtype=np.result_type(x, w))
+    sd, sh, sw = strides
+    for a in range(kd):
+        for i in range(kh):
+            for j in range(kw):
+                full[:, a:a + (d - 1) * sd + 1:sd, i:i + (h - 1) * sh + 1:sh, j:j + (wd - 1) * sw + 1:sw, :] += x @ w[a, i, j].T
+    y = np.zeros((n,) + tuple(outs) + (co,), dtype=full.dtype)
+    src = full[:, pads[0]:pads[0] + outs[0], pads[1]:pads[1] + outs[1], pads[2]:pads[2] + outs[2], :]
+    y[:, :src.shape[1], :src.shape[2], :src.shape[3], :] = src
+    if b is not None:
+        y += b
+    return y
+
+
+def conv3d_transpose_same_bwd(x, w, dy, strides=(1, 2, 2)):
+    kd, kh, kw, co, ci = w.shape
+    n, d, h, wd, _ = x.shape
+    ks, dims = (kd, kh, kw), (d, h, wd)
+    outs = [dims[a] * strides[a] for a in range(3)]
+    fulls = [(dims[a] - 1) * strides[a] + ks[a] for a in range(3)]
+    pads = [max(fulls[a] - outs[a], 0) // 2 for a in range(3)]
+    ext = [min(outs[a], fulls[a] - pads[a]) for a in range(3)]
+    dfull = np.zeros((n,) + tuple(fulls) + (co,), dtype=np.result_type(x, w, dy))
+    dfull[:, pads[0]:pads[0] + ext[0], pads[1]:pads[1] + ext[1], pads[2]:pads[2] + ext[2], :] = dy[:, :ext[0], :ext[1], :ext[2], :]
+    dx = np.zeros_like(x, dtype=dfull.dtype)
+    dw = np.zeros_like(w, dtype=dfull.dtype)
+    x2 = x.reshape(-1, ci)
+    sd, sh, sw = strides
+    for a in range(kd):
+        for i in range(kh):
+            for j in range(kw):
+                g = dfull[:, a:a + (d - 1) * sd + 1:sd, i:i + (h - 1) * sh + 1:sh, j:j + (wd - 1) * sw + 1:sw, :]
+                dx += g @ w[a, i, j]
+                dw[a, i, j] = g.reshape(-1, co).T @ x2
+    return dx, dw, dy.reshape(-1, co).sum(0)
+
+
 def act_fwd(x, kind):
     if kind in (None, 'linear'):
         return x
@@ -714,8 +761,6 @@ class OracleUNet:
         self.opt_m = None
         self.opt_v = None
         self.ndims = len(self.layers[0]['shape']) - 1
-        if self.ndims == 3 and any(l['type'] == 'Conv3DTranspose' for l in self.layers):
-            raise NotImplementedError('oracle: Conv3DTranspose (USE_UPSAMPLE false on 3-D graphs) is not restated')
 
     # -- forward ---------------------------------------------------------------------------
     def forward(self, x, training=False, dropout_masks=None):
@@ -740,6 +785,9 @@ class OracleUNet:
             elif ty == 'Conv2DTranspose':
                 w, b = self.params[name]
                 out = act_fwd(conv2d_transpose_same_fwd(ins[0], w, b, l['strides'][0]), l['activation'])
+            elif ty == 'Conv3DTranspose':
+                w, b = self.params[name]
+                out = act_fwd(conv3d_transpose_same_fwd(ins[0], w, b, tuple(l['strides'])), l['activation'])
             elif ty == 'Activation':
                 out = act_fwd(ins[0], l['activation'])
             elif ty == 'BatchNormalization':
@@ -817,6 +865,12 @@ class OracleUNet:
                 w, _ = self.params[name]
                 dpre = act_bwd(t[name], dy, l['activation'])
                 dx, dw, db = conv2d_transpose_same_bwd(t[ins[0]], w, dpre, l['strides'][0])
+                grads[name] = [dw, db]
+                acc(ins[0], dx)
+            elif ty == 'Conv3DTranspose':
+                w, _ = self.params[name]
+                dpre = act_bwd(t[name], dy, l['activation'])
+                dx, dw, db = conv3d_transpose_same_bwd(t[ins[0]], w, dpre, tuple(l['strides']))
                 grads[name] = [dw, db]
                 acc(ins[0], dx)
             elif ty == 'Activation':

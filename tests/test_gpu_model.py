@@ -75,6 +75,7 @@ VARIANTS = [
     dict(USE_UPSAMPLE=False),                       # Conv2DTranspose decoder (KerasLayers.py:761-765)
     dict(IMG_CHANNELS=3),                           # Input((*dim, IMG_CHANNELS)), Unets.py:77
     dict(DEPTH=5, DIM=[64, 64], FILTERS=4, RVIP_PRECISION='fp32'),   # cfg 4's depth (bottleneck 2x2), fp32: F % 4 == 0
+    dict(DIM=[4, 32, 32], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32, USE_UPSAMPLE=False),   # Conv3DTranspose(3, strides (1, 2, 2)) decoder
     dict(DIM=[4, 32, 32], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32),   # cfg 5's graph (Conv3D, MaxPooling3D, UpSampling3D); 3-D runs on the LDS-DMA kernels only: concat halves must be whole 128-byte rows (F % 32 in fp32)
 ]
 

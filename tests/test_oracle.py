@@ -97,6 +97,27 @@ def test_conv_transpose_same_vs_torch_and_adjoint():
     assert abs(lhs - rhs) < 1e-9 * max(1, abs(lhs))
 
 
+def test_conv3d_transpose_same_vs_torch():
+    """Conv3DTranspose(3, strides (1, 2, 2), 'same'): depth like a stride-1 SAME conv with the flipped kernel, in-plane like the 2-D op."""
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 3, 5, 4, 3)); w = rng.standard_normal((3, 3, 3, 6, 3)); b = rng.standard_normal(6)
+    y = O.conv3d_transpose_same_fwd(x, w, b, (1, 2, 2))
+    assert y.shape == (2, 3, 10, 8, 6)
+    xt, wt = _t(x).requires_grad_(), _t(w).requires_grad_()
+    full = torch.nn.functional.conv_transpose3d(xt.permute(0, 4, 1, 2, 3), wt.permute(4, 3, 0, 1, 2), _t(b), stride=(1, 2, 2))
+    yt = full[:, :, 1:4, :10, :8].permute(0, 2, 3, 4, 1)
+    np.testing.assert_allclose(y, yt.detach().numpy(), atol=1e-12)
+    dy = rng.standard_normal(y.shape)
+    yt.backward(_t(dy))
+    dx, dw, db = O.conv3d_transpose_same_bwd(x, w, dy, (1, 2, 2))
+    np.testing.assert_allclose(dx, xt.grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(dw, wt.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(db, dy.reshape(-1, 6).sum(0), atol=1e-11)
+    # one slice, kernel with only the middle depth tap: the 2-D op
+    w1 = np.zeros_like(w); w1[1] = w[1]
+    np.testing.assert_allclose(O.conv3d_transpose_same_fwd(x[:, :1], w1, b, (1, 2, 2))[:, 0], O.conv2d_transpose_same_fwd(x[:, 0], w[1], b), atol=1e-12)
+
+
 def test_bn_pool_upsample_vs_torch():
     rng = np.random.default_rng(2)
     x = rng.standard_normal((3, 8, 6, 5)); g = rng.standard_normal(5); b = rng.standard_normal(5)
