@@ -717,19 +717,16 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int ESZ = (int)sizeof(T);
     constexpr int ST = NHROWS * CIB * ESZ + 256 * COB * ESZ;
-#ifdef RVIP_WG_TWO_STAGES
-    constexpr int NST = 2;
-#else
     constexpr int NST = (WS && 3 * ST <= 160 * 1024) ? 3 : 2;
-#endif
     // the wave-specialised kernel folds the pixel-split copies of a block through LDS: 4 x [9][32][32] floats
     constexpr int FOLD = (WS && (ESZ == 4 || (CIB / 32) * (COB / 32) < 4)) ? 4 * 9 * 32 * 32 * 4 : 0;
     constexpr int lds = NST * ST > FOLD ? NST * ST : FOLD;
     static_assert(lds <= 160 * 1024, "LDS");
     static std::atomic<bool> attr_done{false};      // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!attr_done) {
-        hipError_t e = WS ? hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma<T, TW, CIB, COB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e;
+        if constexpr (WS) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma<T, TW, CIB, COB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
         attr_done = true;
     }
@@ -739,14 +736,10 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
     return check_launch();
 }
 
-// RVIP_WGRAD=v2 keeps the 4-wave kernel (A/B measurements); default: the wave-specialised one for bf16
+// the wave-specialised kernel for the 16-bit types, the four-wave LDS-DMA kernel for f32
 template <typename T, int TW, int CIB, int COB>
 static int launch_wgrad2(const WgArgs2& a, hipStream_t s) {
-    static const bool v2 = [] { const char* e = getenv("RVIP_WGRAD"); return e && e[0] == 'v' && e[1] == '2'; }();
-    if constexpr (sizeof(T) == 2) {
-        if (!v2) return launch_wgrad2x<T, TW, CIB, COB, true>(a, s);
-    }
-    return launch_wgrad2x<T, TW, CIB, COB, false>(a, s);
+    return launch_wgrad2x<T, TW, CIB, COB, sizeof(T) == 2>(a, s);
 }
 
 
@@ -799,12 +792,11 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     int rc = RVIP_OK;
     const int depth = d->depth > 0 ? d->depth : 1, kd = d->kd > 0 ? d->kd : 1;
     if ((kd != 1 && kd != 3) || d->n % depth) return RVIP_EINVAL;
-    static const bool force_v1 = [] { const char* e = getenv("RVIP_WGRAD"); return e && e[0] == 'v' && e[1] == '1'; }();
     const long long esz = RVIP_ESZ(d->dtype);
     const long long x0b = (long long)a.n * (a.h >> a.up0) * (a.w >> a.up0) * a.c0 * esz, x1b = (long long)a.n * a.h * a.w * a.c1 * esz;
     const long long dyb = (long long)a.n * a.h * a.w * a.cout * esz;
     const Wg2Geom g2 = wgrad2_geometry(a.n, a.h, a.w, a.c0, a.c1, a.cout, d->dtype);
-    if ((!force_v1 || kd > 1) && g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) {
+    if (g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) {
         WgArgs2 b;
         b.x0 = a.x0; b.x1 = a.x1; b.dy = a.dy; b.slab = a.slab;
         b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.dy_bytes = (unsigned)dyb;
@@ -853,14 +845,12 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
 // number of split-K slabs rvip_conv3x3_wgrad writes for this shape (rows of the deferred fold; 0 = invalid descriptor)
 extern "C" int rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d) {
     if (!d || !RVIP_DT_OK(d->dtype) || d->n <= 0 || d->h <= 0 || d->w <= 0) return 0;
-    static const bool force_v1 = [] { const char* e = getenv("RVIP_WGRAD"); return e && e[0] == 'v' && e[1] == '1'; }();
     const int up = d->up0 ? 1 : 0;
     const long long esz = RVIP_ESZ(d->dtype);
     const long long x0b = (long long)d->n * (d->h >> up) * (d->w >> up) * d->c0 * esz, x1b = (long long)d->n * d->h * d->w * d->c1 * esz;
     const long long dyb = (long long)d->n * d->h * d->w * d->cout * esz;
-    const int kd = d->kd > 0 ? d->kd : 1;
     const Wg2Geom g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype);
-    if ((!force_v1 || kd > 1) && g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) return g2.nsplit;
+    if (g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) return g2.nsplit;
     int tw, tx, ty, nt, ns;
     wgrad_geometry(d->n, d->h, d->w, d->c0 + d->c1, d->cout, tw, tx, ty, nt, ns);
     return ns;
