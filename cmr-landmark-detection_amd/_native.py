@@ -57,7 +57,8 @@ class ApplyDesc(C.Structure):
                 ('act', C.c_int32),
                 ('drop_rate', C.c_float), ('mask', vp), ('state', vp), ('layer_id', C.c_int32),
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('c', C.c_int32),
-                ('dtype', C.c_int32)]
+                ('dtype', C.c_int32),
+                ('argmax', vp)]
 
 
 class BnBwdDesc(C.Structure):
@@ -71,7 +72,8 @@ class BnBwdDesc(C.Structure):
                 ('rows', C.c_longlong), ('c', C.c_int32),
                 ('dtype', C.c_int32),
                 ('workspace', vp), ('workspace_bytes', C.c_size_t),
-                ('bias_rows', vp), ('bias_rows_bytes', C.c_size_t)]
+                ('bias_rows', vp), ('bias_rows_bytes', C.c_size_t),
+                ('dpooled', vp), ('argmax', vp), ('h', C.c_int32), ('w', C.c_int32)]
 
 
 class FoldEntry(C.Structure):
@@ -110,6 +112,7 @@ SIGNATURES = {
                                       vp, vp, vp, vp, vp, C.c_size_t, vp]),
     'rvip_bn_infer_coeffs': (C.c_int, [vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp]),
     'rvip_bn_apply': (C.c_int, [C.POINTER(ApplyDesc), vp]),
+    'rvip_bn_apply_argmax_ok': (C.c_int, [C.c_int, C.c_int]),
     'rvip_bn_bwd_reduce': (C.c_int, [C.POINTER(BnBwdDesc), vp]),
     'rvip_bn_bwd_apply': (C.c_int, [C.POINTER(BnBwdDesc), vp]),
     'rvip_maxpool2x2_bwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -308,6 +308,7 @@ __global__ void bn_infer_coeffs_kernel(const float* gamma, const float* beta, co
 // ------------------------------------------------------------------------------------------------
 struct ApplyArgs {
     const unsigned char* z; unsigned char* y; unsigned char* pooled;
+    uint16_t* argmax;          // pooled + column-split kernel only: [windows][C / VE], 2 bits per channel = 2 * row + col of the first maximum
     const float* scale; const float* shift;
     int act; float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
     int n, h, w, c;
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(ApplyArgs a, int cg
         for (int u = 0; u < UNR; ++u) {
             if (!ok[u]) continue;
             float best[VE];
+            unsigned rbits = 0;                                                       // bit e: the lane's column maximum of channel e sits in row 1
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 apply_xform<T, VE, ACT, DROP>(a, e0[u][r], sc, sh, key, v[u][r]);
@@ -455,12 +457,27 @@ __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(ApplyArgs a, int cg
 #pragma unroll
                 for (int e = 0; e < VE; ++e) {
                     const float vr = Vec<T>::round(v[u][r][e]);                     // pool what was stored
-                    best[e] = (r == 0 || vr > best[e]) ? vr : best[e];
+                    const bool take = r == 0 || vr > best[e];                       // first maximum wins
+                    best[e] = take ? vr : best[e];
+                    if (r == 1 && take) rbits |= 1u << e;
                 }
             }
+            // window position of the first maximum in row-major order (2 * row + col), as rvip_maxpool2x2_bwd finds it from y: this lane
+            // holds column px; the other column's candidate wins a tie only if its position is smaller
+            const unsigned orbits = (unsigned)__shfl_xor((int)rbits, cg);
+            unsigned arg = 0;
 #pragma unroll
-            for (int e = 0; e < VE; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], cg));
-            if (px == 0) Vec<T>::store(a.pooled + ((size_t)qi[u] * a.c + cv * VE) * sizeof(T), best);
+            for (int e = 0; e < VE; ++e) {
+                const float ob = __shfl_xor(best[e], cg);
+                const int mine = 2 * (int)((rbits >> e) & 1u) + px, theirs = 2 * (int)((orbits >> e) & 1u) + (px ^ 1);
+                const bool keep = best[e] > ob || (best[e] == ob && mine < theirs);
+                arg |= (unsigned)(keep ? mine : theirs) << (2 * e);
+                best[e] = fmaxf(best[e], ob);
+            }
+            if (px == 0) {
+                Vec<T>::store(a.pooled + ((size_t)qi[u] * a.c + cv * VE) * sizeof(T), best);
+                if (a.argmax) a.argmax[(size_t)qi[u] * cg + cv] = (uint16_t)arg;
+            }
         }
     }
 }
@@ -476,6 +493,10 @@ __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(ApplyArgs a, int cg
 #endif
 struct BnBwdArgs {
     const unsigned char* dy; const unsigned char* z; unsigned char* dz;
+    // MaxPooling2D backward folded into both passes (dp != NULL): the gradient reaching the stage output is
+    // round(route(dp -> argmax position of the 2x2 window) + dy), dy = the skip-connection gradient or NULL
+    const unsigned char* dp; const uint16_t* argmax; int h, w;
+    int lw, lh;                                  // log2(w), log2(h) when both are powers of two (shift / mask pixel coordinates), else -1
     const float* mean; const float* invstd; const float* scale; const float* shift; const float* coef;
     int act, act_after_bn, has_bn;
     float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
@@ -508,7 +529,43 @@ __device__ __forceinline__ void xform_g(const BnBwdArgs& a, size_t e0, int cbase
     }
 }
 
-template <typename T, int ACT = -1, int DROP = -1, int AFTER = -1>
+// Incoming gradient of pixel row rr, channel vector cgi: dy, or -- pooled stage (PARG) -- what rvip_maxpool2x2_bwd would have stored.
+// Two phases so that a thread's loads of all its rows are in flight together: gy_issue only loads (no branch: the window index
+// is clamped, validity is a flag), gy_finish routes.  PARG: compile-time (0 / 1) in the specialised instantiations, -1 = a.dp.
+template <int VE> struct GyRaw { float add[VE]; float d[VE]; unsigned arg, pos; bool sel; };
+template <typename T, int VE, int PARG, bool NT>
+__device__ __forceinline__ void gy_issue(const BnBwdArgs& a, long long rr, int cgi, int cg, size_t e0, GyRaw<VE>& q) {
+    const bool parg = PARG < 0 ? a.dp != nullptr : PARG > 0;
+    if (!parg) {
+        if constexpr (NT) Vec<T>::load_nt(a.dy + e0 * sizeof(T), q.add);
+        else Vec<T>::load(a.dy + e0 * sizeof(T), q.add);
+        return;
+    }
+    int x, y; long long img;
+    if (a.lw >= 0) { x = (int)(rr & (a.w - 1)); y = (int)((rr >> a.lw) & (a.h - 1)); img = rr >> (a.lw + a.lh); }
+    else split_xy(rr, a.w, a.h, x, y, img);
+    const int oh = a.h >> 1, ow = a.w >> 1;
+    if (a.dy) Vec<T>::load_nt(a.dy + e0 * sizeof(T), q.add);
+    else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) q.add[e] = 0.f;
+    }
+    const int wy = (y >> 1) < oh ? (y >> 1) : oh - 1, wx = (x >> 1) < ow ? (x >> 1) : ow - 1;      // odd extents: the last row / column has no window
+    q.sel = (y >> 1) < oh && (x >> 1) < ow;
+    const size_t w = ((size_t)img * oh + wy) * ow + wx;
+    Vec<T>::load(a.dp + (w * a.c + cgi * VE) * sizeof(T), q.d);
+    q.arg = a.argmax[w * cg + cgi];
+    q.pos = 2u * (y & 1) + (x & 1);
+}
+template <typename T, int VE, int PARG>
+__device__ __forceinline__ void gy_finish(const BnBwdArgs& a, const GyRaw<VE>& q, float (&g)[VE]) {
+    const bool parg = PARG < 0 ? a.dp != nullptr : PARG > 0;
+#pragma unroll
+    for (int e = 0; e < VE; ++e)
+        g[e] = parg ? Vec<T>::round(q.add[e] + ((q.sel && ((q.arg >> (2 * e)) & 3u) == q.pos) ? q.d[e] : 0.f)) : q.add[e];
+}
+
+template <typename T, int ACT = -1, int DROP = -1, int AFTER = -1, int PARG = -1>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
@@ -526,16 +583,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom
     if (active) {
         for (long long r = r0 + prow; r < r1; r += RVIP_BWD_U * gm.rpi) {
             float z[RVIP_BWD_U][VE], g[RVIP_BWD_U][VE]; size_t e0[RVIP_BWD_U]; bool ok[RVIP_BWD_U];
+            GyRaw<VE> raw[RVIP_BWD_U];
 #pragma unroll
             for (int u = 0; u < RVIP_BWD_U; ++u) {
                 const long long rr = r + u * gm.rpi;
                 ok[u] = rr < r1;
                 e0[u] = (size_t)rr * a.c + cgi * VE;
-                if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); Vec<T>::load(a.dy + e0[u] * sizeof(T), g[u]); }
+                if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); gy_issue<T, VE, PARG, false>(a, rr, cgi, gm.cg, e0[u], raw[u]); }
             }
 #pragma unroll
             for (int u = 0; u < RVIP_BWD_U; ++u) {
                 if (!ok[u]) continue;
+                gy_finish<T, VE, PARG>(a, raw[u], g[u]);
                 xform_g<T, VE, ACT, DROP, AFTER>(a, e0[u], cgi * VE, key, z[u], g[u]);
 #pragma unroll
                 for (int e = 0; e < VE; ++e) { part[0][e] += g[u][e]; part[1][e] = fmaf(g[u][e], (z[u][e] - mu[e]) * is[e], part[1][e]); }
@@ -560,7 +619,7 @@ struct PostBnBwd {
     }
 };
 
-template <typename T, int ACT = -1, int DROP = -1, int AFTER = -1>
+template <typename T, int ACT = -1, int DROP = -1, int AFTER = -1, int PARG = -1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
@@ -580,6 +639,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
     if (active) {
         for (long long r = r0 + prow; r < r1; r += RVIP_BWD_U_APPLY * gm.rpi) {
             float z[RVIP_BWD_U_APPLY][VE], g[RVIP_BWD_U_APPLY][VE]; size_t e0[RVIP_BWD_U_APPLY]; bool ok[RVIP_BWD_U_APPLY];
+            GyRaw<VE> raw[RVIP_BWD_U_APPLY];
 #pragma unroll
             for (int u = 0; u < RVIP_BWD_U_APPLY; ++u) {
                 const long long rr = r + u * gm.rpi;
@@ -587,11 +647,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
                 e0[u] = (size_t)rr * a.c + cgi * VE;
                 // last reader of both tensors: non-temporal loads leave the cache to dz, which the weight / data gradient
                 // kernels read next (measured: -0.05 ms per step, all of it in those kernels)
-                if (ok[u]) { Vec<T>::load_nt(a.z + e0[u] * sizeof(T), z[u]); Vec<T>::load_nt(a.dy + e0[u] * sizeof(T), g[u]); }
+                if (ok[u]) { Vec<T>::load_nt(a.z + e0[u] * sizeof(T), z[u]); gy_issue<T, VE, PARG, true>(a, rr, cgi, gm.cg, e0[u], raw[u]); }
             }
 #pragma unroll
             for (int u = 0; u < RVIP_BWD_U_APPLY; ++u) {
                 if (!ok[u]) continue;
+                gy_finish<T, VE, PARG>(a, raw[u], g[u]);
                 xform_g<T, VE, ACT, DROP, AFTER>(a, e0[u], cgi * VE, key, z[u], g[u]);
                 float d[VE];
 #pragma unroll
@@ -1276,6 +1337,7 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     a.inv_keep = drop ? 1.f / (1.f - d->drop_rate) : 1.f; a.thr = dropout_thr(d->drop_rate);
     a.mask = d->mask; a.state = d->state; a.layer_id = d->layer_id; a.drop = drop;
     a.n = d->n; a.h = d->h; a.w = d->w; a.c = d->c;
+    a.argmax = nullptr;
     const int cg = d->c / ve;
     if (cg > 256) return RVIP_EINVAL;
     const int rpi = 256 / cg;
@@ -1291,7 +1353,9 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     // specialised instantiations of the reference's default graph (conv + ReLU -> BN: no activation in this pass): 1 = no dropout, 2 = stream
     static const bool spec = [] { const char* e = getenv("RVIP_SPECIALISE"); return !(e && e[0] == '0'); }();
     const int fast = (spec && d->act == RVIP_ACT_NONE) ? (!drop ? 1 : (!d->mask ? 2 : 0)) : 0;
+    if (d->argmax && !(d->pooled && pool2 && cg <= 32 && (cg & (cg - 1)) == 0)) return RVIP_EUNSUPPORTED;   // rvip_bn_apply_argmax_ok
     if (d->pooled && pool2 && cg <= 32 && (cg & (cg - 1)) == 0) {        // column-split form: both lanes of a window in one wave
+        a.argmax = d->argmax;
         const int wpi = 128 / cg;
         const long long ng2 = cdiv(units, wpi);
         long long nb2 = cdiv(ng2, RVIP_POOL2_UNR);
@@ -1321,7 +1385,11 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
 }
 
 static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
-    if (!d || !d->dy || !d->z || !RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
+    if (!d || (!d->dy && !d->dpooled) || !d->z || !RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
+    if (d->dpooled && (!d->argmax || d->h <= 0 || d->w <= 0 || d->rows % ((long long)d->h * d->w))) return RVIP_EINVAL;
+    a.dp = (const unsigned char*)d->dpooled; a.argmax = d->argmax; a.h = d->h; a.w = d->w;
+    a.lw = a.lh = -1;
+    if (d->dpooled && !(d->w & (d->w - 1)) && !(d->h & (d->h - 1))) { a.lw = __builtin_ctz(d->w); a.lh = __builtin_ctz(d->h); }
     if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g)) return RVIP_EINVAL;
     if (d->drop_rate < 0.f || d->drop_rate >= 1.f) return RVIP_EINVAL;
     const int drop = d->drop_rate > 0.f;
@@ -1344,6 +1412,15 @@ static int bnbwd_fast(const BnBwdArgs& a) {
     return !a.drop ? 1 : (!a.mask ? 2 : 0);
 }
 
+// 1 if rvip_bn_apply writes the window argmax for this pooled shape (the column-split kernel runs): the caller may then drop
+// rvip_maxpool2x2_bwd and hand dpooled / argmax to the two BN-backward passes
+extern "C" int rvip_bn_apply_argmax_ok(int c, int dtype) {
+    if (!RVIP_DT_OK(dtype) || c <= 0 || c % RVIP_VE(dtype)) return 0;
+    static const bool pool2 = [] { const char* e = getenv("RVIP_POOL_SPLIT"); return !(e && e[0] == '0'); }();
+    const int cg = c / RVIP_VE(dtype);
+    return (pool2 && cg <= 32 && (cg & (cg - 1)) == 0) ? 1 : 0;
+}
+
 extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     (void)hipGetLastError();
     BnBwdArgs a; RedGeom g;
@@ -1356,8 +1433,9 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     const int fast = bnbwd_fast(a);
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
-        if (fast == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, RVIP_ACT_RELU, 0, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-        else if (fast == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, RVIP_ACT_RELU, 1, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        if (fast == 1 && a.dp) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, RVIP_ACT_RELU, 0, 0, 1>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else if (fast == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, RVIP_ACT_RELU, 0, 0, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else if (fast == 2 && !a.dp) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, RVIP_ACT_RELU, 1, 0, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
         return 0;
     });
@@ -1381,8 +1459,9 @@ extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
     const int fast = bnbwd_fast(a);
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
-        if (fast == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RVIP_ACT_RELU, 0, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
-        else if (fast == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RVIP_ACT_RELU, 1, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        if (fast == 1 && a.dp) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RVIP_ACT_RELU, 0, 0, 1>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else if (fast == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RVIP_ACT_RELU, 0, 0, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
+        else if (fast == 2 && !a.dp) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RVIP_ACT_RELU, 1, 0, 0>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
         return 0;
     });
@@ -1503,7 +1582,7 @@ extern "C" int rvip_bn_apply_head(const rvip_apply_desc* d, const float* head_w,
     if (cg > 64 || (cg & (cg - 1))) return RVIP_EUNSUPPORTED;
     if (y_true && (!sums || !workspace)) return RVIP_EINVAL;
     ApplyArgs a;
-    a.z = (const unsigned char*)d->z; a.y = nullptr; a.pooled = nullptr;
+    a.z = (const unsigned char*)d->z; a.y = nullptr; a.pooled = nullptr; a.argmax = nullptr;
     a.scale = d->scale; a.shift = d->shift; a.act = d->act;
     a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;
     a.n = d->n; a.h = d->h; a.w = d->w; a.c = d->c;
@@ -1543,6 +1622,7 @@ extern "C" int rvip_bn_bwd_reduce_head(const rvip_bnbwd_desc* d, const float* he
     if (d->workspace_bytes < need) return RVIP_EWORKSPACE;
     BnBwdArgs a;
     a.dy = nullptr; a.z = (const unsigned char*)d->z; a.dz = (unsigned char*)d->dz;
+    a.dp = nullptr; a.argmax = nullptr; a.h = a.w = 0; a.lw = a.lh = -1;
     a.mean = d->mean; a.invstd = d->invstd; a.scale = d->scale; a.shift = d->shift; a.coef = d->coef;
     a.act = d->act; a.act_after_bn = d->act_after_bn; a.has_bn = 1;
     a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;
@@ -1577,6 +1657,7 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     if ((defer ? d->bias_rows_bytes : d->workspace_bytes) < (size_t)g.nblk * d->c * sizeof(float) || (!defer && !d->workspace)) return RVIP_EWORKSPACE;
     BnBwdArgs a;
     a.dy = nullptr; a.z = (const unsigned char*)d->z; a.dz = (unsigned char*)d->dz;
+    a.dp = nullptr; a.argmax = nullptr; a.h = a.w = 0; a.lw = a.lh = -1;
     a.mean = d->mean; a.invstd = d->invstd; a.scale = d->scale; a.shift = d->shift; a.coef = d->coef;
     a.act = d->act; a.act_after_bn = d->act_after_bn; a.has_bn = d->gamma != nullptr;
     a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;

@@ -302,6 +302,13 @@ class Engine:
         self.ws_bytes = need
         self.ws_wg = torch.empty(need_wg // 4 + 64, **f32)
         self.ws_wg_bytes = need_wg
+        # 2-bit window argmax of the pooled stages (written by the pooled rvip_bn_apply, read by the stage's BN-backward passes
+        # in place of a materialised MaxPooling gradient); stages the column-split kernel does not cover keep rvip_maxpool2x2_bwd
+        self.argmax = {}
+        if os.environ.get('RVIP_FUSE_POOLBWD', '1') != '0':
+            for st in plan.stages:
+                if st.pool and L.rvip_bn_apply_argmax_ok(st.cout, P.dt):
+                    self.argmax[st.conv] = torch.zeros(n * (st.h // 2) * (st.w // 2) * (st.cout // ve), dtype=torch.int16, device=dev)
         self._graphs, self._eager_steps, self.launch_mode = None, 0, 'eager'
         self.pin_x = None
         self._build_lists()
@@ -416,6 +423,8 @@ class Engine:
                         if st.drop[0] in self.masks:
                             a.mask = self.masks[st.drop[0]].data_ptr()
                     a.n, a.h, a.w, a.c, a.dtype = n, st.h, st.w, st.cout, dt
+                    if training and st.pool and st.conv in self.argmax:
+                        a.argmax = self.argmax[st.conv].data_ptr()        # MaxPooling backward folds into the BN-backward passes
                     self._keep.append(a)
                     if training and st is last and self.fuse_head:
                         last_apply = a                      # consumed by rvip_bn_apply_head below
@@ -500,7 +509,8 @@ class Engine:
             first = st.src0 == 'input_1'
             bwd.label = '%s %dx%dx%d->%d tensor=%.1fMB' % (st.conv, st.h, st.w, st.cin, st.cout, rows * st.cout * esz / 1e6)
             gy, dz, z = self.grd[st.y], self.dz[st.z], self.act[st.z]
-            if st.pool:
+            fuse_pool = st.pool and st.conv in self.argmax
+            if st.pool and not fuse_pool:
                 add = self.gskip.get(st.y)
                 bwd.append((L.rvip_maxpool2x2_bwd, (_ptr(self.act[st.y]), _ptr(self.grd[st.pooled]),
                                                     _ptr(add) if add is not None else None, _ptr(gy), n, st.h, st.w, st.cout, dt)))
@@ -508,6 +518,10 @@ class Engine:
                 raise NotImplementedError('skip tensor without pooling')
             b = N.BnBwdDesc()
             b.dy, b.z, b.dz = gy.data_ptr(), z.data_ptr(), dz.data_ptr()
+            if fuse_pool:                      # gy is never materialised: (pooled gradient, window argmax, skip gradient) instead
+                add = self.gskip.get(st.y)
+                b.dy = add.data_ptr() if add is not None else None
+                b.dpooled, b.argmax, b.h, b.w = self.grd[st.pooled].data_ptr(), self.argmax[st.conv].data_ptr(), st.h, st.w
             if st.bn:
                 b.gamma = P.p(st.bn, 'gamma').value
                 b.mean, b.invstd = self._bn(st, 'mean').value, self._bn(st, 'invstd').value

@@ -231,8 +231,13 @@ typedef struct rvip_apply_desc {
     float        drop_rate; const uint8_t* mask; const uint32_t* state; int32_t layer_id;
     int32_t      n, h, w, c;
     int32_t      dtype;
+    /* pooled != NULL and rvip_bn_apply_argmax_ok(c, dtype): optional [n][h/2][w/2][C/VE] words, 2 bits per channel = position
+     * (2*row + col) of the FIRST maximum of the 2x2 window of y, i.e. what rvip_maxpool2x2_bwd would find; lets the BN-backward
+     * passes of the stage take (dpooled, argmax, skip gradient) instead of a materialised gradient */
+    uint16_t*    argmax;
 } rvip_apply_desc;
 int rvip_bn_apply(const rvip_apply_desc* d, void* stream);
+int rvip_bn_apply_argmax_ok(int c, int dtype);
 
 /* Backward of conv -> [act] -> BN -> [act] -> dropout (autodiff of conv_layer_fn + Dropout).
  * Inputs: dy (grad w.r.t. the dropped-out BN output), z (BN input as stored by the forward) and, only
@@ -257,6 +262,10 @@ typedef struct rvip_bnbwd_desc {
     /* bias_rows != NULL: rvip_bn_bwd_apply leaves the rvip_bn_bwd_rows(rows, c, dtype) partial rows [rows][C] of the
      * bias gradient there instead of folding them into dbias (fold later with rvip_fold_rows_batch, wide = 0). */
     float*       bias_rows; size_t bias_rows_bytes;
+    /* dpooled != NULL: MaxPooling2D backward folded into both stages -- the gradient of pixel (y, x) is
+     * round(dy + (argmax of its window == 2*(y&1) + (x&1) ? dpooled : 0)), dy = the skip-connection gradient (may be NULL),
+     * exactly the tensor rvip_maxpool2x2_bwd would have stored; rows = n*h*w. */
+    const void*  dpooled; const uint16_t* argmax; int32_t h, w;
 } rvip_bnbwd_desc;
 int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);

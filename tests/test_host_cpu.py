@@ -102,7 +102,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(rvip._native.SIGNATURES), declared ^ set(rvip._native.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.rvip_abi_version() == 3 and b'gfx950' in lib.rvip_build_info()
+    assert lib.rvip_abi_version() == 4 and b'gfx950' in lib.rvip_build_info()
     assert lib.rvip_reduce_workspace(1000, 64) > 0 and lib.rvip_conv3x3_wgrad_workspace(2, 32, 32, 8, 8) > 0
 
 
