@@ -1386,7 +1386,7 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
 
 static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
     if (!d || (!d->dy && !d->dpooled) || !d->z || !RVIP_DT_OK(d->dtype)) return RVIP_EINVAL;
-    if (d->dpooled && (!d->argmax || d->h <= 0 || d->w <= 0 || d->rows % ((long long)d->h * d->w))) return RVIP_EINVAL;
+    if (d->dpooled && (!d->argmax || d->h <= 0 || d->w <= 0 || ((d->h | d->w) & 1) || d->rows % ((long long)d->h * d->w))) return RVIP_EINVAL;
     a.dp = (const unsigned char*)d->dpooled; a.argmax = d->argmax; a.h = d->h; a.w = d->w;
     a.lw = a.lh = -1;
     if (d->dpooled && !(d->w & (d->w - 1)) && !(d->h & (d->h - 1))) { a.lw = __builtin_ctz(d->w); a.lh = __builtin_ctz(d->h); }

@@ -564,6 +564,81 @@ def test_batchnorm_dropout_pool_forward_backward(dtype, act_after):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(2, 12, 20, 16), (2, 16, 32, 32), (1, 6, 10, 8)], ids=['12x20', '16x32', '6x10'])
+@pytest.mark.parametrize('rate', [0.0, 0.4])
+def test_window_argmax_replaces_the_maxpool_backward_pass(dtype, shape, rate):
+    """rvip_bn_apply(argmax) + rvip_bn_bwd_reduce / _apply(dpooled, argmax, skip gradient) must give, bit for bit, what
+    rvip_maxpool2x2_bwd + the plain passes give: ties (post-ReLU zeros become one constant after BN) go to the first maximum in
+    row-major window order; power-of-two extents take the shift path for the pixel coordinates, the others the division."""
+    n, h, w, c = shape
+    rows = n * h * w
+    rng = np.random.default_rng(31)
+    z = rnd(np.maximum(rng.standard_normal((n, h, w, c)) * 1.5 - 0.4, 0), dtype)          # ~60 % exact zeros
+    gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    L = N.lib()
+    assert L.rvip_bn_apply_argmax_ok(c, ndt(dtype)) == 1
+    wsb = L.rvip_reduce_workspace(rows, 16 * c)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    zd, gd, bd = up(z, dtype), f32(gamma), f32(beta)
+    mm, mv = f32(np.zeros(c)), f32(np.ones(c))
+    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(4))
+    N.call('rvip_bn_train_stats', P(zd), C.c_longlong(rows), c, ndt(dtype), P(gd), P(bd), P(mm), P(mv), 0.99, 1e-3, 1,
+           P(mean), P(invstd), P(scale), P(shift), P(ws), C.c_size_t(wsb), stream())
+    state = torch.zeros(8, dtype=torch.int32, device=dev())
+    state[N.STATE_SEED], state[N.STATE_STEP] = 77, 3
+    oh, ow = h // 2, w // 2
+    ve = 4 if dtype == 'f32' else 8
+    y = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
+    pooled = torch.empty((n, oh, ow, c), dtype=tdt(dtype), device=dev())
+    arg = torch.full((n * oh * ow * (c // ve),), -1, dtype=torch.int16, device=dev())
+    a = N.ApplyDesc()
+    a.z, a.y, a.pooled, a.argmax = zd.data_ptr(), y.data_ptr(), pooled.data_ptr(), arg.data_ptr()
+    a.scale, a.shift, a.act = scale.data_ptr(), shift.data_ptr(), 0
+    a.drop_rate, a.mask, a.state, a.layer_id = rate, None, state.data_ptr(), 5
+    a.n, a.h, a.w, a.c, a.dtype = n, h, w, c, ndt(dtype)
+    N.call('rvip_bn_apply', C.byref(a), stream())
+    # the argmax words against the oracle's first-maximum index of the stored y
+    yq = down(y).astype(np.float64)
+    _, idx = O.maxpool2x2_fwd(yq)                                       # [n, oh, ow, c] in 0..3
+    words = arg.cpu().numpy().astype(np.uint16).reshape(n, oh, ow, c // ve)
+    got = np.stack([(words >> (2 * e)) & 3 for e in range(ve)], -1).reshape(n, oh, ow, c)
+    np.testing.assert_array_equal(got, idx)
+    dp = rnd(rng.standard_normal((n, oh, ow, c)), dtype)
+    addg = rnd(rng.standard_normal((n, h, w, c)), dtype)
+    dpd, addd = up(dp, dtype), up(addg, dtype)
+
+    def passes(fused, skip):
+        dz = torch.full((n, h, w, c), 7.0, dtype=tdt(dtype), device=dev())
+        dgamma, dbeta, dbias = (torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(3))
+        coef = torch.empty(3 * c, dtype=torch.float32, device=dev())
+        b = N.BnBwdDesc()
+        b.z, b.dz = zd.data_ptr(), dz.data_ptr()
+        if fused:
+            b.dy = addd.data_ptr() if skip else None
+            b.dpooled, b.argmax, b.h, b.w = dpd.data_ptr(), arg.data_ptr(), h, w
+        else:
+            gy = torch.zeros((n, h, w, c), dtype=tdt(dtype), device=dev())
+            N.call('rvip_maxpool2x2_bwd', P(y), P(dpd), P(addd) if skip else None, P(gy), n, h, w, c, ndt(dtype), stream())
+            b.dy = gy.data_ptr()
+            b._gy = gy
+        b.gamma, b.mean, b.invstd = gd.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+        b.scale, b.shift = scale.data_ptr(), shift.data_ptr()
+        b.dgamma, b.dbeta, b.dbias, b.coef = dgamma.data_ptr(), dbeta.data_ptr(), dbias.data_ptr(), coef.data_ptr()
+        b.act, b.act_after_bn = N.ACT['relu'], 0
+        b.drop_rate, b.mask, b.state, b.layer_id = rate, None, state.data_ptr(), 5
+        b.rows, b.c, b.dtype = rows, c, ndt(dtype)
+        b.workspace, b.workspace_bytes = ws.data_ptr(), wsb
+        N.call('rvip_bn_bwd_reduce', C.byref(b), stream())
+        N.call('rvip_bn_bwd_apply', C.byref(b), stream())
+        torch.cuda.synchronize()
+        return [t.clone() for t in (dz, dgamma, dbeta, dbias)]
+    for skip in (True, False):
+        for r0, r1 in zip(passes(False, skip), passes(True, skip)):
+            assert torch.equal(r0, r1), (skip, (r0.float() - r1.float()).abs().max())
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('loss', ['mse', 'bce_dice'])
 @pytest.mark.parametrize('k', [2, 4])               # 4: the loss sums [1]..[4] and BCE-Dice drop the background channel (Loss_and_metrics.py:240-242)
 def test_head_loss_and_backward(dtype, loss, k):
