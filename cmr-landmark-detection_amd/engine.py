@@ -256,10 +256,18 @@ class Engine:
                 shape[st.y] = shape[st.z]
             if st.pool:
                 alloc(st.pooled, st.h // 2, st.w // 2, st.cout, self.act)
+        # 2-bit window argmax of the pooled stages (written by the pooled rvip_bn_apply, read by the stage's BN-backward passes
+        # in place of a materialised MaxPooling gradient); stages the column-split kernel does not cover keep rvip_maxpool2x2_bwd
+        self.argmax = {}
+        if os.environ.get('RVIP_FUSE_POOLBWD', '1') != '0':
+            for st in plan.stages:
+                if st.pool and L.rvip_bn_apply_argmax_ok(st.cout, P.dt):
+                    self.argmax[st.conv] = torch.zeros(n * (st.h // 2) * (st.w // 2) * (st.cout // ve), dtype=torch.int16, device=dev)
         # gradients: d(y) per stage, d(pooled), d(z) (= grad of the conv output), skip-branch grads
         self.dz = {}
         for st in plan.stages:
-            alloc(st.y, st.h, st.w, st.cout, self.grd)
+            if st.conv not in self.argmax:            # a fused pooled stage never materialises the gradient of its output
+                alloc(st.y, st.h, st.w, st.cout, self.grd)
             alloc(st.z, st.h, st.w, st.cout, self.dz)
             if st.pool:
                 alloc(st.pooled, st.h // 2, st.w // 2, st.cout, self.grd)
@@ -302,13 +310,6 @@ class Engine:
         self.ws_bytes = need
         self.ws_wg = torch.empty(need_wg // 4 + 64, **f32)
         self.ws_wg_bytes = need_wg
-        # 2-bit window argmax of the pooled stages (written by the pooled rvip_bn_apply, read by the stage's BN-backward passes
-        # in place of a materialised MaxPooling gradient); stages the column-split kernel does not cover keep rvip_maxpool2x2_bwd
-        self.argmax = {}
-        if os.environ.get('RVIP_FUSE_POOLBWD', '1') != '0':
-            for st in plan.stages:
-                if st.pool and L.rvip_bn_apply_argmax_ok(st.cout, P.dt):
-                    self.argmax[st.conv] = torch.zeros(n * (st.h // 2) * (st.w // 2) * (st.cout // ve), dtype=torch.int16, device=dev)
         self._graphs, self._eager_steps, self.launch_mode = None, 0, 'eager'
         self.pin_x = None
         self._build_lists()
@@ -508,7 +509,7 @@ class Engine:
             rows = n * st.h * st.w
             first = st.src0 == 'input_1'
             bwd.label = '%s %dx%dx%d->%d tensor=%.1fMB' % (st.conv, st.h, st.w, st.cin, st.cout, rows * st.cout * esz / 1e6)
-            gy, dz, z = self.grd[st.y], self.dz[st.z], self.act[st.z]
+            gy, dz, z = self.grd.get(st.y), self.dz[st.z], self.act[st.z]
             fuse_pool = st.pool and st.conv in self.argmax
             if st.pool and not fuse_pool:
                 add = self.gskip.get(st.y)
@@ -517,7 +518,7 @@ class Engine:
             elif st.y in self.gskip and not st.pool:
                 raise NotImplementedError('skip tensor without pooling')
             b = N.BnBwdDesc()
-            b.dy, b.z, b.dz = gy.data_ptr(), z.data_ptr(), dz.data_ptr()
+            b.dy, b.z, b.dz = (gy.data_ptr() if gy is not None else None), z.data_ptr(), dz.data_ptr()
             if fuse_pool:                      # gy is never materialised: (pooled gradient, window argmax, skip gradient) instead
                 add = self.gskip.get(st.y)
                 b.dy = add.data_ptr() if add is not None else None
