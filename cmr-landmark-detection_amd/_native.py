@@ -12,6 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RVIP_LIB') or os.path.join(_HERE, 'librvip_hip.so')     # RVIP_LIB: A/B another build of the same ABI
 
+EXPECTED_ABI = 4          # RVIP_ABI_VERSION of include/rvip_hip.h (tests/test_host_cpu.py holds the two together)
 F32, BF16, F16 = 0, 1, 2
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'elu': 2, 'sigmoid': 3}
 LOSS_MSE, LOSS_BCE_DICE = 0, 1
@@ -156,6 +157,10 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        got = L.rvip_abi_version()
+        if got != EXPECTED_ABI:        # also for RVIP_LIB overrides: descriptors of another ABI would be misread silently
+            raise RvipError('%s has ABI version %d, this package binds version %d: rebuild it (__graft_entry__.build())'
+                            % (LIB_PATH, got, EXPECTED_ABI))
         _lib = L
     return _lib
 

@@ -1586,7 +1586,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 
 using namespace rvip;
 
-extern "C" int rvip_abi_version(void) { return 4; }     // 3: round-2 prune; 4: window argmax of the pooled stages (apply / BN-backward descriptors), IMG_CHANNELS 2..4 entry points
+extern "C" int rvip_abi_version(void) { return RVIP_ABI_VERSION; }     // 3: round-2 prune; 4: window argmax of the pooled stages (apply / BN-backward descriptors), IMG_CHANNELS 2..4 entry points
 extern "C" const char* rvip_build_info(void) { return "rvip_hip gfx950 wave64 mfma"; }
 extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
 

@@ -55,6 +55,7 @@ extern "C" {
 #define RVIP_STATE_SEED   2     /* dropout seed */
 #define RVIP_STATE_WORDS  8
 
+#define RVIP_ABI_VERSION 4   /* what rvip_abi_version() of a matching library returns; _native.py checks it at every load */
 int         rvip_abi_version(void);
 const char* rvip_build_info(void);          /* "gfx950 ..." */
 int         rvip_last_hip_error(void);      /* last hipError_t seen by a launcher (0 = none) */

@@ -102,8 +102,15 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(rvip._native.SIGNATURES), declared ^ set(rvip._native.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.rvip_abi_version() == 4 and b'gfx950' in lib.rvip_build_info()
+    abi = int(re.search(r'#define\s+RVIP_ABI_VERSION\s+(\d+)', hdr).group(1))
+    assert lib.rvip_abi_version() == abi == rvip._native.EXPECTED_ABI and b'gfx950' in lib.rvip_build_info()
     assert lib.rvip_reduce_workspace(1000, 64) > 0 and lib.rvip_conv3x3_wgrad_workspace(2, 32, 32, 8, 8) > 0
+
+
+def test_build_entry_point_runs():
+    """__graft_entry__.build() (the driver's build check and INTEGRATION.md's build command) must succeed on the tree as it is."""
+    import __graft_entry__ as g
+    assert g.build() is None
 
 
 def test_struct_layouts_match_header(tmp_path):
