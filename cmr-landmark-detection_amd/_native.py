@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RVIP_LIB') or os.path.join(_HERE, 'librvip_hip.so')     # RVIP_LIB: A/B another build of the same ABI
 
-EXPECTED_ABI = 4          # RVIP_ABI_VERSION of include/rvip_hip.h (tests/test_host_cpu.py holds the two together)
+EXPECTED_ABI = 5          # RVIP_ABI_VERSION of include/rvip_hip.h (tests/test_host_cpu.py holds the two together)
 F32, BF16, F16 = 0, 1, 2
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'elu': 2, 'sigmoid': 3}
 LOSS_MSE, LOSS_BCE_DICE = 0, 1
@@ -34,7 +34,8 @@ class Conv3x3Desc(C.Structure):
                 ('y', vp), ('y1', vp), ('csplit', C.c_int32),
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('act', C.c_int32), ('dtype', C.c_int32),
-                ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32), ('subpix', C.c_int32), ('stream_in', C.c_int32)]
+                ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32), ('subpix', C.c_int32), ('stream_in', C.c_int32),
+                ('gdrop_rate', C.c_float), ('gdrop_state', vp), ('gdrop_layer_id', C.c_int32)]
 
 
 class PackEntry(C.Structure):
@@ -49,7 +50,8 @@ class Wgrad3x3Desc(C.Structure):
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('dtype', C.c_int32),
                 ('workspace', vp), ('workspace_bytes', C.c_size_t),
-                ('depth', C.c_int32), ('kd', C.c_int32), ('defer_fold', C.c_int32)]
+                ('depth', C.c_int32), ('kd', C.c_int32), ('defer_fold', C.c_int32),
+                ('w_master', vp), ('dot_rows', vp), ('dot_rows_bytes', C.c_size_t)]
 
 
 class ApplyDesc(C.Structure):
@@ -74,7 +76,21 @@ class BnBwdDesc(C.Structure):
                 ('dtype', C.c_int32),
                 ('workspace', vp), ('workspace_bytes', C.c_size_t),
                 ('bias_rows', vp), ('bias_rows_bytes', C.c_size_t),
-                ('dpooled', vp), ('argmax', vp), ('h', C.c_int32), ('w', C.c_int32)]
+                ('dpooled', vp), ('argmax', vp), ('h', C.c_int32), ('w', C.c_int32),
+                ('run_if', vp), ('run_if_n', C.c_int32)]
+
+
+class BnCoefSrc(C.Structure):
+    _fields_ = [('rows', vp), ('nrows', C.c_int32), ('stride', C.c_int32), ('offset', C.c_int32), ('reserved', C.c_int32)]
+
+
+class BnCoefDesc(C.Structure):
+    _fields_ = [('t1', BnCoefSrc * 2), ('t2', BnCoefSrc * 2),
+                ('gamma', vp), ('beta', vp), ('mean', vp), ('invstd', vp),
+                ('dgamma', vp), ('dbeta', vp), ('coef', vp),
+                ('flags', vp),
+                ('count', C.c_longlong), ('c', C.c_int32),
+                ('min_gamma', C.c_float), ('max_beta_ratio', C.c_float)]
 
 
 class FoldEntry(C.Structure):
@@ -97,6 +113,7 @@ SIGNATURES = {
     'rvip_conv3x3_wgrad_workspace': (C.c_size_t, [C.c_int] * 5),
     'rvip_conv3x3_wgrad': (C.c_int, [C.POINTER(Wgrad3x3Desc), vp]),
     'rvip_conv3x3_wgrad_splits': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
+    'rvip_conv3x3_wgrad_dot_rows': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
     'rvip_fold_rows_batch': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'rvip_bn_bwd_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'rvip_bn_bwd_apply_head_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_int]),
@@ -116,6 +133,7 @@ SIGNATURES = {
     'rvip_bn_apply_argmax_ok': (C.c_int, [C.c_int, C.c_int]),
     'rvip_bn_bwd_reduce': (C.c_int, [C.POINTER(BnBwdDesc), vp]),
     'rvip_bn_bwd_apply': (C.c_int, [C.POINTER(BnBwdDesc), vp]),
+    'rvip_bn_bwd_coef': (C.c_int, [C.POINTER(BnCoefDesc), vp]),
     'rvip_maxpool2x2_bwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_subsample_odd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_upsample2x_fwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -50,6 +50,8 @@ struct ConvArgs {
     int down2;                                // store the 2x2 block sums of the result at half resolution (gradient of UpSampling2D)
     int subpix;                               // UpSampling2D -> conv as four 2x2-tap phase convolutions on the low-resolution input
     int nt_in;                                // non-temporal input reads (last reader of x0)
+    // statistics launches of a data gradient whose output crosses a Dropout layer backwards: store / sum keep ? g * inv_keep : 0
+    int gdrop; float g_inv_keep; uint32_t g_thr; const uint32_t* g_state; int g_layer;
 };
 
 template <typename T, int TW, int NCT>
@@ -284,16 +286,30 @@ struct ConvArgs2 {
     int nt_in;                               // input pieces with the non-temporal hint
     int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
+    int gdrop; float g_inv_keep; uint32_t g_thr; const uint32_t* g_state; int g_layer;      // see ConvArgs
 };
+
+// Dropout backward on four consecutive channels of one pixel (STATS launches with gdrop): the keep bits of the counter stream the
+// forward rvip_bn_apply used -- one hash per PAIR of elements, pair index = (pixel * C + channel) / 2 (dropout_keep in rvip_common.h).
+__device__ __forceinline__ void gdrop4(float (&v)[4], unsigned pix, int cout, int co, uint32_t key, uint32_t thr, float inv_keep) {
+    const uint32_t pr = pix * (uint32_t)(cout >> 1) + (uint32_t)(co >> 1);
+    const uint32_t h0 = hash32(pr ^ key), h1 = hash32((pr + 1u) ^ key);
+    v[0] = (h0 & 0xffffu) < thr ? v[0] * inv_keep : 0.f;
+    v[1] = (h0 >> 16) < thr ? v[1] * inv_keep : 0.f;
+    v[2] = (h1 & 0xffffu) < thr ? v[2] * inv_keep : 0.f;
+    v[3] = (h1 >> 16) < thr ? v[3] * inv_keep : 0.f;
+}
 
 // Epilogue of the data gradient of an UpSampling2D -> conv pair (KerasLayers.py:756-758): the gradient w.r.t. the
 // low-resolution tensor is the sum over each 2x2 block of the full-resolution data gradient.  The block's two rows are
 // two pixel tiles of the same lane (TW = 32) or lanes j and j ^ 16 (TW = 16), its two columns lanes j and j ^ 1; the
 // even lane stores the sum at [N, H/2, W/2, Cout].  No bias, activation, channel split or statistics in this mode.
 // Returns nothing; issues (NPT / ROWS) * NCT * (bf16 ? 2 : 4) buffer stores per wave, ROWS = TW == 32 ? 2 : 1.
-template <typename T, int TW, int NCT, int NPT>
+template <int M> __device__ __forceinline__ float swz(float v);
+__device__ __forceinline__ float lane_channel_sum(const float (&a)[16], int j);
+template <typename T, int TW, int NCT, int NPT, bool STATS = false>
 __device__ __forceinline__ void epilogue_down2(f32x16 (&acc)[NCT][NPT], int pbase, int j, int hf, int n, int ty0, int tx0, int co0,
-                                               const ConvArgs2& a, __amdgpu_buffer_rsrc_t ry) {
+                                               const ConvArgs2& a, __amdgpu_buffer_rsrc_t ry, float* st_sum = nullptr) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int ROWS = TW == 32 ? 2 : 1;
     const int hl = a.h >> 1, wl = a.w >> 1;
@@ -314,6 +330,12 @@ __device__ __forceinline__ void epilogue_down2(f32x16 (&acc)[NCT][NPT], int pbas
                 if constexpr (ROWS == 2) { t += acc[ct][pt + 1][r]; acc[ct][pt + 1][r] = 0.f; }
                 else t += __shfl_xor(t, 16);
                 v[r] = t + __shfl_xor(t, 1);
+            }
+            if constexpr (STATS) {                   // column sums of what is stored (the kept lanes' block sums)
+                float qs[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) qs[r] = keep ? Vec<T>::round(v[r]) : 0.f;
+                st_sum[ct] += lane_channel_sum(qs, j);
             }
             if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -359,6 +381,7 @@ template <int M>
 __device__ __forceinline__ float swz(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (M << 10) | 0x1f));
 }
+// (epilogue_down2 above uses lane_channel_sum through its forward declaration)
 // value of lane ^ 1 through DPP (quad_perm [1,0,3,2]): __shfl_xor(v, 1) compiles to ds_bpermute_b32, a trip through the LDS crossbar
 __device__ __forceinline__ float lane_xor1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -582,6 +605,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
     float st_sum[NCT], st_sq[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) st_sum[ct] = st_sq[ct] = 0.f;
+    uint32_t gkey = 0;
+    if constexpr (STATS) { if (a.gdrop) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer); }
 
     int it = 0;
     for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
@@ -671,6 +696,17 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                             const float t = acc[ct][pt][r] + lbias[ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3)];
                             acc[ct][pt][r] = 0.f;
                             v[r] = actf(t);
+                        }
+                        if (a.gdrop) {                   // Dropout backward on the result (wave-uniform)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float u[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                                gdrop4(u, pix, a.cout, co0 + ct * 32 + 8 * q + 4 * hf, gkey, a.g_thr, a.g_inv_keep);
+                                v[4 * q] = u[0]; v[4 * q + 1] = u[1]; v[4 * q + 2] = u[2]; v[4 * q + 3] = u[3];
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
                             const float q = pix_ok ? Vec<T>::round(v[r]) : 0.f;     // statistics of what is stored
                             qs[r] += q;
                             qq[r] = fmaf(q, q, qq[r]);
@@ -702,7 +738,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                 }
             }
         };
-        if (a.down2) epilogue_down2<T, TW, NCT, NPT>(acc, wv * (NPT * 32), j, hf, n, ty0, tx0, co0, a, ry);
+        if (a.down2) epilogue_down2<T, TW, NCT, NPT, STATS>(acc, wv * (NPT * 32), j, hf, n, ty0, tx0, co0, a, ry, st_sum);
         else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
         else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
         else epilogue([&](float t) { return act_fwd(t, a.act); });
@@ -958,6 +994,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     float st_sum[NCB], st_sq[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) st_sum[cb] = st_sq[cb] = 0.f;
+    uint32_t gkey = 0;
+    if constexpr (STATS) { if (a.gdrop) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer); }
 
     int it = 0;
     for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
@@ -1040,17 +1078,20 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                         int gy, gx;
                         block_pixel(blk, gy, gx);
                         ok[s2] = gy < a.h && gx < a.w;
+                        const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gy + pa) * 2 * a.w + 2 * gx + pb)
+                                                       : (unsigned)((n * a.h + gy) * a.w + gx);
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2) {
                             const int cb = 2 * cp + c2;
                             float v[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { v[r] = actf(acc[cb][blk][r]); acc[cb][blk][r] = bias_r[cb][r]; }
+                            if constexpr (STATS) {           // Dropout backward on the result (wave-uniform test)
+                                if (a.gdrop) gdrop4(v, pix, a.cout, co0 + cb * 16 + 4 * kq, gkey, a.g_thr, a.g_inv_keep);
+                            }
                             pk[s2][c2][0] = Vec<T>::pack2(v[0], v[1]);
                             pk[s2][c2][1] = Vec<T>::pack2(v[2], v[3]);
                         }
-                        const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gy + pa) * 2 * a.w + 2 * gx + pb)
-                                                       : (unsigned)((n * a.h + gy) * a.w + gx);
                         store_cbpair(cp, pk[s2][0][0], pk[s2][0][1], pk[s2][1][0], pk[s2][1][1], pix, ok[s2]);
                     }
                     if constexpr (STATS) {                                      // statistics of what is stored: the packed words, widened
@@ -1083,6 +1124,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             const int hl = a.h >> 1, wl = a.w >> 1;
 #pragma unroll
             for (int cp = 0; cp < NCB / 2; ++cp) {
+                float qd[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     // TW = 32: unit = (row pair m, column block cx); TW = 16: unit = row pair m
@@ -1103,8 +1145,19 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                     }
                     const bool keep = gyu < a.h && gxu < a.w && !(i16 & 1);
                     const unsigned pix = (unsigned)((n * hl + (gyu >> 1)) * wl + (gxu >> 1));
-                    store_cbpair(cp, Vec<T>::pack2(v[0][0], v[0][1]), Vec<T>::pack2(v[0][2], v[0][3]), Vec<T>::pack2(v[1][0], v[1][1]),
-                                 Vec<T>::pack2(v[1][2], v[1][3]), pix, keep);
+                    const unsigned w00 = Vec<T>::pack2(v[0][0], v[0][1]), w01 = Vec<T>::pack2(v[0][2], v[0][3]);
+                    const unsigned w10 = Vec<T>::pack2(v[1][0], v[1][1]), w11 = Vec<T>::pack2(v[1][2], v[1][3]);
+                    store_cbpair(cp, w00, w01, w10, w11, pix, keep);
+                    if constexpr (STATS) {                                     // column sums of the stored block sums
+                        qd[0][0] += keep ? Vec<T>::lo(w00) : 0.f; qd[0][1] += keep ? Vec<T>::hi(w00) : 0.f;
+                        qd[0][2] += keep ? Vec<T>::lo(w01) : 0.f; qd[0][3] += keep ? Vec<T>::hi(w01) : 0.f;
+                        qd[1][0] += keep ? Vec<T>::lo(w10) : 0.f; qd[1][1] += keep ? Vec<T>::hi(w10) : 0.f;
+                        qd[1][2] += keep ? Vec<T>::lo(w11) : 0.f; qd[1][3] += keep ? Vec<T>::hi(w11) : 0.f;
+                    }
+                }
+                if constexpr (STATS) {
+                    st_sum[2 * cp] += lane16_channel_sum(qd[0], i16);
+                    st_sum[2 * cp + 1] += lane16_channel_sum(qd[1], i16);
                 }
             }
         };
@@ -1168,6 +1221,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
     b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = a0.subpix; b.nt_in = a0.nt_in;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
+    b.gdrop = stats ? a0.gdrop : 0; b.g_inv_keep = a0.g_inv_keep; b.g_thr = a0.g_thr; b.g_state = a0.g_state; b.g_layer = a0.g_layer;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
     const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 <= LDS_MAX;
@@ -1614,6 +1668,7 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     if (a.down2 && (d->y1 || d->bias || d->act != RVIP_ACT_NONE || ((d->h | d->w) & 1))) return RVIP_EINVAL;
     a.nt_in = d->stream_in ? 1 : 0;
     a.subpix = d->subpix ? 1 : 0;
+    a.gdrop = 0; a.g_inv_keep = 1.f; a.g_thr = 65536u; a.g_state = nullptr; a.g_layer = 0;
     if (a.subpix) {                      // UpSampling2D -> conv as four phase convolutions on the low-resolution grid
         if (d->up0 != 1 || d->c1 || d->y1 || a.kd != 1 || a.down2) return RVIP_EINVAL;
         a.up0 = 0; a.h = d->h / 2; a.w = d->w / 2;
@@ -1640,7 +1695,7 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
 // register-staged fallback kernel, which does not fuse statistics: run rvip_bn_train_stats instead).
 extern "C" int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d) {
     ConvArgs a;
-    if (conv_args_from_desc(d, a) != RVIP_OK || d->y1) return 0;
+    if (conv_args_from_desc(d, a) != RVIP_OK) return 0;
     bool used = false; int rows = 0;
     const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, nullptr, &rows, true, !a.subpix); });
     return (rc == RVIP_OK && used) ? rows : 0;
@@ -1654,6 +1709,11 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
     if (rc) return rc;
     const int rows = rvip_conv3x3_fwd_stats_rows(d);
     if (!stats_ws || rows <= 0) return RVIP_EUNSUPPORTED;
+    if (d->gdrop_rate != 0.f) {                       // Dropout backward in the epilogue (data-gradient launches)
+        if (d->gdrop_rate < 0.f || d->gdrop_rate >= 1.f || !d->gdrop_state || d->y1 || d->down2 || d->subpix || (d->cout & 7)) return RVIP_EINVAL;
+        a.gdrop = 1; a.g_inv_keep = 1.f / (1.f - d->gdrop_rate); a.g_thr = dropout_thr(d->gdrop_rate);
+        a.g_state = d->gdrop_state; a.g_layer = d->gdrop_layer_id;
+    }
     if (stats_ws_bytes < (size_t)rows * 2 * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
     bool used = false;
     hipStream_t s = (hipStream_t)stream;

@@ -74,9 +74,18 @@ __device__ __forceinline__ void block_fold(const float (&part)[K][VE], bool acti
 // GROUPS row groups of 32 channels: 32 (1024 threads) halves the chain of load round trips of the 1024-row folds; a Post whose
 // epilogue needs many registers (PostBnStats: double-precision moving-average arithmetic) stays at 16 -- under the 128-VGPR
 // cap of a 1024-thread workgroup it spills, and a kernel with scratch pays for it at every (tiny) launch.
+// run_if: optional guard words -- the launch returns at once unless one of them is non-zero (rvip_bnbwd_desc.run_if)
+__device__ __forceinline__ bool guard_skips(const int* run_if, int n) {
+    if (!run_if) return false;
+    int any = 0;
+    for (int i = 0; i < n; ++i) any |= run_if[i];
+    return any == 0;
+}
 template <int K, typename Post, int GROUPS>
-__global__ __launch_bounds__(32 * GROUPS) void fold_finalize(const float* __restrict__ ws, int nblk, int width, Post post) {
+__global__ __launch_bounds__(32 * GROUPS) void fold_finalize(const float* __restrict__ ws, int nblk, int width, Post post,
+                                                             const int* __restrict__ run_if = nullptr, int run_if_n = 0) {
     __shared__ double sh[GROUPS][K][32];
+    if (guard_skips(run_if, run_if_n)) return;
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int ch = blockIdx.x * 32 + c;
     double s[K];
@@ -116,8 +125,8 @@ __global__ __launch_bounds__(32 * GROUPS) void fold_finalize(const float* __rest
 }
 
 template <int K, typename Post, int GROUPS = 32>
-static int launch_fold(const float* ws, int nblk, int width, Post post, hipStream_t s) {
-    hipLaunchKernelGGL((fold_finalize<K, Post, GROUPS>), dim3((unsigned)cdiv(width, 32)), dim3(32 * GROUPS), 0, s, ws, nblk, width, post);
+static int launch_fold(const float* ws, int nblk, int width, Post post, hipStream_t s, const int* run_if = nullptr, int run_if_n = 0) {
+    hipLaunchKernelGGL((fold_finalize<K, Post, GROUPS>), dim3((unsigned)cdiv(width, 32)), dim3(32 * GROUPS), 0, s, ws, nblk, width, post, run_if, run_if_n);
     return check_launch();
 }
 
@@ -501,6 +510,7 @@ struct BnBwdArgs {
     int act, act_after_bn, has_bn;
     float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
     long long rows; int c;
+    const int* run_if; int run_if_n;             // rvip_bn_bwd_reduce only: see guard_skips
 };
 
 // g = dL/d(BN-side output before dropout) [times act'(y) when the activation follows BN]
@@ -569,6 +579,7 @@ template <typename T, int ACT = -1, int DROP = -1, int AFTER = -1, int PARG = -1
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
+    if (guard_skips(a.run_if, a.run_if_n)) return;
     const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
     const bool active = prow < gm.rpi;
     const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
@@ -1401,6 +1412,7 @@ static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
     a.inv_keep = drop ? 1.f / (1.f - d->drop_rate) : 1.f; a.thr = dropout_thr(d->drop_rate);
     a.mask = d->mask; a.state = d->state; a.layer_id = d->layer_id; a.drop = drop;
     a.rows = d->rows; a.c = d->c;
+    a.run_if = nullptr; a.run_if_n = 0;
     return RVIP_OK;
 }
 
@@ -1431,6 +1443,10 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)d->workspace;
     const int fast = bnbwd_fast(a);
+    if (d->run_if) {
+        if (d->run_if_n <= 0 || d->run_if_n > 64) return RVIP_EINVAL;
+        a.run_if = d->run_if; a.run_if_n = d->run_if_n;
+    }
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
         if (fast == 1 && a.dp) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, RVIP_ACT_RELU, 0, 0, 1>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
@@ -1442,7 +1458,91 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     rc = check_launch();
     if (rc) return rc;
     PostBnBwd p{d->gamma, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef, (double)d->rows, d->c};
-    return launch_fold<2, PostBnBwd>(ws, g.nblk, d->c, p, s);
+    return launch_fold<2, PostBnBwd>(ws, g.nblk, d->c, p, s, a.run_if, a.run_if_n);
+}
+
+// ---- stage 1 of the BatchNormalization backward from the consumers' by-products (include/rvip_hip.h: rvip_bn_bwd_coef) ----
+namespace rvip {
+struct CoefSrc { const float* rows; int nrows, stride, offset; };
+struct CoefArgs {
+    CoefSrc t1[2], t2[2];
+    const float* gamma; const float* beta; const float* mean; const float* invstd;
+    float* dgamma; float* dbeta; float* coef; int* flags;
+    double n; int c; float min_gamma, max_beta_ratio;
+};
+// 1024 threads = 32 channels x 32 row groups; double accumulation in a fixed order (sources in order, rows strided by group)
+__global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(CoefArgs a) {
+    __shared__ double sh[2][32][32];
+    __shared__ int bad[32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int ch = blockIdx.x * 32 + c;
+    double s[2] = {0.0, 0.0};
+    if (ch < a.c) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const CoefSrc src = k == 0 ? a.t1[q] : a.t2[q];
+                if (!src.rows) continue;
+                const float* base = src.rows + src.offset + ch;
+                int b = g;
+                for (; b + 96 < src.nrows; b += 128) {
+                    const float v0 = base[(size_t)b * src.stride], v1 = base[(size_t)(b + 32) * src.stride];
+                    const float v2 = base[(size_t)(b + 64) * src.stride], v3 = base[(size_t)(b + 96) * src.stride];
+                    s[k] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+                }
+                for (; b < src.nrows; b += 32) s[k] += (double)base[(size_t)b * src.stride];
+            }
+        }
+    }
+    sh[0][g][c] = s[0]; sh[1][g][c] = s[1];
+    __syncthreads();
+    if (g == 0) {
+        int isbad = 0;
+        if (ch < a.c) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < 32; ++gg) { t1 += sh[0][gg][c]; t2 += sh[1][gg][c]; }
+            const float gm = a.gamma[ch], bt = a.beta ? a.beta[ch] : 0.f, is = a.invstd[ch], mu = a.mean[ch];
+            isbad = !(fabsf(gm) >= a.min_gamma && fabsf(bt) <= a.max_beta_ratio * fabsf(gm));
+            // y = gamma * xhat + beta  =>  sum g*xhat = (sum g*y - beta * sum g) / gamma
+            const double tx = isbad ? 0.0 : (t2 - (double)bt * t1) / (double)gm;
+            a.dbeta[ch] = (float)t1;
+            a.dgamma[ch] = (float)tx;
+            const float c1 = gm * is;
+            const float c2 = -gm * is * is * (float)(tx / a.n);
+            const float c3 = -gm * is * (float)(t1 / a.n) - c2 * mu;
+            a.coef[ch] = c1; a.coef[a.c + ch] = c2; a.coef[2 * a.c + ch] = c3;
+        }
+        bad[c] = isbad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int any = 0;
+        for (int i = 0; i < 32; ++i) any |= bad[i];
+        a.flags[blockIdx.x] = any;
+    }
+}
+}  // namespace rvip
+
+extern "C" int rvip_bn_bwd_coef(const rvip_bncoef_desc* d, void* stream) {
+    (void)hipGetLastError();
+    if (!d || d->c <= 0 || d->count <= 0 || !d->gamma || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->coef || !d->flags) return RVIP_EINVAL;
+    if (!d->t1[0].rows || !d->t2[0].rows || !(d->min_gamma > 0.f) || !(d->max_beta_ratio > 0.f)) return RVIP_EINVAL;
+    CoefArgs a;
+    for (int q = 0; q < 2; ++q) {
+        const rvip_bncoef_src* in[2] = {&d->t1[q], &d->t2[q]};
+        CoefSrc* out[2] = {&a.t1[q], &a.t2[q]};
+        for (int k = 0; k < 2; ++k) {
+            if (in[k]->rows && (in[k]->nrows <= 0 || in[k]->offset < 0 || in[k]->stride < in[k]->offset + d->c)) return RVIP_EINVAL;
+            *out[k] = CoefSrc{in[k]->rows, in[k]->nrows, in[k]->stride, in[k]->offset};
+        }
+    }
+    a.gamma = d->gamma; a.beta = d->beta; a.mean = d->mean; a.invstd = d->invstd;
+    a.dgamma = d->dgamma; a.dbeta = d->dbeta; a.coef = d->coef; a.flags = d->flags;
+    a.n = (double)d->count; a.c = d->c; a.min_gamma = d->min_gamma; a.max_beta_ratio = d->max_beta_ratio;
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((unsigned)cdiv(d->c, 32)), dim3(1024), 0, (hipStream_t)stream, a);
+    return check_launch();
 }
 
 extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {

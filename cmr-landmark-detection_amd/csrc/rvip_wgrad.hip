@@ -672,6 +672,83 @@ static int launch_wgrad_fold(const float* slab, int nsplit, long long count, flo
     return check_launch();
 }
 
+// The same fold, row-aligned, with the contraction against the layer's own kernel riding along:
+//   dw[i] = sum_k slab[k][i]   and   rows[(tap * nchunk + chunk)][ci] = sum over the chunk's output channels of Wr[tap][ci][o] * dw[tap][ci][o]
+// (Wr = the fp32 master rounded to the activation type, i.e. the values the data-gradient kernel multiplies with).  Summed over
+// all rows, column ci is  T2[ci] = sum_{t,o} W dW = sum_pixels X[., ci] * dX[., ci]  -- the conv is linear in its input, so the
+// inner product of an input channel with its own gradient can be read off the weight gradient (rvip_bn_bwd_coef uses it as the
+// sum g*y of the producer's BatchNormalization backward; no pass over g and y).
+// A (tap, ci) row of the kernel = cout4 float4s handled by LW = min(32, pow2 >= cout4) lanes of the 32 "element" lanes; 32 / LW
+// rows per workgroup, nchunk = ceil(cout4 / 32) workgroups per row.  G split groups as in wgrad_fold_kernel.
+template <typename T, int G, int U>
+__global__ __launch_bounds__(32 * G) void wgrad_fold_dot_kernel(const float4* __restrict__ slab, int nsplit, long long count4, float4* __restrict__ dw,
+                                                                const float4* __restrict__ w, int cout4, int cin, int nrow, int lw, int nchunk,
+                                                                float* __restrict__ rows) {
+    __shared__ float4 sh[G][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int rpw = 32 / lw, rl = e / lw, l = e - rl * lw;
+    const int chunk = blockIdx.x % nchunk, row = (blockIdx.x / nchunk) * rpw + rl, col4 = chunk * 32 + l;
+    const bool valid = row < nrow && col4 < cout4;
+    const long long i = (long long)row * cout4 + col4;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        for (int k0 = g; k0 < nsplit; k0 += G * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * G;
+                v[u] = k < nsplit ? slab[(size_t)k * count4 + i] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+    sh[g][e] = acc;
+    __syncthreads();
+    if (g >= 2) return;                                   // the first wave (element lanes 0..31 twice) finishes
+    float p = 0.f;
+    if (g == 0 && valid) {
+        float4 t = sh[0][e];
+#pragma unroll
+        for (int gg = 1; gg < G; ++gg) { t.x += sh[gg][e].x; t.y += sh[gg][e].y; t.z += sh[gg][e].z; t.w += sh[gg][e].w; }
+        dw[i] = t;
+        const float4 wv = w[i];
+        p = fmaf(Vec<T>::round(wv.x), t.x, fmaf(Vec<T>::round(wv.y), t.y, fmaf(Vec<T>::round(wv.z), t.z, Vec<T>::round(wv.w) * t.w)));
+    }
+    for (int o = 1; o < lw; o <<= 1) p += __shfl_xor(p, o);        // lw is a power of two <= 32: stays inside the row's lanes
+    if (g == 0 && l == 0 && row < nrow) {
+        const int tap = row / cin, ci = row - tap * cin;
+        rows[((size_t)tap * nchunk + chunk) * cin + ci] = p;
+    }
+}
+
+struct DotGeom { int cout4, lw, nchunk, nrow; };
+static DotGeom dot_geometry(int taps, int cin, int cout) {
+    DotGeom g;
+    g.cout4 = cout / 4;
+    int lw = 1;
+    while (lw < g.cout4 && lw < 32) lw <<= 1;
+    g.lw = lw;
+    g.nchunk = (int)cdiv(g.cout4, 32);
+    g.nrow = taps * cin;
+    return g;
+}
+
+template <typename T>
+static int launch_wgrad_fold_dot(const float* slab, int nsplit, int cin, int cout, float* dw, const float* w, float* rows, hipStream_t s) {
+    const long long count = 9LL * cin * cout;
+    if (cout % 4 || ((uintptr_t)slab & 15) || ((uintptr_t)dw & 15) || ((uintptr_t)w & 15)) return RVIP_EINVAL;
+    const DotGeom g = dot_geometry(9, cin, cout);
+    const dim3 grid((unsigned)(cdiv(g.nrow, 32 / g.lw) * g.nchunk));
+    const float4* sl = reinterpret_cast<const float4*>(slab);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    float4* out = reinterpret_cast<float4*>(dw);
+    if (nsplit > 32) hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, 32, 8>), grid, dim3(1024), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, rows);
+    else if (nsplit > 4) hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, 8, 4>), grid, dim3(256), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, rows);
+    else hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, 4, 1>), grid, dim3(128), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, rows);
+    return check_launch();
+}
+
 static void wgrad_geometry(int n, int h, int w, int cin, int cout, int& tw, int& tiles_x, int& tiles_y, int& ntiles, int& nsplit) {
     tw = w > 16 ? 32 : 16;
     const int th = 256 / tw;
@@ -765,6 +842,7 @@ static int launch_wgrad(const WgArgs& a, hipStream_t s) {
 
 using namespace rvip;
 
+extern "C" int rvip_conv3x3_wgrad_dot_rows(const rvip_wgrad3x3_desc* d);
 extern "C" size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout) {
     int tw, tx, ty, nt, ns;
     wgrad_geometry(n, h, w, cin, cout, tw, tx, ty, nt, ns);
@@ -792,6 +870,10 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     int rc = RVIP_OK;
     const int depth = d->depth > 0 ? d->depth : 1, kd = d->kd > 0 ? d->kd : 1;
     if ((kd != 1 && kd != 3) || d->n % depth) return RVIP_EINVAL;
+    if (d->dot_rows) {
+        if (!d->w_master || d->defer_fold) return RVIP_EINVAL;
+        if (d->dot_rows_bytes < (size_t)rvip_conv3x3_wgrad_dot_rows(d) * (d->c0 + d->c1) * sizeof(float)) return RVIP_EWORKSPACE;
+    }
     const long long esz = RVIP_ESZ(d->dtype);
     const long long x0b = (long long)a.n * (a.h >> a.up0) * (a.w >> a.up0) * a.c0 * esz, x1b = (long long)a.n * a.h * a.w * a.c1 * esz;
     const long long dyb = (long long)a.n * a.h * a.w * a.cout * esz;
@@ -826,7 +908,13 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
             });
             if (rc) return rc;
             if (d->defer_fold && kd == 1) return RVIP_OK;      // slabs stay in the caller's workspace for rvip_fold_rows_batch
-            rc = launch_wgrad_fold(a.slab, b.nsplit, count2, d->dw + (size_t)kdi * count2, s);
+            if (d->dot_rows) {
+                const int rpp = 9 * dot_geometry(9, a.cin, a.cout).nchunk;            // rows per depth-tap pass
+                rc = by_dtype(d->dtype, [&](auto t) {
+                    return launch_wgrad_fold_dot<decltype(t)>(a.slab, b.nsplit, a.cin, a.cout, d->dw + (size_t)kdi * count2,
+                                                              d->w_master + (size_t)kdi * count2, d->dot_rows + (size_t)kdi * rpp * a.cin, s);
+                });
+            } else rc = launch_wgrad_fold(a.slab, b.nsplit, count2, d->dw + (size_t)kdi * count2, s);
             if (rc) return rc;
         }
         return RVIP_OK;
@@ -839,7 +927,15 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     rc = by_dtype(d->dtype, [&](auto t) { return tw == 32 ? launch_wgrad<decltype(t), 32>(a, s) : launch_wgrad<decltype(t), 16>(a, s); });
     if (rc || d->defer_fold) return rc;
     const long long count = 9LL * a.cin * a.cout;
+    if (d->dot_rows) return by_dtype(d->dtype, [&](auto t) { return launch_wgrad_fold_dot<decltype(t)>(a.slab, a.nsplit, a.cin, a.cout, d->dw, d->w_master, d->dot_rows, s); });
     return launch_wgrad_fold(a.slab, a.nsplit, count, d->dw, s);
+}
+
+// rows of rvip_wgrad3x3_desc.dot_rows for this shape: [kd * 9 * ceil(cout / 128)][cin]
+extern "C" int rvip_conv3x3_wgrad_dot_rows(const rvip_wgrad3x3_desc* d) {
+    if (!d || d->cout <= 0 || d->cout % 4 || d->c0 <= 0) return 0;
+    const int kd = d->kd > 0 ? d->kd : 1;
+    return kd * 9 * dot_geometry(9, d->c0 + d->c1, d->cout).nchunk;
 }
 
 // number of split-K slabs rvip_conv3x3_wgrad writes for this shape (rows of the deferred fold; 0 = invalid descriptor)

@@ -502,6 +502,94 @@ class Engine:
                 bwd.label = 'deferred folds (%s, %d layers)' % ('weight gradients' if is_wide else 'bias gradients', len(entries))
                 bwd.append((L.rvip_fold_rows_batch, (_ptr(tabd), len(entries), C.c_longlong(max(e[3] for e in entries)), is_wide)))
                 del entries[:]
+        # ---- weight- and data-gradient descriptors of every igemm stage (built first: the BN-backward planning below queries them) ----
+        fuse_down_on = os.environ.get('RVIP_FUSE_DOWN2', '1') != '0'
+        wg_desc, dg_desc = {}, {}
+        for st in plan.stages:
+            if st.src0 == 'input_1':
+                continue
+            dz = self.dz[st.z]
+            wg = N.Wgrad3x3Desc()
+            wg.x0, wg.c0, wg.up0 = self.act[st.src0].data_ptr(), st.c0, st.up0
+            wg.x1, wg.c1 = (self.act[st.src1].data_ptr(), st.c1) if st.src1 else (None, 0)
+            wg.dy, wg.dw = dz.data_ptr(), P.g(st.conv, 'kernel').value
+            wg.n, wg.h, wg.w, wg.cout, wg.dtype = n, st.h, st.w, st.cout, dt
+            wg.depth, wg.kd = self.depth, self.kd
+            wg.workspace, wg.workspace_bytes = self.ws_wg.data_ptr(), self.ws_wg_bytes
+            dg = N.Conv3x3Desc()
+            dg.x0, dg.c0, dg.up0, dg.x1, dg.c1 = dz.data_ptr(), st.cout, 0, None, 0
+            dg.w_packed, dg.bias = P.packed[st.conv][1].data_ptr(), None
+            dg.n, dg.h, dg.w, dg.cout, dg.act, dg.dtype = n, st.h, st.w, st.cin, 0, dt
+            dg.depth, dg.kd = self.depth, self.kd
+            dg.y1, dg.csplit = None, 0
+            # stream_in (non-temporal fetch of dz, whose other reader - the weight gradient - ran already): measured slower,
+            # the Cout / 64 workgroup columns of the data gradient re-read the same tile (5.72 vs 5.69 ms); opt-in
+            dg.stream_in = 1 if os.environ.get('RVIP_NT_DGRAD', '0') == '1' else 0
+            if st.src1:
+                dg.y, dg.y1, dg.csplit = self.grd[st.src0].data_ptr(), self.gskip[st.src1].data_ptr(), st.c0
+            elif st.up0 == 1 and fuse_down_on:      # UpSampling2D: the 2x2 block sums leave the data-gradient epilogue directly
+                dg.y, dg.down2 = self.grd[st.src0].data_ptr(), 1
+            elif st.up0:
+                dg.y = self.up_tmp[st.conv].data_ptr()
+            else:
+                dg.y = self.grd[st.src0].data_ptr()
+            self._keep += [wg, dg]
+            wg_desc[st.conv], dg_desc[st.conv] = wg, dg
+
+        # ---- BatchNormalization backward WITHOUT its reduction pass (rvip_bn_bwd_coef, include/rvip_hip.h) ----
+        # For a stage  z -> BN -> [Dropout] -> y  every consumer of y is a 3x3 conv (directly, through MaxPooling2D / UpSampling2D, or
+        # as the skip half of a Concatenate), so  sum g  is the column sum of the consumers' data-gradient outputs (fused into their
+        # epilogues, Dropout backward included) and  sum g*y = sum W * dW  of the consumers (read off their weight gradients while the
+        # split-K slabs are folded).  The 2 x tensor re-read of rvip_bn_bwd_reduce disappears; the classic kernels stay in the launch
+        # list behind a device-side guard (ill-conditioned gamma / beta) and return at once otherwise.
+        alg_on = os.environ.get('RVIP_BNBWD_ALGEBRAIC', '1') != '0'
+        producer = {}
+        for st in plan.stages:
+            producer[st.y] = st
+            if st.pool:
+                producer[st.pooled] = st
+        consumers = {st.conv: [] for st in plan.stages}
+        for st in plan.stages:
+            for which, src in ((0, st.src0), (1, st.src1)):
+                if src and src in producer:
+                    consumers[producer[src].conv].append((st, which))
+
+        def algebraic_ok(p):
+            if not alg_on or not p.bn or p.act_post or (p is last and self.fuse_head):
+                return False
+            cl = consumers[p.conv]
+            dropping = bool(p.drop and p.drop[1] > 0)
+            if not cl or len(cl) > 2 or (dropping and (p.drop[0] in self.masks or p.pool or len(cl) != 1)):
+                return False
+            for c, which in cl:
+                if c.conv not in dg_desc or c.up0 == 2 or (c.up0 == 1 and not fuse_down_on) or (dropping and (c.src1 or c.up0)):
+                    return False
+                if L.rvip_conv3x3_fwd_stats_rows(C.byref(dg_desc[c.conv])) <= 0:
+                    return False
+                if dropping and (c.cin % 8):
+                    return False
+            return True
+        self.algebraic = {p.conv for p in plan.stages if algebraic_ok(p)}
+        self._alg_bufs = {}
+        sums_rows, dot_rows = {}, {}            # consumer conv name -> (tensor, nrows)
+        for p in plan.stages:
+            if p.conv not in self.algebraic:
+                continue
+            for c, which in consumers[p.conv]:
+                dg, wg = dg_desc[c.conv], wg_desc[c.conv]
+                if c.conv not in sums_rows:
+                    nr = L.rvip_conv3x3_fwd_stats_rows(C.byref(dg))
+                    sums_rows[c.conv] = (torch.zeros(nr * 2 * c.cin, dtype=torch.float32, device=self.ws.device), nr)
+                    nd = L.rvip_conv3x3_wgrad_dot_rows(C.byref(wg))
+                    dbuf = torch.zeros(nd * c.cin, dtype=torch.float32, device=self.ws.device)
+                    dot_rows[c.conv] = (dbuf, nd)
+                    wg.w_master, wg.dot_rows, wg.dot_rows_bytes = P.p(c.conv, 'kernel').value, dbuf.data_ptr(), dbuf.numel() * 4
+                if p.drop and p.drop[1] > 0:          # Dropout backward rides in the consumer's data-gradient epilogue
+                    dg.gdrop_rate, dg.gdrop_state, dg.gdrop_layer_id = p.drop[1], state.value, p.drop[2]
+        self._alg_bufs['sums'], self._alg_bufs['dots'] = sums_rows, dot_rows
+        min_gamma = float(os.environ.get('RVIP_BNBWD_MIN_GAMMA', 1.0 / 64))
+        max_beta_ratio = float(os.environ.get('RVIP_BNBWD_MAX_BETA_RATIO', 64.0))
+
         for si, st in reversed(list(enumerate(plan.stages))):
             if si == n_enc - 1:
                 flush_folds()                  # bucket 0 (head, decoder, bottleneck) is complete here
@@ -533,7 +621,8 @@ class Engine:
             b.act = N.ACT[st.act_post] if st.act_post else N.ACT[st.act_conv]
             b.act_after_bn = 1 if st.act_post else 0
             b.drop_rate, b.mask, b.state, b.layer_id = 0.0, None, state.value, 0
-            if st.drop and st.drop[1] > 0:
+            alg = st.conv in self.algebraic
+            if st.drop and st.drop[1] > 0 and not alg:       # (algebraic: the gradient arrives with the Dropout backward applied)
                 b.drop_rate, b.layer_id = st.drop[1], st.drop[2]
                 if st.drop[0] in self.masks:
                     b.mask = self.masks[st.drop[0]].data_ptr()
@@ -555,6 +644,25 @@ class Engine:
                                                         P.g(hd['conv'], 'bias'))))
                 bwd.append((L.rvip_bn_bwd_apply_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'])))
             else:
+                if alg:
+                    cd = N.BnCoefDesc()
+                    for q, (c, which) in enumerate(consumers[st.conv]):
+                        off = 0 if which == 0 else c.c0
+                        sbuf_, nr = sums_rows[c.conv]
+                        dbuf_, nd = dot_rows[c.conv]
+                        cd.t1[q].rows, cd.t1[q].nrows, cd.t1[q].stride, cd.t1[q].offset = sbuf_.data_ptr(), nr, 2 * c.cin, off
+                        cd.t2[q].rows, cd.t2[q].nrows, cd.t2[q].stride, cd.t2[q].offset = dbuf_.data_ptr(), nd, c.cin, off
+                    cd.gamma, cd.beta = P.p(st.bn, 'gamma').value, P.p(st.bn, 'beta').value
+                    cd.mean, cd.invstd = b.mean, b.invstd
+                    cd.dgamma, cd.dbeta, cd.coef = b.dgamma, b.dbeta, b.coef
+                    nflags = -(-st.cout // 32)
+                    flags = torch.zeros(nflags, dtype=torch.int32, device=self.ws.device)
+                    self._fold_bufs.append(flags)
+                    cd.flags, cd.count, cd.c = flags.data_ptr(), rows, st.cout
+                    cd.min_gamma, cd.max_beta_ratio = min_gamma, max_beta_ratio
+                    self._keep.append(cd)
+                    bwd.append((L.rvip_bn_bwd_coef, (C.byref(cd),)))
+                    b.run_if, b.run_if_n = flags.data_ptr(), nflags       # the classic reduction: runs only when a flag is set
                 if st.bn:
                     bwd.append((L.rvip_bn_bwd_reduce, (C.byref(b),)))
                 bwd.append((L.rvip_bn_bwd_apply, (C.byref(b),)))
@@ -570,41 +678,20 @@ class Engine:
                 bwd.append((L.rvip_conv3x3_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, st.h, st.w,
                                                       st.cout, dt, _ptr(self.ws_wg), C.c_size_t(self.ws_wg_bytes))))
                 continue
-            wg = N.Wgrad3x3Desc()
-            wg.x0, wg.c0, wg.up0 = self.act[st.src0].data_ptr(), st.c0, st.up0
-            wg.x1, wg.c1 = (self.act[st.src1].data_ptr(), st.c1) if st.src1 else (None, 0)
-            wg.dy, wg.dw = dz.data_ptr(), P.g(st.conv, 'kernel').value
-            wg.n, wg.h, wg.w, wg.cout, wg.dtype = n, st.h, st.w, st.cout, dt
-            wg.depth, wg.kd = self.depth, self.kd
-            wg.workspace, wg.workspace_bytes = self.ws_wg.data_ptr(), self.ws_wg_bytes
-            if defer:
+            wg, dg = wg_desc[st.conv], dg_desc[st.conv]
+            if defer and st.conv not in dot_rows:   # (a layer whose kernel gradient feeds rvip_bn_bwd_coef is folded at once, with the dot rows)
                 ns = L.rvip_conv3x3_wgrad_splits(C.byref(wg))
                 sbuf = torch.empty(ns * 9 * st.cin * st.cout, dtype=torch.float32, device=self.ws.device)
                 self._fold_bufs.append(sbuf)
                 wg.workspace, wg.workspace_bytes, wg.defer_fold = sbuf.data_ptr(), sbuf.numel() * 4, 1
                 wide.append((sbuf, P.g(st.conv, 'kernel'), ns, 9 * st.cin * st.cout))
-            self._keep.append(wg)
             bwd.append((L.rvip_conv3x3_wgrad, (C.byref(wg),)))
-            dg = N.Conv3x3Desc()
-            dg.x0, dg.c0, dg.up0, dg.x1, dg.c1 = dz.data_ptr(), st.cout, 0, None, 0
-            dg.w_packed, dg.bias = P.packed[st.conv][1].data_ptr(), None
-            dg.n, dg.h, dg.w, dg.cout, dg.act, dg.dtype = n, st.h, st.w, st.cin, 0, dt
-            dg.depth, dg.kd = self.depth, self.kd
-            dg.y1, dg.csplit = None, 0
-            # stream_in (non-temporal fetch of dz, whose other reader - the weight gradient - ran already): measured slower,
-            # the Cout / 64 workgroup columns of the data gradient re-read the same tile (5.72 vs 5.69 ms); opt-in
-            dg.stream_in = 1 if os.environ.get('RVIP_NT_DGRAD', '0') == '1' else 0
-            fuse_down = st.up0 == 1 and os.environ.get('RVIP_FUSE_DOWN2', '1') != '0'
-            if st.src1:
-                dg.y, dg.y1, dg.csplit = self.grd[st.src0].data_ptr(), self.gskip[st.src1].data_ptr(), st.c0
-            elif fuse_down:                 # UpSampling2D: the 2x2 block sums leave the data-gradient epilogue directly
-                dg.y, dg.down2 = self.grd[st.src0].data_ptr(), 1
-            elif st.up0:
-                dg.y = self.up_tmp[st.conv].data_ptr()
+            fuse_down = st.up0 == 1 and fuse_down_on
+            if st.conv in sums_rows:        # the column sums of the result ride in the epilogue (sum g of the producers' BN backward)
+                sb = sums_rows[st.conv][0]
+                bwd.append((L.rvip_conv3x3_fwd_stats, (C.byref(dg), _ptr(sb), C.c_size_t(sb.numel() * 4))))
             else:
-                dg.y = self.grd[st.src0].data_ptr()
-            self._keep.append(dg)
-            bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
+                bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
             if st.up0 and not fuse_down:    # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions
                 back = L.rvip_upsample2x_bwd if st.up0 == 1 else L.rvip_subsample_odd
                 bwd.append((back, (_ptr(self.up_tmp[st.conv]), _ptr(self.grd[st.src0]), n, st.h // 2, st.w // 2, st.c0, dt)))

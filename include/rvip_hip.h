@@ -55,7 +55,7 @@ extern "C" {
 #define RVIP_STATE_SEED   2     /* dropout seed */
 #define RVIP_STATE_WORDS  8
 
-#define RVIP_ABI_VERSION 4   /* what rvip_abi_version() of a matching library returns; _native.py checks it at every load */
+#define RVIP_ABI_VERSION 5   /* what rvip_abi_version() of a matching library returns; _native.py checks it at every load */
 int         rvip_abi_version(void);
 const char* rvip_build_info(void);          /* "gfx950 ..." */
 int         rvip_last_hip_error(void);      /* last hipError_t seen by a launcher (0 = none) */
@@ -100,6 +100,11 @@ typedef struct rvip_conv3x3_desc {
     /* stream_in != 0: hint that this launch is the last reader of x0 for a while (e.g. the data gradient reading dz):
      * its input is fetched with the non-temporal cache policy. */
     int32_t      stream_in;
+    /* rvip_conv3x3_fwd_stats only, data-gradient launches (ABI 5): the result is the gradient reaching the OUTPUT of a Dropout layer
+     * (KerasLayers.py:718,772) and what is stored -- and summed -- is the gradient at its INPUT: keep ? g / (1 - gdrop_rate) : 0
+     * with the keep bits of the counter stream (gdrop_state, gdrop_layer_id: the Dropout layer's id, element index = position in y).
+     * The BN-backward apply pass of the producer stage then runs without dropout.  0 = none; not with y1 / down2 / subpix. */
+    float        gdrop_rate; const uint32_t* gdrop_state; int32_t gdrop_layer_id;
 } rvip_conv3x3_desc;
 
 int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
@@ -107,7 +112,10 @@ int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
 /* The same convolution with the BatchNormalization statistics of its (stored) output fused into the epilogue:
  * writes rvip_conv3x3_fwd_stats_rows(d) partial rows [rows][2][cout] (per-channel sum, sum of squares) to stats_ws;
  * finish with rvip_bn_stats_finalize.  rows == 0 means this shape runs on the register-staged fallback kernel,
- * which does not fuse statistics (use rvip_conv3x3_fwd + rvip_bn_train_stats). */
+ * which does not fuse statistics (use rvip_conv3x3_fwd + rvip_bn_train_stats).
+ * ABI 5: also valid for data-gradient launches -- with y1 (channel c of the virtual [y, y1] row is column c of the partial rows),
+ * with down2 (sums of the stored 2x2 block sums; the sum-of-squares half stays zero) and with gdrop_rate: the column sums are the
+ * `T1 = sum g` term of the producer's BatchNormalization backward, see rvip_bn_bwd_coef. */
 int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d);
 int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_ws, size_t stats_ws_bytes, void* stream);
 
@@ -151,11 +159,19 @@ typedef struct rvip_wgrad3x3_desc {
      * stay in `workspace` (which the caller must then keep private to this layer) and dw is not written; sum them later,
      * together with other layers', with rvip_fold_rows_batch(..., wide = 1). */
     int32_t      defer_fold;
+    /* dot_rows != NULL (ABI 5; needs w_master, excludes defer_fold): the fold of the slabs also writes
+     * rvip_conv3x3_wgrad_dot_rows(d) partial rows [rows][C0+C1] whose column sums are  T2[i] = sum_{t,o} Wr[t][i][o] * dw[t][i][o],
+     * Wr = w_master rounded to `dtype` (what the data gradient multiplies with).  Because the conv is linear in its input X,
+     * T2[i] = sum_pixels X[.,i] * dX[.,i]: the `sum g*y` term of the BatchNormalization backward of whichever stage produced
+     * channel i of X, without a pass over g and y (rvip_bn_bwd_coef). */
+    const float* w_master;            /* [taps][C0+C1][Cout] fp32, the layer's HWIO kernel */
+    float*       dot_rows; size_t dot_rows_bytes;
 } rvip_wgrad3x3_desc;
 
 size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout);
 int    rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream);
 int    rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d);
+int    rvip_conv3x3_wgrad_dot_rows(const rvip_wgrad3x3_desc* d);
 
 /* Batched stage 2 for reductions whose result only the optimiser reads (bias gradients, weight gradients):
  * dst[i] = sum_r src[r*width + i], r < nrows, for `entries` records of a DEVICE table in ONE launch, fixed order.
@@ -267,10 +283,36 @@ typedef struct rvip_bnbwd_desc {
      * round(dy + (argmax of its window == 2*(y&1) + (x&1) ? dpooled : 0)), dy = the skip-connection gradient (may be NULL),
      * exactly the tensor rvip_maxpool2x2_bwd would have stored; rows = n*h*w. */
     const void*  dpooled; const uint16_t* argmax; int32_t h, w;
+    /* run_if != NULL (ABI 5, rvip_bn_bwd_reduce only): both kernels of the stage return at once unless one of the run_if_n
+     * words is non-zero -- the conditioning flags rvip_bn_bwd_coef wrote for this stage.  The launch stays in a captured graph
+     * as the exact fallback of the algebraic route and costs a few microseconds when it is not needed. */
+    const int32_t* run_if; int32_t run_if_n;
 } rvip_bnbwd_desc;
 int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_rows(long long rows, int c, int dtype);
+
+/* Stage 1 of the BatchNormalization backward WITHOUT a pass over (g, z) (ABI 5).  For a stage  z -> BN -> [Dropout] -> y  whose
+ * consumers are 3x3 convolutions (through MaxPooling2D / UpSampling2D / Concatenate or directly):
+ *   T1[c] = sum g[c]       = column sums of the consumers' data-gradient outputs        (rvip_conv3x3_fwd_stats rows, k = 0)
+ *   T2[c] = sum g[c]*y[c]  = sum_{t,o} W[t][c][o] * dW[t][c][o] over the consumers      (rvip_conv3x3_wgrad dot_rows)
+ * and with y = gamma * xhat + beta:  dbeta = T1,  dgamma = sum g*xhat = (T2 - beta*T1) / gamma.  Up to two sources per term
+ * (a pooled stage with a skip connection has two consumers); source = `nrows` rows of `stride` floats, this stage's channels
+ * start at column `offset`.  Writes dgamma, dbeta and the coef[3][C] vectors of rvip_bn_bwd_apply exactly like
+ * rvip_bn_bwd_reduce.  The division needs |gamma| >= min_gamma and |beta| <= max_beta_ratio * |gamma| in every channel; the
+ * kernel writes flags[ceil(C/32)] (1 = some channel of that block fails) and the caller follows with rvip_bn_bwd_reduce(run_if =
+ * flags), which recomputes the stage the classic way when -- and only when -- a flag is set. */
+typedef struct rvip_bncoef_src { const float* rows; int32_t nrows; int32_t stride; int32_t offset; int32_t reserved; } rvip_bncoef_src;
+typedef struct rvip_bncoef_desc {
+    rvip_bncoef_src t1[2]; rvip_bncoef_src t2[2];      /* rows == NULL: unused */
+    const float* gamma; const float* beta; const float* mean; const float* invstd;
+    float*       dgamma; float* dbeta; float* coef;
+    int32_t*     flags;                                /* [ceil(c / 32)] */
+    long long    count;                                /* N*H*W of the stage */
+    int32_t      c;
+    float        min_gamma, max_beta_ratio;
+} rvip_bncoef_desc;
+int rvip_bn_bwd_coef(const rvip_bncoef_desc* d, void* stream);
 /* the same count for rvip_bn_bwd_apply_head (its grid is one resident round of workgroups) */
 int rvip_bn_bwd_apply_head_rows(long long rows, int c, int dtype, int k);
 
