@@ -76,8 +76,7 @@ class BnBwdDesc(C.Structure):
                 ('dtype', C.c_int32),
                 ('workspace', vp), ('workspace_bytes', C.c_size_t),
                 ('bias_rows', vp), ('bias_rows_bytes', C.c_size_t),
-                ('dpooled', vp), ('argmax', vp), ('h', C.c_int32), ('w', C.c_int32),
-                ('run_if', vp), ('run_if_n', C.c_int32)]
+                ('dpooled', vp), ('argmax', vp), ('h', C.c_int32), ('w', C.c_int32)]
 
 
 class BnCoefSrc(C.Structure):
@@ -88,7 +87,7 @@ class BnCoefDesc(C.Structure):
     _fields_ = [('t1', BnCoefSrc * 2), ('t2', BnCoefSrc * 2),
                 ('gamma', vp), ('beta', vp), ('mean', vp), ('invstd', vp),
                 ('dgamma', vp), ('dbeta', vp), ('coef', vp),
-                ('flags', vp),
+                ('flags', vp), ('fallback', C.POINTER(BnBwdDesc)),
                 ('count', C.c_longlong), ('c', C.c_int32),
                 ('min_gamma', C.c_float), ('max_beta_ratio', C.c_float)]
 
@@ -105,6 +104,8 @@ SIGNATURES = {
     'rvip_conv3x3_fwd': (C.c_int, [C.POINTER(Conv3x3Desc), vp]),
     'rvip_conv3x3_fwd_stats_rows': (C.c_int, [C.POINTER(Conv3x3Desc)]),
     'rvip_conv3x3_fwd_stats': (C.c_int, [C.POINTER(Conv3x3Desc), vp, C.c_size_t, vp]),
+    'rvip_conv3x3_fwd_sums_rows': (C.c_int, [C.POINTER(Conv3x3Desc)]),
+    'rvip_conv3x3_fwd_sums': (C.c_int, [C.POINTER(Conv3x3Desc), vp, C.c_size_t, vp]),
     'rvip_bn_stats_finalize': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp, vp]),
     'rvip_pack_conv3x3_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_pack_subpixel_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),

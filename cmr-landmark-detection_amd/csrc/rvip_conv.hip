@@ -307,7 +307,7 @@ __device__ __forceinline__ void gdrop4(float (&v)[4], unsigned pix, int cout, in
 // Returns nothing; issues (NPT / ROWS) * NCT * (bf16 ? 2 : 4) buffer stores per wave, ROWS = TW == 32 ? 2 : 1.
 template <int M> __device__ __forceinline__ float swz(float v);
 __device__ __forceinline__ float lane_channel_sum(const float (&a)[16], int j);
-template <typename T, int TW, int NCT, int NPT, bool STATS = false>
+template <typename T, int TW, int NCT, int NPT, int STATS = 0>
 __device__ __forceinline__ void epilogue_down2(f32x16 (&acc)[NCT][NPT], int pbase, int j, int hf, int n, int ty0, int tx0, int co0,
                                                const ConvArgs2& a, __amdgpu_buffer_rsrc_t ry, float* st_sum = nullptr) {
     constexpr unsigned OOB = 0x80000000u;
@@ -331,7 +331,7 @@ __device__ __forceinline__ void epilogue_down2(f32x16 (&acc)[NCT][NPT], int pbas
                 else t += __shfl_xor(t, 16);
                 v[r] = t + __shfl_xor(t, 1);
             }
-            if constexpr (STATS) {                   // column sums of what is stored (the kept lanes' block sums)
+            if constexpr (STATS == 2) {              // column sums of what is stored (the kept lanes' block sums)
                 float qs[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) qs[r] = keep ? Vec<T>::round(v[r]) : 0.f;
@@ -399,7 +399,9 @@ __device__ __forceinline__ float lane_channel_sum(const float (&a)[16], int j) {
     return e + swz<1>(e);
 }
 
-template <typename T, int TW, int NCT, int NPIX, bool STATS, int TAPS = 9, int NCW = 4>
+// STATS: 0 none; 1 BatchNormalization statistics of the stored output (sum, sum of squares: forward launches); 2 column sums only,
+// for data-gradient launches (with the 2x2-sum / channel-split epilogues and the Dropout backward): rows [gridDim.x][cout]
+template <typename T, int TW, int NCT, int NPIX, int STATS, int TAPS = 9, int NCW = 4>
 __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     static_assert(TAPS == 9 || TAPS == 4, "taps");
     constexpr int TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
@@ -606,7 +608,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) st_sum[ct] = st_sq[ct] = 0.f;
     uint32_t gkey = 0;
-    if constexpr (STATS) { if (a.gdrop) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer); }
+    if constexpr (STATS == 2) { if (a.gdrop) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer); }
 
     int it = 0;
     for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
@@ -697,7 +699,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                             acc[ct][pt][r] = 0.f;
                             v[r] = actf(t);
                         }
-                        if (a.gdrop) {                   // Dropout backward on the result (wave-uniform)
+                        if (STATS == 2 && a.gdrop) {     // Dropout backward on the result (wave-uniform)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 float u[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
@@ -709,12 +711,12 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                         for (int r = 0; r < 16; ++r) {
                             const float q = pix_ok ? Vec<T>::round(v[r]) : 0.f;     // statistics of what is stored
                             qs[r] += q;
-                            qq[r] = fmaf(q, q, qq[r]);
+                            if constexpr (STATS == 1) qq[r] = fmaf(q, q, qq[r]);
                         }
                         store_tile(ct, v, pix, pix_ok);
                     }
                     st_sum[ct] += lane_channel_sum(qs, j);
-                    st_sq[ct] += lane_channel_sum(qq, j);
+                    if constexpr (STATS == 1) st_sq[ct] += lane_channel_sum(qq, j);
                 }
             } else {
 #pragma unroll
@@ -745,23 +747,24 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
     }
     if constexpr (STATS) {
         asm volatile("s_barrier" ::: "memory");                            // every stage has been consumed
-        float* lst = reinterpret_cast<float*>(smem);                       // [NCW compute waves][2][BN]
+        constexpr int KS = STATS == 1 ? 2 : 1;
+        float* lst = reinterpret_cast<float*>(smem);                       // [NCW compute waves][KS][BN]
         if (!(j & 1)) {                                                    // lanes j and j ^ 1 hold the same channel
             const int r = (j >> 1) & 15;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int c = ct * 32 + 8 * (r >> 2) + 4 * hf + (r & 3);
-                lst[(wv * 2 + 0) * BN + c] = st_sum[ct];
-                lst[(wv * 2 + 1) * BN + c] = st_sq[ct];
+                lst[(wv * KS + 0) * BN + c] = st_sum[ct];
+                if constexpr (STATS == 1) lst[(wv * KS + 1) * BN + c] = st_sq[ct];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (tid < 2 * BN) {
+        if (tid < KS * BN) {
             const int k = tid / BN, c = tid % BN;
             float t = 0.f;
 #pragma unroll
-            for (int w4 = 0; w4 < NCW; ++w4) t += lst[(w4 * 2 + k) * BN + c];
-            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * 2 + k) * a.cout + co0 + c] = t;
+            for (int w4 = 0; w4 < NCW; ++w4) t += lst[(w4 * KS + k) * BN + c];
+            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * KS + k) * a.cout + co0 + c] = t;
         }
     }
 }
@@ -786,7 +789,9 @@ __device__ __forceinline__ float lane16_channel_sum(const float (&a)[4], int i16
     e += swz<2>(e);
     return e + swz<1>(e);
 }
-template <typename T, int TW, int NCT, int NPIX, bool STATS, int TAPS = 9, int NCW = 4>
+// STATS: 0 none; 1 BatchNormalization statistics of the stored output (sum, sum of squares: forward launches); 2 column sums only,
+// for data-gradient launches (with the 2x2-sum / channel-split epilogues and the Dropout backward): rows [gridDim.x][cout]
+template <typename T, int TW, int NCT, int NPIX, int STATS, int TAPS = 9, int NCW = 4>
 __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs2 a) {
     static_assert(sizeof(T) == 2, "16-bit storage types");
     static_assert(TAPS == 9 || TAPS == 4, "taps");
@@ -995,7 +1000,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) st_sum[cb] = st_sq[cb] = 0.f;
     uint32_t gkey = 0;
-    if constexpr (STATS) { if (a.gdrop) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer); }
+    if constexpr (STATS == 2) { if (a.gdrop) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer); }
 
     int it = 0;
     for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
@@ -1086,7 +1091,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                             float v[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { v[r] = actf(acc[cb][blk][r]); acc[cb][blk][r] = bias_r[cb][r]; }
-                            if constexpr (STATS) {           // Dropout backward on the result (wave-uniform test)
+                            if constexpr (STATS == 2) {      // Dropout backward on the result (wave-uniform test)
                                 if (a.gdrop) gdrop4(v, pix, a.cout, co0 + cb * 16 + 4 * kq, gkey, a.g_thr, a.g_inv_keep);
                             }
                             pk[s2][c2][0] = Vec<T>::pack2(v[0], v[1]);
@@ -1103,7 +1108,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                             for (int r = 0; r < 4; ++r) {
                                 const float u0 = ok[0] ? ux[r] : 0.f, u1 = ok[1] ? uy[r] : 0.f;
                                 qs[c2][r] += u0 + u1;
-                                qq[c2][r] = fmaf(u0, u0, fmaf(u1, u1, qq[c2][r]));
+                                if constexpr (STATS == 1) qq[c2][r] = fmaf(u0, u0, fmaf(u1, u1, qq[c2][r]));
                             }
                         }
                     }
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
                         st_sum[2 * cp + c2] += lane16_channel_sum(qs[c2], i16);
-                        st_sq[2 * cp + c2] += lane16_channel_sum(qq[c2], i16);
+                        if constexpr (STATS == 1) st_sq[2 * cp + c2] += lane16_channel_sum(qq[c2], i16);
                     }
                 }
             }
@@ -1148,14 +1153,14 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                     const unsigned w00 = Vec<T>::pack2(v[0][0], v[0][1]), w01 = Vec<T>::pack2(v[0][2], v[0][3]);
                     const unsigned w10 = Vec<T>::pack2(v[1][0], v[1][1]), w11 = Vec<T>::pack2(v[1][2], v[1][3]);
                     store_cbpair(cp, w00, w01, w10, w11, pix, keep);
-                    if constexpr (STATS) {                                     // column sums of the stored block sums
+                    if constexpr (STATS == 2) {                                // column sums of the stored block sums
                         qd[0][0] += keep ? Vec<T>::lo(w00) : 0.f; qd[0][1] += keep ? Vec<T>::hi(w00) : 0.f;
                         qd[0][2] += keep ? Vec<T>::lo(w01) : 0.f; qd[0][3] += keep ? Vec<T>::hi(w01) : 0.f;
                         qd[1][0] += keep ? Vec<T>::lo(w10) : 0.f; qd[1][1] += keep ? Vec<T>::hi(w10) : 0.f;
                         qd[1][2] += keep ? Vec<T>::lo(w11) : 0.f; qd[1][3] += keep ? Vec<T>::hi(w11) : 0.f;
                     }
                 }
-                if constexpr (STATS) {
+                if constexpr (STATS == 2) {
                     st_sum[2 * cp] += lane16_channel_sum(qd[0], i16);
                     st_sum[2 * cp + 1] += lane16_channel_sum(qd[1], i16);
                 }
@@ -1168,28 +1173,29 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     }
     if constexpr (STATS) {
         asm volatile("s_barrier" ::: "memory");                            // every stage has been consumed
-        float* lst = reinterpret_cast<float*>(smem);                       // [NCW compute waves][2][BN]
+        constexpr int KS = STATS == 1 ? 2 : 1;
+        float* lst = reinterpret_cast<float*>(smem);                       // [NCW compute waves][KS][BN]
         if (!(i16 & 3)) {                                                  // four lanes hold the same channel
             const int r = 2 * ((i16 >> 3) & 1) + ((i16 >> 2) & 1);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const int c = cb * 16 + 4 * kq + r;
-                lst[(wv * 2 + 0) * BN + c] = st_sum[cb];
-                lst[(wv * 2 + 1) * BN + c] = st_sq[cb];
+                lst[(wv * KS + 0) * BN + c] = st_sum[cb];
+                if constexpr (STATS == 1) lst[(wv * KS + 1) * BN + c] = st_sq[cb];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (tid < 2 * BN) {
+        if (tid < KS * BN) {
             const int k = tid / BN, c = tid % BN;
             float t = 0.f;
 #pragma unroll
-            for (int w4 = 0; w4 < NCW; ++w4) t += lst[(w4 * 2 + k) * BN + c];
-            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * 2 + k) * a.cout + co0 + c] = t;
+            for (int w4 = 0; w4 < NCW; ++w4) t += lst[(w4 * KS + k) * BN + c];
+            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * KS + k) * a.cout + co0 + c] = t;
         }
     }
 }
 
-template <typename T, bool V5, int TW, int NCT, int NPIX, bool STATS, int TAPS, int NCW>
+template <typename T, bool V5, int TW, int NCT, int NPIX, int STATS, int TAPS, int NCW>
 static constexpr auto igemm_ws_kernel() {
     // (the four-compute-wave 512-pixel tiling holds 128 accumulators per lane: the wider fragment set of v5 would spill there)
     if constexpr (V5 && sizeof(T) == 2 && NPIX / (32 * NCW) <= 2) return &conv3x3_igemm_ws16<T, TW, NCT, NPIX, STATS, TAPS, NCW>;
@@ -1197,7 +1203,7 @@ static constexpr auto igemm_ws_kernel() {
 }
 
 template <typename T, bool V5, int TW, int NCT, int NPIX, int TAPS = 9, int NCW = 4>
-static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry) {
+static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry, int smode = 1) {
     constexpr int TH = NPIX / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int IN_BYTES = NHROWS * 64, W_BYTES = TAPS * NCT * 32 * 64;
@@ -1221,7 +1227,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
     b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = a0.subpix; b.nt_in = a0.nt_in;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
-    b.gdrop = stats ? a0.gdrop : 0; b.g_inv_keep = a0.g_inv_keep; b.g_thr = a0.g_thr; b.g_state = a0.g_state; b.g_layer = a0.g_layer;
+    b.gdrop = (stats && smode == 2) ? a0.gdrop : 0; b.g_inv_keep = a0.g_inv_keep; b.g_thr = a0.g_thr; b.g_state = a0.g_state; b.g_layer = a0.g_layer;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
     const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 <= LDS_MAX;
@@ -1231,10 +1237,12 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (lds > LDS_MAX) return RVIP_OK;
     static std::atomic<int> attr_lds{0};             // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!dry && lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, false, TAPS, NCW>()),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, 0, TAPS, NCW>()),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         if constexpr (TAPS == 9) {
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, true, TAPS, NCW>()),
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, 1, TAPS, NCW>()),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, 2, TAPS, NCW>()),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         }
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
@@ -1251,16 +1259,18 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (rows_out) *rows_out = gx;
     if (dry) { used = true; return RVIP_OK; }
     if (stats) {
-        if constexpr (TAPS == 9) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, true, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
-        else return RVIP_EUNSUPPORTED;
-    } else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, false, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
+        if constexpr (TAPS == 9) {
+            if (smode == 2) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 2, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
+            else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 1, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
+        } else return RVIP_EUNSUPPORTED;
+    } else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 0, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
     used = true;
     return check_launch();
 }
 
 template <typename T, bool V5 = false>
 static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float* stats = nullptr, int* rows_out = nullptr, bool dry = false,
-                             bool wide = false) {
+                             bool wide = false, int smode = 1) {
     bool two = a.cout > 32;
     if (two && !a.subpix) {
         // small maps: 64-channel tiles can leave half of the CUs without a workgroup (e.g. 256 -> 128 at 32 x 32: 64 tiles x 2
@@ -1272,18 +1282,18 @@ static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float
     if (a.subpix) {                     // a.h, a.w = the low-resolution grid
         if (a.w > 16 && a.h >= 16) {
             // 16-bit types: eight compute waves (the 16x16x32 kernel; its four-wave form would hold 128 accumulators per lane): +0.4 % of the step
-            if (sizeof(T) == 2) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 4, 8>(a, s, used, stats, rows_out, dry);
-            return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry);
+            if (sizeof(T) == 2) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4, 8>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 32, 1, 512, 4, 8>(a, s, used, stats, rows_out, dry, smode);
+            return two ? launch_igemm_ws<T, V5, 32, 2, 512, 4>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 32, 1, 512, 4>(a, s, used, stats, rows_out, dry, smode);
         }
-        if (a.w > 16) return two ? launch_igemm_ws<T, V5, 32, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 256, 4>(a, s, used, stats, rows_out, dry);
-        return two ? launch_igemm_ws<T, V5, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry);
+        if (a.w > 16) return two ? launch_igemm_ws<T, V5, 32, 2, 256, 4>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 32, 1, 256, 4>(a, s, used, stats, rows_out, dry, smode);
+        return two ? launch_igemm_ws<T, V5, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry, smode);
     }
     if (a.w > 16 && a.h >= 16) {
-        if (wide) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 9, 8>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512, 9, 8>(a, s, used, stats, rows_out, dry);
-        return two ? launch_igemm_ws<T, V5, 32, 2, 512>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 512>(a, s, used, stats, rows_out, dry);
+        if (wide) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 9, 8>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 32, 1, 512, 9, 8>(a, s, used, stats, rows_out, dry, smode);
+        return two ? launch_igemm_ws<T, V5, 32, 2, 512>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 32, 1, 512>(a, s, used, stats, rows_out, dry, smode);
     }
-    if (a.w > 16) return two ? launch_igemm_ws<T, V5, 32, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 32, 1, 256>(a, s, used, stats, rows_out, dry);
-    return two ? launch_igemm_ws<T, V5, 16, 2, 256>(a, s, used, stats, rows_out, dry) : launch_igemm_ws<T, V5, 16, 1, 256>(a, s, used, stats, rows_out, dry);
+    if (a.w > 16) return two ? launch_igemm_ws<T, V5, 32, 2, 256>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 32, 1, 256>(a, s, used, stats, rows_out, dry, smode);
+    return two ? launch_igemm_ws<T, V5, 16, 2, 256>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 16, 1, 256>(a, s, used, stats, rows_out, dry, smode);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1695,7 +1705,7 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
 // register-staged fallback kernel, which does not fuse statistics: run rvip_bn_train_stats instead).
 extern "C" int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d) {
     ConvArgs a;
-    if (conv_args_from_desc(d, a) != RVIP_OK) return 0;
+    if (conv_args_from_desc(d, a) != RVIP_OK || d->y1 || d->down2) return 0;
     bool used = false; int rows = 0;
     const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, nullptr, &rows, true, !a.subpix); });
     return (rc == RVIP_OK && used) ? rows : 0;
@@ -1709,15 +1719,40 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
     if (rc) return rc;
     const int rows = rvip_conv3x3_fwd_stats_rows(d);
     if (!stats_ws || rows <= 0) return RVIP_EUNSUPPORTED;
-    if (d->gdrop_rate != 0.f) {                       // Dropout backward in the epilogue (data-gradient launches)
-        if (d->gdrop_rate < 0.f || d->gdrop_rate >= 1.f || !d->gdrop_state || d->y1 || d->down2 || d->subpix || (d->cout & 7)) return RVIP_EINVAL;
-        a.gdrop = 1; a.g_inv_keep = 1.f / (1.f - d->gdrop_rate); a.g_thr = dropout_thr(d->gdrop_rate);
-        a.g_state = d->gdrop_state; a.g_layer = d->gdrop_layer_id;
-    }
+    if (d->gdrop_rate != 0.f) return RVIP_EINVAL;     // (rvip_conv3x3_fwd_sums)
     if (stats_ws_bytes < (size_t)rows * 2 * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
     bool used = false;
     hipStream_t s = (hipStream_t)stream;
     rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, s, used, stats_ws, nullptr, false, !a.subpix); });
+    if (rc) return rc;
+    return used ? RVIP_OK : RVIP_EUNSUPPORTED;
+}
+
+// Data-gradient launches: the per-channel sums of the STORED result as partial rows sums_ws[rows][cout] (include/rvip_hip.h)
+extern "C" int rvip_conv3x3_fwd_sums_rows(const rvip_conv3x3_desc* d) {
+    ConvArgs a;
+    if (conv_args_from_desc(d, a) != RVIP_OK || d->subpix) return 0;
+    bool used = false; int rows = 0;
+    const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, nullptr, &rows, true, true, 2); });
+    return (rc == RVIP_OK && used) ? rows : 0;
+}
+
+extern "C" int rvip_conv3x3_fwd_sums(const rvip_conv3x3_desc* d, float* sums_ws, size_t sums_ws_bytes, void* stream) {
+    (void)hipGetLastError();
+    ConvArgs a;
+    int rc = conv_args_from_desc(d, a);
+    if (rc) return rc;
+    const int rows = rvip_conv3x3_fwd_sums_rows(d);
+    if (!sums_ws || rows <= 0) return RVIP_EUNSUPPORTED;
+    if (sums_ws_bytes < (size_t)rows * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
+    if (d->gdrop_rate != 0.f) {                       // Dropout backward in the epilogue
+        if (d->gdrop_rate < 0.f || d->gdrop_rate >= 1.f || !d->gdrop_state || d->y1 || d->down2 || (d->cout & 7)) return RVIP_EINVAL;
+        a.gdrop = 1; a.g_inv_keep = 1.f / (1.f - d->gdrop_rate); a.g_thr = dropout_thr(d->gdrop_rate);
+        a.g_state = d->gdrop_state; a.g_layer = d->gdrop_layer_id;
+    }
+    bool used = false;
+    hipStream_t s = (hipStream_t)stream;
+    rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, s, used, sums_ws, nullptr, false, true, 2); });
     if (rc) return rc;
     return used ? RVIP_OK : RVIP_EUNSUPPORTED;
 }

@@ -74,18 +74,9 @@ __device__ __forceinline__ void block_fold(const float (&part)[K][VE], bool acti
 // GROUPS row groups of 32 channels: 32 (1024 threads) halves the chain of load round trips of the 1024-row folds; a Post whose
 // epilogue needs many registers (PostBnStats: double-precision moving-average arithmetic) stays at 16 -- under the 128-VGPR
 // cap of a 1024-thread workgroup it spills, and a kernel with scratch pays for it at every (tiny) launch.
-// run_if: optional guard words -- the launch returns at once unless one of them is non-zero (rvip_bnbwd_desc.run_if)
-__device__ __forceinline__ bool guard_skips(const int* run_if, int n) {
-    if (!run_if) return false;
-    int any = 0;
-    for (int i = 0; i < n; ++i) any |= run_if[i];
-    return any == 0;
-}
 template <int K, typename Post, int GROUPS>
-__global__ __launch_bounds__(32 * GROUPS) void fold_finalize(const float* __restrict__ ws, int nblk, int width, Post post,
-                                                             const int* __restrict__ run_if = nullptr, int run_if_n = 0) {
+__global__ __launch_bounds__(32 * GROUPS) void fold_finalize(const float* __restrict__ ws, int nblk, int width, Post post) {
     __shared__ double sh[GROUPS][K][32];
-    if (guard_skips(run_if, run_if_n)) return;
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int ch = blockIdx.x * 32 + c;
     double s[K];
@@ -125,8 +116,8 @@ __global__ __launch_bounds__(32 * GROUPS) void fold_finalize(const float* __rest
 }
 
 template <int K, typename Post, int GROUPS = 32>
-static int launch_fold(const float* ws, int nblk, int width, Post post, hipStream_t s, const int* run_if = nullptr, int run_if_n = 0) {
-    hipLaunchKernelGGL((fold_finalize<K, Post, GROUPS>), dim3((unsigned)cdiv(width, 32)), dim3(32 * GROUPS), 0, s, ws, nblk, width, post, run_if, run_if_n);
+static int launch_fold(const float* ws, int nblk, int width, Post post, hipStream_t s) {
+    hipLaunchKernelGGL((fold_finalize<K, Post, GROUPS>), dim3((unsigned)cdiv(width, 32)), dim3(32 * GROUPS), 0, s, ws, nblk, width, post);
     return check_launch();
 }
 
@@ -510,7 +501,6 @@ struct BnBwdArgs {
     int act, act_after_bn, has_bn;
     float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
     long long rows; int c;
-    const int* run_if; int run_if_n;             // rvip_bn_bwd_reduce only: see guard_skips
 };
 
 // g = dL/d(BN-side output before dropout) [times act'(y) when the activation follows BN]
@@ -579,7 +569,6 @@ template <typename T, int ACT = -1, int DROP = -1, int AFTER = -1, int PARG = -1
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
     __shared__ float lds[256 * VE];
-    if (guard_skips(a.run_if, a.run_if_n)) return;
     const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
     const bool active = prow < gm.rpi;
     const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
@@ -1412,7 +1401,6 @@ static int fill_bnbwd(const rvip_bnbwd_desc* d, BnBwdArgs& a, RedGeom& g) {
     a.inv_keep = drop ? 1.f / (1.f - d->drop_rate) : 1.f; a.thr = dropout_thr(d->drop_rate);
     a.mask = d->mask; a.state = d->state; a.layer_id = d->layer_id; a.drop = drop;
     a.rows = d->rows; a.c = d->c;
-    a.run_if = nullptr; a.run_if_n = 0;
     return RVIP_OK;
 }
 
@@ -1443,10 +1431,6 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)d->workspace;
     const int fast = bnbwd_fast(a);
-    if (d->run_if) {
-        if (d->run_if_n <= 0 || d->run_if_n > 64) return RVIP_EINVAL;
-        a.run_if = d->run_if; a.run_if_n = d->run_if_n;
-    }
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
         if (fast == 1 && a.dp) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, RVIP_ACT_RELU, 0, 0, 1>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);
@@ -1458,7 +1442,7 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
     rc = check_launch();
     if (rc) return rc;
     PostBnBwd p{d->gamma, d->mean, d->invstd, d->dgamma, d->dbeta, d->coef, (double)d->rows, d->c};
-    return launch_fold<2, PostBnBwd>(ws, g.nblk, d->c, p, s, a.run_if, a.run_if_n);
+    return launch_fold<2, PostBnBwd>(ws, g.nblk, d->c, p, s);
 }
 
 // ---- stage 1 of the BatchNormalization backward from the consumers' by-products (include/rvip_hip.h: rvip_bn_bwd_coef) ----
@@ -1469,11 +1453,29 @@ struct CoefArgs {
     const float* gamma; const float* beta; const float* mean; const float* invstd;
     float* dgamma; float* dbeta; float* coef; int* flags;
     double n; int c; float min_gamma, max_beta_ratio;
+    BnBwdArgs fb;                                  // the stage's classic descriptor: the exact route of an ill-conditioned block
 };
-// 1024 threads = 32 channels x 32 row groups; double accumulation in a fixed order (sources in order, rows strided by group)
+__device__ __forceinline__ void coef_store(const CoefArgs& a, int ch, double t1, double tx) {
+    a.dbeta[ch] = (float)t1;
+    a.dgamma[ch] = (float)tx;
+    const float gm = a.gamma[ch], is = a.invstd[ch], mu = a.mean[ch];
+    const float c1 = gm * is;
+    const float c2 = -gm * is * is * (float)(tx / a.n);
+    const float c3 = -gm * is * (float)(t1 / a.n) - c2 * mu;
+    a.coef[ch] = c1; a.coef[a.c + ch] = c2; a.coef[2 * a.c + ch] = c3;
+}
+// 1024 threads = 32 channels x 32 row groups; double accumulation in a fixed order (sources in order, rows strided by group).
+// A workgroup whose 32 channels hold an ill-conditioned one (|gamma| tiny, or |beta| >> |gamma|: the division below would amplify
+// the rounding of the sums) recomputes ITS channels the classic way -- one workgroup streaming (g, z) of 32 channels, slow and
+// exact; the condition does not arise in training from the Keras initialisation (gamma = 1, beta = 0), so the launch list needs
+// no second, guarded kernel.
+template <typename T>
 __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(CoefArgs a) {
+    constexpr int VE = Vec<T>::VE, NV = 32 / VE, NS = 1024 / NV;
     __shared__ double sh[2][32][32];
+    __shared__ float part_lds[NS][32];
     __shared__ int bad[32];
+    __shared__ int sbad;
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int ch = blockIdx.x * 32 + c;
     double s[2] = {0.0, 0.0};
@@ -1497,22 +1499,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(CoefArgs a) {
     }
     sh[0][g][c] = s[0]; sh[1][g][c] = s[1];
     __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+    float gm = 1.f, bt = 0.f;
     if (g == 0) {
         int isbad = 0;
         if (ch < a.c) {
-            double t1 = 0.0, t2 = 0.0;
 #pragma unroll
             for (int gg = 0; gg < 32; ++gg) { t1 += sh[0][gg][c]; t2 += sh[1][gg][c]; }
-            const float gm = a.gamma[ch], bt = a.beta ? a.beta[ch] : 0.f, is = a.invstd[ch], mu = a.mean[ch];
+            gm = a.gamma[ch]; bt = a.beta ? a.beta[ch] : 0.f;
             isbad = !(fabsf(gm) >= a.min_gamma && fabsf(bt) <= a.max_beta_ratio * fabsf(gm));
-            // y = gamma * xhat + beta  =>  sum g*xhat = (sum g*y - beta * sum g) / gamma
-            const double tx = isbad ? 0.0 : (t2 - (double)bt * t1) / (double)gm;
-            a.dbeta[ch] = (float)t1;
-            a.dgamma[ch] = (float)tx;
-            const float c1 = gm * is;
-            const float c2 = -gm * is * is * (float)(tx / a.n);
-            const float c3 = -gm * is * (float)(t1 / a.n) - c2 * mu;
-            a.coef[ch] = c1; a.coef[a.c + ch] = c2; a.coef[2 * a.c + ch] = c3;
         }
         bad[c] = isbad;
     }
@@ -1521,14 +1516,63 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(CoefArgs a) {
         int any = 0;
         for (int i = 0; i < 32; ++i) any |= bad[i];
         a.flags[blockIdx.x] = any;
+        sbad = any;
     }
+    __syncthreads();
+    if (!sbad) {
+        // y = gamma * xhat + beta  =>  sum g*xhat = (sum g*y - beta * sum g) / gamma
+        if (g == 0 && ch < a.c) coef_store(a, ch, t1, (t2 - (double)bt * t1) / (double)gm);
+        return;
+    }
+    // ---------------- exact route for this block: sum g and sum g*xhat over every row, as rvip_bn_bwd_reduce computes them ----------------
+    const BnBwdArgs& f = a.fb;
+    const int cv = threadIdx.x % NV, slot = threadIdx.x / NV, cgi = blockIdx.x * NV + cv, cg = a.c / VE;
+    const bool active = cgi < cg;
+    const uint32_t key = (f.drop && !f.mask) ? dropout_key(f.state[RVIP_STATE_SEED], f.state[RVIP_STATE_STEP], (uint32_t)f.layer_id) : 0u;
+    float part[2][VE], mu[VE], is[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        part[0][e] = part[1][e] = 0.f;
+        mu[e] = active ? a.mean[cgi * VE + e] : 0.f;
+        is[e] = active ? a.invstd[cgi * VE + e] : 0.f;
+    }
+    if (active) {
+        for (long long rr = slot; rr < f.rows; rr += NS) {
+            float z[VE], gv[VE];
+            GyRaw<VE> raw;
+            const size_t e0 = (size_t)rr * a.c + cgi * VE;
+            Vec<T>::load(f.z + e0 * sizeof(T), z);
+            gy_issue<T, VE, -1, false>(f, rr, cgi, cg, e0, raw);
+            gy_finish<T, VE, -1>(f, raw, gv);
+            xform_g<T, VE>(f, e0, cgi * VE, key, z, gv);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { part[0][e] += gv[e]; part[1][e] = fmaf(gv[e], (z[e] - mu[e]) * is[e], part[1][e]); }
+        }
+    }
+    double tot[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VE; ++e) part_lds[slot][cv * VE + e] = part[k][e];
+        __syncthreads();
+        double acc = 0.0;
+        for (int r = g; r < NS; r += 32) acc += (double)part_lds[r][c];
+        sh[k][g][c] = acc;
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int gg = 0; gg < 32; ++gg) tot[k] += sh[k][gg][c];
+        }
+    }
+    if (g == 0 && ch < a.c) coef_store(a, ch, tot[0], tot[1]);
 }
 }  // namespace rvip
 
 extern "C" int rvip_bn_bwd_coef(const rvip_bncoef_desc* d, void* stream) {
     (void)hipGetLastError();
     if (!d || d->c <= 0 || d->count <= 0 || !d->gamma || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->coef || !d->flags) return RVIP_EINVAL;
-    if (!d->t1[0].rows || !d->t2[0].rows || !(d->min_gamma > 0.f) || !(d->max_beta_ratio > 0.f)) return RVIP_EINVAL;
+    if (!d->t1[0].rows || !d->t2[0].rows || !(d->min_gamma > 0.f) || !(d->max_beta_ratio > 0.f) || !d->fallback) return RVIP_EINVAL;
     CoefArgs a;
     for (int q = 0; q < 2; ++q) {
         const rvip_bncoef_src* in[2] = {&d->t1[q], &d->t2[q]};
@@ -1538,10 +1582,17 @@ extern "C" int rvip_bn_bwd_coef(const rvip_bncoef_desc* d, void* stream) {
             *out[k] = CoefSrc{in[k]->rows, in[k]->nrows, in[k]->stride, in[k]->offset};
         }
     }
+    RedGeom g;
+    const int rc = fill_bnbwd(d->fallback, a.fb, g);
+    if (rc) return rc;
+    if (d->fallback->c != d->c || d->fallback->rows != d->count || d->fallback->act_after_bn || !d->fallback->gamma) return RVIP_EINVAL;
     a.gamma = d->gamma; a.beta = d->beta; a.mean = d->mean; a.invstd = d->invstd;
     a.dgamma = d->dgamma; a.dbeta = d->dbeta; a.coef = d->coef; a.flags = d->flags;
     a.n = (double)d->count; a.c = d->c; a.min_gamma = d->min_gamma; a.max_beta_ratio = d->max_beta_ratio;
-    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((unsigned)cdiv(d->c, 32)), dim3(1024), 0, (hipStream_t)stream, a);
+    by_dtype(d->fallback->dtype, [&](auto t) {
+        hipLaunchKernelGGL(bn_bwd_coef_kernel<decltype(t)>, dim3((unsigned)cdiv(d->c, 32)), dim3(1024), 0, (hipStream_t)stream, a);
+        return 0;
+    });
     return check_launch();
 }
 

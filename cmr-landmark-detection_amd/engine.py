@@ -540,8 +540,8 @@ class Engine:
         # For a stage  z -> BN -> [Dropout] -> y  every consumer of y is a 3x3 conv (directly, through MaxPooling2D / UpSampling2D, or
         # as the skip half of a Concatenate), so  sum g  is the column sum of the consumers' data-gradient outputs (fused into their
         # epilogues, Dropout backward included) and  sum g*y = sum W * dW  of the consumers (read off their weight gradients while the
-        # split-K slabs are folded).  The 2 x tensor re-read of rvip_bn_bwd_reduce disappears; the classic kernels stay in the launch
-        # list behind a device-side guard (ill-conditioned gamma / beta) and return at once otherwise.
+        # split-K slabs are folded).  The 2 x tensor re-read of rvip_bn_bwd_reduce disappears; a 32-channel block with an ill-conditioned
+        # gamma / beta takes the exact route inside rvip_bn_bwd_coef itself.
         alg_on = os.environ.get('RVIP_BNBWD_ALGEBRAIC', '1') != '0'
         producer = {}
         for st in plan.stages:
@@ -564,13 +564,14 @@ class Engine:
             for c, which in cl:
                 if c.conv not in dg_desc or c.up0 == 2 or (c.up0 == 1 and not fuse_down_on) or (dropping and (c.src1 or c.up0)):
                     return False
-                if L.rvip_conv3x3_fwd_stats_rows(C.byref(dg_desc[c.conv])) <= 0:
+                if L.rvip_conv3x3_fwd_sums_rows(C.byref(dg_desc[c.conv])) <= 0:
                     return False
                 if dropping and (c.cin % 8):
                     return False
             return True
         self.algebraic = {p.conv for p in plan.stages if algebraic_ok(p)}
         self._alg_bufs = {}
+        self.bn_flags = {}                      # stage -> device flags of rvip_bn_bwd_coef (1 = that 32-channel block took the exact route)
         sums_rows, dot_rows = {}, {}            # consumer conv name -> (tensor, nrows)
         for p in plan.stages:
             if p.conv not in self.algebraic:
@@ -578,8 +579,8 @@ class Engine:
             for c, which in consumers[p.conv]:
                 dg, wg = dg_desc[c.conv], wg_desc[c.conv]
                 if c.conv not in sums_rows:
-                    nr = L.rvip_conv3x3_fwd_stats_rows(C.byref(dg))
-                    sums_rows[c.conv] = (torch.zeros(nr * 2 * c.cin, dtype=torch.float32, device=self.ws.device), nr)
+                    nr = L.rvip_conv3x3_fwd_sums_rows(C.byref(dg))
+                    sums_rows[c.conv] = (torch.zeros(nr * c.cin, dtype=torch.float32, device=self.ws.device), nr)
                     nd = L.rvip_conv3x3_wgrad_dot_rows(C.byref(wg))
                     dbuf = torch.zeros(nd * c.cin, dtype=torch.float32, device=self.ws.device)
                     dot_rows[c.conv] = (dbuf, nd)
@@ -650,7 +651,7 @@ class Engine:
                         off = 0 if which == 0 else c.c0
                         sbuf_, nr = sums_rows[c.conv]
                         dbuf_, nd = dot_rows[c.conv]
-                        cd.t1[q].rows, cd.t1[q].nrows, cd.t1[q].stride, cd.t1[q].offset = sbuf_.data_ptr(), nr, 2 * c.cin, off
+                        cd.t1[q].rows, cd.t1[q].nrows, cd.t1[q].stride, cd.t1[q].offset = sbuf_.data_ptr(), nr, c.cin, off
                         cd.t2[q].rows, cd.t2[q].nrows, cd.t2[q].stride, cd.t2[q].offset = dbuf_.data_ptr(), nd, c.cin, off
                     cd.gamma, cd.beta = P.p(st.bn, 'gamma').value, P.p(st.bn, 'beta').value
                     cd.mean, cd.invstd = b.mean, b.invstd
@@ -660,10 +661,11 @@ class Engine:
                     self._fold_bufs.append(flags)
                     cd.flags, cd.count, cd.c = flags.data_ptr(), rows, st.cout
                     cd.min_gamma, cd.max_beta_ratio = min_gamma, max_beta_ratio
+                    cd.fallback = C.pointer(b)                   # the exact route of an ill-conditioned block reads what the apply pass reads
                     self._keep.append(cd)
+                    self.bn_flags[st.conv] = flags
                     bwd.append((L.rvip_bn_bwd_coef, (C.byref(cd),)))
-                    b.run_if, b.run_if_n = flags.data_ptr(), nflags       # the classic reduction: runs only when a flag is set
-                if st.bn:
+                elif st.bn:
                     bwd.append((L.rvip_bn_bwd_reduce, (C.byref(b),)))
                 bwd.append((L.rvip_bn_bwd_apply, (C.byref(b),)))
             if first and self.kd == 3:
@@ -689,7 +691,7 @@ class Engine:
             fuse_down = st.up0 == 1 and fuse_down_on
             if st.conv in sums_rows:        # the column sums of the result ride in the epilogue (sum g of the producers' BN backward)
                 sb = sums_rows[st.conv][0]
-                bwd.append((L.rvip_conv3x3_fwd_stats, (C.byref(dg), _ptr(sb), C.c_size_t(sb.numel() * 4))))
+                bwd.append((L.rvip_conv3x3_fwd_sums, (C.byref(dg), _ptr(sb), C.c_size_t(sb.numel() * 4))))
             else:
                 bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
             if st.up0 and not fuse_down:    # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions

@@ -100,10 +100,10 @@ typedef struct rvip_conv3x3_desc {
     /* stream_in != 0: hint that this launch is the last reader of x0 for a while (e.g. the data gradient reading dz):
      * its input is fetched with the non-temporal cache policy. */
     int32_t      stream_in;
-    /* rvip_conv3x3_fwd_stats only, data-gradient launches (ABI 5): the result is the gradient reaching the OUTPUT of a Dropout layer
-     * (KerasLayers.py:718,772) and what is stored -- and summed -- is the gradient at its INPUT: keep ? g / (1 - gdrop_rate) : 0
-     * with the keep bits of the counter stream (gdrop_state, gdrop_layer_id: the Dropout layer's id, element index = position in y).
-     * The BN-backward apply pass of the producer stage then runs without dropout.  0 = none; not with y1 / down2 / subpix. */
+    /* rvip_conv3x3_fwd_sums only (ABI 5): the result is the gradient reaching the OUTPUT of a Dropout layer (KerasLayers.py:718,772)
+     * and what is stored -- and summed -- is the gradient at its INPUT: keep ? g / (1 - gdrop_rate) : 0 with the keep bits of the
+     * counter stream (gdrop_state, gdrop_layer_id: the Dropout layer's id, element index = position in y).  The BN-backward apply
+     * pass of the producer stage then runs without dropout.  0 = none; not with y1 / down2. */
     float        gdrop_rate; const uint32_t* gdrop_state; int32_t gdrop_layer_id;
 } rvip_conv3x3_desc;
 
@@ -112,12 +112,15 @@ int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
 /* The same convolution with the BatchNormalization statistics of its (stored) output fused into the epilogue:
  * writes rvip_conv3x3_fwd_stats_rows(d) partial rows [rows][2][cout] (per-channel sum, sum of squares) to stats_ws;
  * finish with rvip_bn_stats_finalize.  rows == 0 means this shape runs on the register-staged fallback kernel,
- * which does not fuse statistics (use rvip_conv3x3_fwd + rvip_bn_train_stats).
- * ABI 5: also valid for data-gradient launches -- with y1 (channel c of the virtual [y, y1] row is column c of the partial rows),
- * with down2 (sums of the stored 2x2 block sums; the sum-of-squares half stays zero) and with gdrop_rate: the column sums are the
- * `T1 = sum g` term of the producer's BatchNormalization backward, see rvip_bn_bwd_coef. */
+ * which does not fuse statistics (use rvip_conv3x3_fwd + rvip_bn_train_stats).  Not with y1 / down2 / subpix. */
 int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d);
 int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_ws, size_t stats_ws_bytes, void* stream);
+/* ABI 5, for data-gradient launches: the convolution with the per-channel SUMS of its stored result as rvip_conv3x3_fwd_sums_rows(d)
+ * partial rows [rows][cout] -- also with y1 (channel c of the virtual [y, y1] row is column c), with down2 (sums of the stored 2x2
+ * block sums) and with gdrop_rate.  Added over the rows, column c is the `T1 = sum g` term of the BatchNormalization backward of
+ * the stage that produced channel c of this launch's result tensor (rvip_bn_bwd_coef).  rows == 0: fallback kernel, no sums. */
+int rvip_conv3x3_fwd_sums_rows(const rvip_conv3x3_desc* d);
+int rvip_conv3x3_fwd_sums(const rvip_conv3x3_desc* d, float* sums_ws, size_t sums_ws_bytes, void* stream);
 
 /* Re-layout the fp32 HWIO master kernel [3][3][Cin][Cout] into the two packed operands:
  *   w_fwd [9][Cout][Cin]  (w_fwd[t][o][i] = W[t][i][o])        -- forward
@@ -283,10 +286,6 @@ typedef struct rvip_bnbwd_desc {
      * round(dy + (argmax of its window == 2*(y&1) + (x&1) ? dpooled : 0)), dy = the skip-connection gradient (may be NULL),
      * exactly the tensor rvip_maxpool2x2_bwd would have stored; rows = n*h*w. */
     const void*  dpooled; const uint16_t* argmax; int32_t h, w;
-    /* run_if != NULL (ABI 5, rvip_bn_bwd_reduce only): both kernels of the stage return at once unless one of the run_if_n
-     * words is non-zero -- the conditioning flags rvip_bn_bwd_coef wrote for this stage.  The launch stays in a captured graph
-     * as the exact fallback of the algebraic route and costs a few microseconds when it is not needed. */
-    const int32_t* run_if; int32_t run_if_n;
 } rvip_bnbwd_desc;
 int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream);
 int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream);
@@ -294,20 +293,23 @@ int rvip_bn_bwd_rows(long long rows, int c, int dtype);
 
 /* Stage 1 of the BatchNormalization backward WITHOUT a pass over (g, z) (ABI 5).  For a stage  z -> BN -> [Dropout] -> y  whose
  * consumers are 3x3 convolutions (through MaxPooling2D / UpSampling2D / Concatenate or directly):
- *   T1[c] = sum g[c]       = column sums of the consumers' data-gradient outputs        (rvip_conv3x3_fwd_stats rows, k = 0)
+ *   T1[c] = sum g[c]       = column sums of the consumers' data-gradient outputs        (rvip_conv3x3_fwd_sums rows)
  *   T2[c] = sum g[c]*y[c]  = sum_{t,o} W[t][c][o] * dW[t][c][o] over the consumers      (rvip_conv3x3_wgrad dot_rows)
  * and with y = gamma * xhat + beta:  dbeta = T1,  dgamma = sum g*xhat = (T2 - beta*T1) / gamma.  Up to two sources per term
  * (a pooled stage with a skip connection has two consumers); source = `nrows` rows of `stride` floats, this stage's channels
  * start at column `offset`.  Writes dgamma, dbeta and the coef[3][C] vectors of rvip_bn_bwd_apply exactly like
- * rvip_bn_bwd_reduce.  The division needs |gamma| >= min_gamma and |beta| <= max_beta_ratio * |gamma| in every channel; the
- * kernel writes flags[ceil(C/32)] (1 = some channel of that block fails) and the caller follows with rvip_bn_bwd_reduce(run_if =
- * flags), which recomputes the stage the classic way when -- and only when -- a flag is set. */
+ * rvip_bn_bwd_reduce.  The division needs |gamma| >= min_gamma and |beta| <= max_beta_ratio * |gamma|: a workgroup (32 channels)
+ * that holds a channel failing the test recomputes ITS channels exactly -- sum g and sum g*xhat over every row of (g, z) as
+ * described by `fallback`, the stage's rvip_bn_bwd_reduce descriptor (dy = the gradient the apply pass will read; drop_rate 0
+ * when the consumer's data gradient already applied the Dropout backward) -- slowly (one workgroup per 32 channels), inside the
+ * same launch; flags[ceil(C/32)] reports which blocks did (1).  Training from the Keras initialisation never takes that route. */
 typedef struct rvip_bncoef_src { const float* rows; int32_t nrows; int32_t stride; int32_t offset; int32_t reserved; } rvip_bncoef_src;
 typedef struct rvip_bncoef_desc {
     rvip_bncoef_src t1[2]; rvip_bncoef_src t2[2];      /* rows == NULL: unused */
     const float* gamma; const float* beta; const float* mean; const float* invstd;
     float*       dgamma; float* dbeta; float* coef;
     int32_t*     flags;                                /* [ceil(c / 32)] */
+    const struct rvip_bnbwd_desc* fallback;            /* required; c, rows == count, act before BN (act_after_bn == 0) */
     long long    count;                                /* N*H*W of the stage */
     int32_t      c;
     float        min_gamma, max_beta_ratio;

@@ -1,10 +1,10 @@
 """BatchNormalization backward without its reduction pass (ABI 5): the pieces, each through the C ABI.
 
-  sum g    = column sums of the consumer's data-gradient output   (rvip_conv3x3_fwd_stats on a dgrad launch: plain, channel split,
-             2x2 block sums, Dropout backward in the epilogue)
+  sum g    = column sums of the consumer's data-gradient output   (rvip_conv3x3_fwd_sums: plain, channel split, 2x2 block sums,
+             Dropout backward in the epilogue)
   sum g*y  = sum_{t,o} W[t][c][o] * dW[t][c][o]                   (rvip_conv3x3_wgrad with dot_rows)
-  stage 1  = rvip_bn_bwd_coef, held against the classic rvip_bn_bwd_reduce on the same chain, and the device-side guard that
-             falls back to it.
+  stage 1  = rvip_bn_bwd_coef, held against the classic rvip_bn_bwd_reduce on the same chain, and its exact in-kernel route for
+             ill-conditioned channel blocks.
 The identity is the adjoint relation of the conv (autodiff of Conv2D, KerasLayers.py:683-691): <dX, X> = <dY, W * X> per input
 channel.  End-to-end parity of the engine that uses these lives in tests/test_gpu_model.py."""
 import ctypes as C
@@ -22,12 +22,12 @@ pytestmark = pytest.mark.gpu
 N = rvip._native
 
 
-def _stats_launch(d, cols):
+def _sums_launch(d, cols):
     L = N.lib()
-    rows = L.rvip_conv3x3_fwd_stats_rows(C.byref(d))
+    rows = L.rvip_conv3x3_fwd_sums_rows(C.byref(d))
     assert rows > 0
-    buf = torch.full((rows, 2, cols), 7.0, dtype=torch.float32, device=dev())
-    N.call('rvip_conv3x3_fwd_stats', C.byref(d), P(buf), C.c_size_t(buf.numel() * 4), stream())
+    buf = torch.full((rows, cols), 7.0, dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_fwd_sums', C.byref(d), P(buf), C.c_size_t(buf.numel() * 4), stream())
     return down(buf).astype(np.float64)
 
 
@@ -35,7 +35,7 @@ def _stats_launch(d, cols):
 @pytest.mark.parametrize('shape', [(2, 24, 40, 32, 32), (1, 16, 16, 16, 40), (2, 40, 72, 64, 64), (2, 8, 72, 8, 8)])
 @pytest.mark.parametrize('mode', ['plain', 'split', 'down2', 'dropout'])
 def test_dgrad_epilogue_column_sums(shape, dtype, mode):
-    """The statistics launch stores what the plain launch stores (Dropout backward applied in 'dropout') and its partial rows add
+    """The launch with column sums stores what the plain launch stores (Dropout backward applied in 'dropout') and its partial rows add
     up to the column sums of the STORED tensor."""
     n, h, w, ci, co = shape                                         # the data gradient maps dy [.., co] to dx [.., ci]
     if mode == 'split' and ci < 64:
@@ -67,7 +67,7 @@ def test_dgrad_epilogue_column_sums(shape, dtype, mode):
     rate, lid = 0.3, 4
     if mode == 'dropout':
         d.gdrop_rate, d.gdrop_state, d.gdrop_layer_id = rate, state.data_ptr(), lid
-    rows = _stats_launch(d, ci)
+    rows = _sums_launch(d, ci)
     stored = down(yb) if y1b is None else np.concatenate([down(yb), down(y1b)], -1)
     if mode == 'dropout':
         keep = ds.keep_mask((n, h, w, ci), rate, 99, 5, lid).astype(bool)
@@ -78,11 +78,9 @@ def test_dgrad_epilogue_column_sums(shape, dtype, mode):
         plain = down(ya) if y1a is None else np.concatenate([down(ya), down(y1a)], -1)
         np.testing.assert_array_equal(stored, plain)                # same bits as the launch without statistics
     want = stored.astype(np.float64).reshape(-1, ci).sum(0)
-    got = rows[:, 0, :].sum(0)
+    got = rows.sum(0)
     tol = 1e-5 * np.abs(stored.astype(np.float64)).reshape(-1, ci).sum(0).max() + 1e-6
     assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), tol)
-    if mode == 'down2':
-        assert not rows[:, 1, :].any()                              # no sum of squares in this mode
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
@@ -167,10 +165,9 @@ def _bn_chain(dtype, rate, n=2, h=24, w=40, c=32, co=64, seed=3, gamma_scale=1.0
     return k
 
 
-def _classic(k, gy, rate, run_if=None):
+def _classic_desc(k, gy, rate, out):
+    """the stage's rvip_bn_bwd_reduce descriptor: gradient gy, Dropout backward at `rate` inside the pass"""
     c = k['c']
-    out = dict(dgamma=torch.full((c,), 7.0, dtype=torch.float32, device=dev()), dbeta=torch.full((c,), 7.0, dtype=torch.float32, device=dev()),
-               coef=torch.full((3 * c,), 7.0, dtype=torch.float32, device=dev()))
     b = N.BnBwdDesc()
     b.dy, b.z, b.dz = gy.data_ptr(), k['zd'].data_ptr(), None
     b.gamma, b.mean, b.invstd = k['gd'].data_ptr(), k['mean'].data_ptr(), k['invstd'].data_ptr()
@@ -179,8 +176,17 @@ def _classic(k, gy, rate, run_if=None):
     b.drop_rate, b.mask, b.state, b.layer_id = rate, None, k['state'].data_ptr(), k['lid']
     b.rows, b.c, b.dtype = k['rows'], c, ndt(k['dtype'])
     b.workspace, b.workspace_bytes = k['ws'].data_ptr(), k['wsb']
-    if run_if is not None:
-        b.run_if, b.run_if_n = run_if.data_ptr(), run_if.numel()
+    return b
+
+
+def _outputs(c):
+    return dict(dgamma=torch.full((c,), 7.0, dtype=torch.float32, device=dev()), dbeta=torch.full((c,), 7.0, dtype=torch.float32, device=dev()),
+                coef=torch.full((3 * c,), 7.0, dtype=torch.float32, device=dev()))
+
+
+def _classic(k, gy, rate):
+    out = _outputs(k['c'])
+    b = _classic_desc(k, gy, rate, out)
     N.call('rvip_bn_bwd_reduce', C.byref(b), stream())
     return {kk: down(v).astype(np.float64) for kk, v in out.items()}
 
@@ -212,64 +218,67 @@ def test_bn_bwd_coef_equals_the_reduction_pass(dtype, rate):
     dst = conv_desc(k['dz2'], co, 0, None, 0, k['wd'], None, g2, None, 0, n, h, w, c, 0, dtype)
     if rate:
         dst.gdrop_rate, dst.gdrop_state, dst.gdrop_layer_id = rate, k['state'].data_ptr(), k['lid']
-    nr = L.rvip_conv3x3_fwd_stats_rows(C.byref(dst))
-    srows = torch.empty((nr, 2, c), dtype=torch.float32, device=dev())
-    N.call('rvip_conv3x3_fwd_stats', C.byref(dst), P(srows), C.c_size_t(srows.numel() * 4), stream())
+    nr = L.rvip_conv3x3_fwd_sums_rows(C.byref(dst))
+    srows = torch.empty((nr, c), dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_fwd_sums', C.byref(dst), P(srows), C.c_size_t(srows.numel() * 4), stream())
 
     def coef(min_gamma):
-        out = dict(dgamma=torch.full((c,), 7.0, dtype=torch.float32, device=dev()), dbeta=torch.full((c,), 7.0, dtype=torch.float32, device=dev()),
-                   coef=torch.full((3 * c,), 7.0, dtype=torch.float32, device=dev()), flags=torch.full((-(-c // 32),), 7, dtype=torch.int32, device=dev()))
+        out = _outputs(c)
+        out['flags'] = torch.full((-(-c // 32),), 7, dtype=torch.int32, device=dev())
+        fb = _classic_desc(k, g2, 0.0, out)                   # what the engine hands over: the already-masked gradient, no dropout in the pass
         cd = N.BnCoefDesc()
-        cd.t1[0].rows, cd.t1[0].nrows, cd.t1[0].stride, cd.t1[0].offset = srows.data_ptr(), nr, 2 * c, 0
+        cd.t1[0].rows, cd.t1[0].nrows, cd.t1[0].stride, cd.t1[0].offset = srows.data_ptr(), nr, c, 0
         cd.t2[0].rows, cd.t2[0].nrows, cd.t2[0].stride, cd.t2[0].offset = drows.data_ptr(), nd, c, 0
         cd.gamma, cd.beta, cd.mean, cd.invstd = k['gd'].data_ptr(), k['bd'].data_ptr(), k['mean'].data_ptr(), k['invstd'].data_ptr()
         cd.dgamma, cd.dbeta, cd.coef, cd.flags = out['dgamma'].data_ptr(), out['dbeta'].data_ptr(), out['coef'].data_ptr(), out['flags'].data_ptr()
         cd.count, cd.c, cd.min_gamma, cd.max_beta_ratio = k['rows'], c, min_gamma, 64.0
+        cd.fallback = C.pointer(fb)
         N.call('rvip_bn_bwd_coef', C.byref(cd), stream())
-        return out
-    out = coef(1.0 / 64)
-    assert not down(out['flags']).any()
+        return {kk: down(v).astype(np.float64) for kk, v in out.items()}
     # the two routes see the same g up to its storage rounding (the algebraic sum g*y uses the unrounded data gradient)
     tol = {'f32': 2e-5, 'bf16': 4e-3, 'f16': 6e-4}[dtype]
-    for name in ('dbeta', 'dgamma', 'coef'):
-        got, want = down(out[name]).astype(np.float64), ref[name]
-        if name == 'coef':
-            got, want = got.reshape(3, c), want.reshape(3, c)
-            for i in range(3):
+
+    def check(out):
+        for name in ('dbeta', 'dgamma', 'coef'):
+            got, want = out[name].reshape(-1, c), ref[name].reshape(-1, c)
+            for i in range(got.shape[0]):
                 assert np.abs(got[i] - want[i]).max() <= tol * np.abs(want[i]).max() + 1e-12, (name, i, np.abs(got[i] - want[i]).max(), np.abs(want[i]).max())
-        else:
-            assert np.abs(got - want).max() <= tol * np.abs(want).max(), (name, np.abs(got - want).max(), np.abs(want).max())
-    # the guard: every channel "ill-conditioned" -> flags set, and the guarded classic launch then produces the classic result
-    # (from the already-masked gradient, as the engine runs it); with clear flags it leaves its outputs alone
+    out = coef(1.0 / 64)
+    assert not out['flags'].any()
+    check(out)
+    # every channel declared ill-conditioned: the launch takes its exact route (sum g, sum g*xhat over all rows, inside the kernel)
     bad = coef(1e9)
-    assert down(bad['flags']).all()
-    redo = _classic(k, g2, 0.0, run_if=bad['flags'])
-    for name in ('dbeta', 'dgamma', 'coef'):
-        np.testing.assert_allclose(redo[name], ref[name], rtol=0, atol={'f32': 2e-5, 'bf16': 4e-3, 'f16': 6e-4}[dtype] * np.abs(ref[name]).max())
-    untouched = _classic(k, g2, 0.0, run_if=out['flags'])
-    assert all((v == 7.0).all() for v in untouched.values())
+    assert bad['flags'].all()
+    check(bad)
 
 
 def test_bn_bwd_coef_flags_small_gamma_and_refuses_bad_arguments():
     k = _bn_chain('f32', 0.0, c=64, gamma_scale=1.0)
     c = k['c']
-    gam = down(k['gd']).copy()
+    gam = np.abs(down(k['gd'])) + 0.5                               # every channel well-conditioned ...
     gam[40] = 1e-4                                                   # one channel of the second 32-channel block
     k['gd'].copy_(torch.from_numpy(gam))
     rows = torch.ones((4, c), dtype=torch.float32, device=dev())
-    out = [torch.zeros(c, dtype=torch.float32, device=dev()) for _ in range(2)] + [torch.zeros(3 * c, dtype=torch.float32, device=dev())]
+    o = _outputs(c)
+    out = [o['dgamma'], o['dbeta'], o['coef']]
+    gy = torch.zeros((k['n'], k['h'], k['w'], c), dtype=torch.float32, device=dev())
+    fb = _classic_desc(k, gy, 0.0, o)
     flags = torch.full((2,), 7, dtype=torch.int32, device=dev())
     cd = N.BnCoefDesc()
+    cd.fallback = C.pointer(fb)
     cd.t1[0].rows, cd.t1[0].nrows, cd.t1[0].stride, cd.t1[0].offset = rows.data_ptr(), 4, c, 0
     cd.t2[0].rows, cd.t2[0].nrows, cd.t2[0].stride, cd.t2[0].offset = rows.data_ptr(), 4, c, 0
     cd.gamma, cd.beta, cd.mean, cd.invstd = k['gd'].data_ptr(), k['bd'].data_ptr(), k['mean'].data_ptr(), k['invstd'].data_ptr()
     cd.dgamma, cd.dbeta, cd.coef, cd.flags = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), flags.data_ptr()
     cd.count, cd.c, cd.min_gamma, cd.max_beta_ratio = k['rows'], c, 1.0 / 64, 64.0
     N.call('rvip_bn_bwd_coef', C.byref(cd), stream())
-    assert down(flags).tolist() == [0, 1]
-    np.testing.assert_allclose(down(out[1]), 4.0)                    # dbeta = sum of the T1 rows
+    assert down(flags).tolist() == [0, 1]                           # ... except one
+    np.testing.assert_allclose(down(out[1])[:32], 4.0)               # dbeta = sum of the T1 rows in the algebraic block,
+    np.testing.assert_allclose(down(out[1])[32:], 0.0)               # = sum of the (zero) gradient tensor in the block that went the exact way
     L = N.lib()
     cd.min_gamma = 0.0
     assert L.rvip_bn_bwd_coef(C.byref(cd), stream()) == -1
     cd.min_gamma, cd.t1[0].stride = 1.0 / 64, c - 1
+    assert L.rvip_bn_bwd_coef(C.byref(cd), stream()) == -1
+    cd.t1[0].stride, cd.fallback = c, None
     assert L.rvip_bn_bwd_coef(C.byref(cd), stream()) == -1
