@@ -160,7 +160,7 @@ def main():
         import ctypes as C
         s = torch.cuda.current_stream()
         L = rvip._native.lib()
-        conv_fn, conv_stats_fn, wgrad_fn = L.rvip_conv3x3_fwd, L.rvip_conv3x3_fwd_stats, L.rvip_conv3x3_wgrad
+        conv_fn, conv_stats_fn, conv_sums_fn, wgrad_fn = L.rvip_conv3x3_fwd, L.rvip_conv3x3_fwd_stats, L.rvip_conv3x3_fwd_sums, L.rvip_conv3x3_wgrad
         reps = 3
         agg = {}
         detail = []
@@ -176,7 +176,7 @@ def main():
                     e1.record(s)
                     assert rc == 0
                     flops = 0.0
-                    if fn is conv_fn or fn is conv_stats_fn:      # the same igemm kernels; the second adds the BN partial sums
+                    if fn is conv_fn or fn is conv_stats_fn or fn is conv_sums_fn:      # the same igemm kernels; the others add the BN partial sums / the column sums
                         d = a[0]._obj
                         flops = 2.0 * d.n * d.h * d.w * 9 * max(d.kd, 1) * (d.c0 + d.c1) * d.cout
                     elif fn is wgrad_fn:
@@ -202,7 +202,7 @@ def main():
             fl = sum(f for _, _, f in evs)
             per_kernel[name] = dict(launches_per_step=len(evs) // reps, ms_per_step=round(ms / reps, 4),
                                     tflops=round(fl / (ms * 1e-3) / 1e12, 2) if (fl > 0 and ms > 0) else None)
-        cv = agg['rvip_conv3x3_fwd'] + agg.get('rvip_conv3x3_fwd_stats', [])
+        cv = agg['rvip_conv3x3_fwd'] + agg.get('rvip_conv3x3_fwd_stats', []) + agg.get('rvip_conv3x3_fwd_sums', [])
         ms = sum(a.elapsed_time(b) for a, b, _ in cv)
         fl = sum(f for _, _, f in cv)
         achieved = fl / (ms * 1e-3) / 1e12

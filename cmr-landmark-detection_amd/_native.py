@@ -35,7 +35,7 @@ class Conv3x3Desc(C.Structure):
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('act', C.c_int32), ('dtype', C.c_int32),
                 ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32), ('subpix', C.c_int32), ('stream_in', C.c_int32),
-                ('gdrop_rate', C.c_float), ('gdrop_state', vp), ('gdrop_layer_id', C.c_int32)]
+                ('gdrop_rate', C.c_float), ('gdrop_state', vp), ('gdrop_layer_id', C.c_int32), ('sums_from', C.c_int32)]
 
 
 class PackEntry(C.Structure):

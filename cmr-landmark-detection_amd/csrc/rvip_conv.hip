@@ -52,6 +52,7 @@ struct ConvArgs {
     int nt_in;                                // non-temporal input reads (last reader of x0)
     // statistics launches of a data gradient whose output crosses a Dropout layer backwards: store / sum keep ? g * inv_keep : 0
     int gdrop; float g_inv_keep; uint32_t g_thr; const uint32_t* g_state; int g_layer;
+    int sums_from;
 };
 
 template <typename T, int TW, int NCT>
@@ -287,6 +288,7 @@ struct ConvArgs2 {
     int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
     int gdrop; float g_inv_keep; uint32_t g_thr; const uint32_t* g_state; int g_layer;      // see ConvArgs
+    int sums_from;                           // STATS == 2: columns below this channel are not needed (left unwritten or partial)
 };
 
 // Dropout backward on four consecutive channels of one pixel (STATS launches with gdrop): the keep bits of the counter stream the
@@ -1073,6 +1075,11 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                 float qs[2][4], qq[2][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) qs[0][r] = qs[1][r] = qq[0][r] = qq[1][r] = 0.f;
+                // column sums (STATS == 2): of the fp32 values in front of the storage rounding, only for the channel pairs somebody
+                // reads (sums_from: the first half of a split result belongs to a stage without BatchNormalization), and without the
+                // per-pixel validity select when the whole tile lies inside the image -- all wave-uniform
+                const bool need_sums = STATS == 2 && co0 + cp * 32 + 32 > a.sums_from;
+                const bool interior = ty0 + TH <= a.h && tx0 + TW <= a.w;
 #pragma unroll
                 for (int q = 0; q < NPB / 2; ++q) {
                     unsigned pk[2][2][2];                                       // [pixel block of the pair][channel block A / B][word]
@@ -1093,13 +1100,22 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                             for (int r = 0; r < 4; ++r) { v[r] = actf(acc[cb][blk][r]); acc[cb][blk][r] = bias_r[cb][r]; }
                             if constexpr (STATS == 2) {      // Dropout backward on the result (wave-uniform test)
                                 if (a.gdrop) gdrop4(v, pix, a.cout, co0 + cb * 16 + 4 * kq, gkey, a.g_thr, a.g_inv_keep);
+                                if (need_sums) {
+                                    if (interior) {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) qs[c2][r] += v[r];
+                                    } else {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) qs[c2][r] += ok[s2] ? v[r] : 0.f;
+                                    }
+                                }
                             }
                             pk[s2][c2][0] = Vec<T>::pack2(v[0], v[1]);
                             pk[s2][c2][1] = Vec<T>::pack2(v[2], v[3]);
                         }
                         store_cbpair(cp, pk[s2][0][0], pk[s2][0][1], pk[s2][1][0], pk[s2][1][1], pix, ok[s2]);
                     }
-                    if constexpr (STATS) {                                      // statistics of what is stored: the packed words, widened
+                    if constexpr (STATS == 1) {                                 // statistics of what is stored: the packed words, widened
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2) {
                             const float ux[4] = {Vec<T>::lo(pk[0][c2][0]), Vec<T>::hi(pk[0][c2][0]), Vec<T>::lo(pk[0][c2][1]), Vec<T>::hi(pk[0][c2][1])};
@@ -1108,16 +1124,22 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                             for (int r = 0; r < 4; ++r) {
                                 const float u0 = ok[0] ? ux[r] : 0.f, u1 = ok[1] ? uy[r] : 0.f;
                                 qs[c2][r] += u0 + u1;
-                                if constexpr (STATS == 1) qq[c2][r] = fmaf(u0, u0, fmaf(u1, u1, qq[c2][r]));
+                                qq[c2][r] = fmaf(u0, u0, fmaf(u1, u1, qq[c2][r]));
                             }
                         }
                     }
                 }
-                if constexpr (STATS) {
+                if constexpr (STATS == 1) {
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
                         st_sum[2 * cp + c2] += lane16_channel_sum(qs[c2], i16);
-                        if constexpr (STATS == 1) st_sq[2 * cp + c2] += lane16_channel_sum(qq[c2], i16);
+                        st_sq[2 * cp + c2] += lane16_channel_sum(qq[c2], i16);
+                    }
+                }
+                if constexpr (STATS == 2) {
+                    if (need_sums) {
+                        st_sum[2 * cp] += lane16_channel_sum(qs[0], i16);
+                        st_sum[2 * cp + 1] += lane16_channel_sum(qs[1], i16);
                     }
                 }
             }
@@ -1153,11 +1175,11 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                     const unsigned w00 = Vec<T>::pack2(v[0][0], v[0][1]), w01 = Vec<T>::pack2(v[0][2], v[0][3]);
                     const unsigned w10 = Vec<T>::pack2(v[1][0], v[1][1]), w11 = Vec<T>::pack2(v[1][2], v[1][3]);
                     store_cbpair(cp, w00, w01, w10, w11, pix, keep);
-                    if constexpr (STATS == 2) {                                // column sums of the stored block sums
-                        qd[0][0] += keep ? Vec<T>::lo(w00) : 0.f; qd[0][1] += keep ? Vec<T>::hi(w00) : 0.f;
-                        qd[0][2] += keep ? Vec<T>::lo(w01) : 0.f; qd[0][3] += keep ? Vec<T>::hi(w01) : 0.f;
-                        qd[1][0] += keep ? Vec<T>::lo(w10) : 0.f; qd[1][1] += keep ? Vec<T>::hi(w10) : 0.f;
-                        qd[1][2] += keep ? Vec<T>::lo(w11) : 0.f; qd[1][3] += keep ? Vec<T>::hi(w11) : 0.f;
+                    if constexpr (STATS == 2) {                                // column sums of the block sums (fp32, in front of the rounding)
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) qd[c2][r] += keep ? v[c2][r] : 0.f;
                     }
                 }
                 if constexpr (STATS == 2) {
@@ -1227,7 +1249,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
     b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = a0.subpix; b.nt_in = a0.nt_in;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
-    b.gdrop = (stats && smode == 2) ? a0.gdrop : 0; b.g_inv_keep = a0.g_inv_keep; b.g_thr = a0.g_thr; b.g_state = a0.g_state; b.g_layer = a0.g_layer;
+    b.gdrop = (stats && smode == 2) ? a0.gdrop : 0; b.sums_from = a0.sums_from; b.g_inv_keep = a0.g_inv_keep; b.g_thr = a0.g_thr; b.g_state = a0.g_state; b.g_layer = a0.g_layer;
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
     const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 <= LDS_MAX;
@@ -1679,6 +1701,7 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     a.nt_in = d->stream_in ? 1 : 0;
     a.subpix = d->subpix ? 1 : 0;
     a.gdrop = 0; a.g_inv_keep = 1.f; a.g_thr = 65536u; a.g_state = nullptr; a.g_layer = 0;
+    a.sums_from = (d->sums_from > 0 && d->sums_from % 32 == 0) ? d->sums_from : 0;
     if (a.subpix) {                      // UpSampling2D -> conv as four phase convolutions on the low-resolution grid
         if (d->up0 != 1 || d->c1 || d->y1 || a.kd != 1 || a.down2) return RVIP_EINVAL;
         a.up0 = 0; a.h = d->h / 2; a.w = d->w / 2;

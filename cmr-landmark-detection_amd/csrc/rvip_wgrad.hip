@@ -194,6 +194,7 @@ struct WgArgs2 {
     int zs;
     int depth, dshift;                        // Conv3D depth tap: X is read from image n + dshift of the same volume (zeros outside)
     int dbg;                                  // ablation only (RVIP_DBG): 1 = no DMA after the first tile, 2 = no MFMA, 4 = DMAs fetch nothing
+    int nt_slab;                              // slabs leave with the non-temporal hint (deferred fold: their reader runs milliseconds later)
 };
 
 template <typename T, int TW, int CIB, int COB>
@@ -600,7 +601,10 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
                 const int ci = ci0 + ci_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf, co = co0 + co_t * 32 + j;
                 // the slab is read back by the batched fold at the end of the gradient bucket, milliseconds later: non-temporal
                 // stores keep its 37.7 MB per layer from displacing the activations (measured: -0.07 ms per step)
-                if (ci < a.cin && co < a.cout) __builtin_nontemporal_store(acc[t][r], &out[((size_t)t * a.cin + ci) * a.cout + co]);
+                if (ci < a.cin && co < a.cout) {
+                    if (a.nt_slab) __builtin_nontemporal_store(acc[t][r], &out[((size_t)t * a.cin + ci) * a.cout + co]);
+                    else out[((size_t)t * a.cin + ci) * a.cout + co] = acc[t][r];      // folded by the next launch: keep it cached
+                }
             }
     } else {
         // every compute wave parks its block in LDS (the stages are free), one barrier, then 256 threads add the PSPLIT copies in
@@ -621,7 +625,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
             const int e = 4 * e4, pr = e / BLK, rem = e % BLK;
             const int t = rem >> 10, ci = ci0 + (pr % NCI) * 32 + ((rem >> 5) & 31), co = co0 + (pr / NCI) * 32 + (rem & 31);
             if (ci < a.cin && co + 3 < a.cout) {
-                __builtin_nontemporal_store(sum, reinterpret_cast<f32x4*>(&out[((size_t)t * a.cin + ci) * a.cout + co]));
+                if (a.nt_slab) __builtin_nontemporal_store(sum, reinterpret_cast<f32x4*>(&out[((size_t)t * a.cin + ci) * a.cout + co]));
+                else *reinterpret_cast<f32x4*>(&out[((size_t)t * a.cin + ci) * a.cout + co]) = sum;
             } else if (ci < a.cin) {
                 for (int q = 0; q < 4; ++q) if (co + q < a.cout) __builtin_nontemporal_store(sum[q], &out[((size_t)t * a.cin + ci) * a.cout + co + q]);
             }
@@ -885,6 +890,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
         b.c0 = a.c0; b.c1 = a.c1; b.up0 = a.up0; b.zs = a.zs; b.n = a.n; b.h = a.h; b.w = a.w; b.cin = a.cin; b.cout = a.cout;
         b.tiles_x = g2.tiles_x; b.tiles_y = g2.tiles_y; b.ntiles = g2.ntiles; b.nsplit = g2.nsplit;
         { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
+        { static const int nts = [] { const char* e = getenv("RVIP_NT_SLAB"); return e ? atoi(e) : -1; }(); b.nt_slab = nts >= 0 ? nts : (d->defer_fold ? 1 : 0); }
         if (d->workspace_bytes < (size_t)b.nsplit * 9 * a.cin * a.cout * sizeof(float)) return RVIP_EWORKSPACE;
         // Conv3D: one pass per depth tap (X shifted by kdi - 1 images inside the volume) into dw[kdi][9][Cin][Cout]
         const long long count2 = 9LL * a.cin * a.cout;

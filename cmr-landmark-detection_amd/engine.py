@@ -587,6 +587,9 @@ class Engine:
                     wg.w_master, wg.dot_rows, wg.dot_rows_bytes = P.p(c.conv, 'kernel').value, dbuf.data_ptr(), dbuf.numel() * 4
                 if p.drop and p.drop[1] > 0:          # Dropout backward rides in the consumer's data-gradient epilogue
                     dg.gdrop_rate, dg.gdrop_state, dg.gdrop_layer_id = p.drop[1], state.value, p.drop[2]
+        for c in plan.stages:                   # a split result whose first half nobody sums (the up-conv has no BatchNormalization)
+            if c.conv in sums_rows and c.src1 and not (c.src0 in producer and producer[c.src0].conv in self.algebraic):
+                dg_desc[c.conv].sums_from = c.c0
         self._alg_bufs['sums'], self._alg_bufs['dots'] = sums_rows, dot_rows
         min_gamma = float(os.environ.get('RVIP_BNBWD_MIN_GAMMA', 1.0 / 64))
         max_beta_ratio = float(os.environ.get('RVIP_BNBWD_MAX_BETA_RATIO', 64.0))

@@ -105,6 +105,9 @@ typedef struct rvip_conv3x3_desc {
      * counter stream (gdrop_state, gdrop_layer_id: the Dropout layer's id, element index = position in y).  The BN-backward apply
      * pass of the producer stage then runs without dropout.  0 = none; not with y1 / down2. */
     float        gdrop_rate; const uint32_t* gdrop_state; int32_t gdrop_layer_id;
+    /* rvip_conv3x3_fwd_sums only: the caller reads columns >= sums_from of the partial rows only (a multiple of 32; e.g. csplit when
+     * the first half of a split result belongs to a stage without BatchNormalization); the columns below are unspecified. */
+    int32_t      sums_from;
 } rvip_conv3x3_desc;
 
 int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
@@ -116,7 +119,7 @@ int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
 int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d);
 int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_ws, size_t stats_ws_bytes, void* stream);
 /* ABI 5, for data-gradient launches: the convolution with the per-channel SUMS of its stored result as rvip_conv3x3_fwd_sums_rows(d)
- * partial rows [rows][cout] -- also with y1 (channel c of the virtual [y, y1] row is column c), with down2 (sums of the stored 2x2
+ * partial rows [rows][cout] (of the fp32 values in front of the storage rounding) -- also with y1 (channel c of the virtual [y, y1] row is column c), with down2 (sums of the stored 2x2
  * block sums) and with gdrop_rate.  Added over the rows, column c is the `T1 = sum g` term of the BatchNormalization backward of
  * the stage that produced channel c of this launch's result tensor (rvip_bn_bwd_coef).  rows == 0: fallback kernel, no sums. */
 int rvip_conv3x3_fwd_sums_rows(const rvip_conv3x3_desc* d);
