@@ -9,8 +9,10 @@ the 256x256 4-level U-Net with 2 heat-maps, bf16 activations / fp32 accumulate, 
 Rank 0 prints ONE JSON line.  ``value`` = slices all ranks processed / max-over-ranks wall time of exactly K steps
 with the synthetic batch already resident in HBM.  ``roofline`` is for the dominant kernel family (the MFMA
 implicit-GEMM conv, forward + data-gradient launches): achieved = algorithmic conv FLOPs of those launches /
-their summed durations, measured live with HIP events on the launch stream in a separate pass after the timed
-region.  ``cpu_baseline`` (rank 0, N=1 only) times the same training step on the host cores with the PyTorch-CPU
+the duration of those launches, measured live with HIP events around replays of a hipGraph that holds exactly the
+family's launches of one step (back to back, as in the captured step; a per-launch eager pass would add the launch gaps) after the
+timed region; ``roofline.profile`` holds the same figure from the committed rocprofv3 kernel trace when it was taken on these
+kernel sources, ``roofline_wgrad`` the weight-gradient kernels the same way, ``kernels`` the per-entry-point eager table.  ``cpu_baseline`` (rank 0, N=1 only) times the same training step on the host cores with the PyTorch-CPU
 port in oracle/ (the reference's own TF2-CPU path cannot run here: no TensorFlow) on a bounded sample.
 """
 import argparse
@@ -26,7 +28,8 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0       # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = 'r02_pmc_summary.json'
+PMC_SUMMARY = 'r03_pmc_summary.json'
+KERNEL_STATS = 'r03_bench_kernel_stats.csv'          # rocprofv3 --kernel-trace --stats of this command (tools/profile_round.sh), + .meta.json
 
 
 def csrc_sha16():
@@ -61,6 +64,7 @@ def main():
     ap.add_argument('--no-aux', action='store_true', help='skip the informational predict pass (PMC runs: only training-step kernels)')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--detail', default=None, help='write a per-launch timing table (conv / wgrad shapes) to this file')
+    ap.add_argument('--no-roofline-pass', action='store_true', help='skip the eager per-launch and family-graph passes (profiling runs: only the captured step in the trace)')
     args = ap.parse_args()
 
     import numpy as np
@@ -156,7 +160,8 @@ def main():
     # ---- roofline pass: HIP events around every launch, eager, on the launch stream -------------------------
     roof = None
     per_kernel = {}
-    if rank == 0:
+    hbm_step = None
+    if rank == 0 and not args.no_roofline_pass:
         import ctypes as C
         s = torch.cuda.current_stream()
         L = rvip._native.lib()
@@ -203,9 +208,41 @@ def main():
             per_kernel[name] = dict(launches_per_step=len(evs) // reps, ms_per_step=round(ms / reps, 4),
                                     tflops=round(fl / (ms * 1e-3) / 1e12, 2) if (fl > 0 and ms > 0) else None)
         cv = agg['rvip_conv3x3_fwd'] + agg.get('rvip_conv3x3_fwd_stats', []) + agg.get('rvip_conv3x3_fwd_sums', [])
-        ms = sum(a.elapsed_time(b) for a, b, _ in cv)
         fl = sum(f for _, _, f in cv)
-        achieved = fl / (ms * 1e-3) / 1e12
+
+        def family_ms(calls, nrep=20):
+            """ms per step of `calls` launched back to back: a hipGraph of exactly these launches, replayed nrep times between two events"""
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for fn, a in calls:
+                    assert fn(*a, cs) == 0
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            for _ in range(nrep):
+                g.replay()
+            e1.record(s)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / nrep
+        conv_calls = [(th[0], th[1]) for seq in (eng.fwd_train, eng.bwd) for th in seq if th[0] in (conv_fn, conv_stats_fn, conv_sums_fn)]
+        fam_ms = family_ms(conv_calls)
+        achieved = (fl / reps) / (fam_ms * 1e-3) / 1e12
+        ms = fam_ms * reps                     # (kept for avg_launch_ms below: per-step family time x the eager pass's repetitions)
+        # weight-gradient kernels alone: the same descriptors with the fold left out (slabs to the shared workspace)
+        wg_calls, wg_keep, wg_fl = [], [], 0.0
+        for th in eng.bwd:
+            if th[0] is wgrad_fn:
+                d0 = th[1][0]._obj
+                d1 = type(d0).from_buffer_copy(d0)
+                if max(d0.kd, 1) == 1:
+                    d1.defer_fold, d1.dot_rows, d1.w_master = 1, None, None
+                    d1.workspace, d1.workspace_bytes = eng.ws_wg.data_ptr(), eng.ws_wg_bytes
+                wg_keep.append(d1)
+                wg_calls.append((wgrad_fn, (C.byref(d1),)))
+                wg_fl += 2.0 * d0.n * d0.h * d0.w * 9 * max(d0.kd, 1) * (d0.c0 + d0.c1) * d0.cout
+        wg_ms = family_ms(wg_calls) if wg_calls else None
         traffic, traffic_src, hbm_step, pmc_note = None, None, None, None
         try:                                   # HBM bytes per launch of this kernel family from the committed PMC passes of THESE kernels
             pm = json.load(open(os.path.join(ROOT, 'profiles', PMC_SUMMARY)))
@@ -223,13 +260,46 @@ def main():
                     hbm_step = pm.get('hbm_bytes_per_step')
         except FileNotFoundError:
             pmc_note = 'profiles/%s missing' % PMC_SUMMARY
+        except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError) as e:      # truncated / stale-schema file: report, do not lose the line
+            traffic, traffic_src, hbm_step = None, None, None
+            pmc_note = 'profiles/%s unusable (%s: %s)' % (PMC_SUMMARY, type(e).__name__, e)
+        # the same family in the committed rocprofv3 kernel trace of this command (captured step), when taken on THESE sources
+        prof, prof_wg = None, None
+        try:
+            import csv
+            meta = json.load(open(os.path.join(ROOT, 'profiles', KERNEL_STATS + '.meta.json')))
+            if meta.get('csrc_sha16') != csrc_sha16() or meta.get('workload') != workload_key(args):
+                prof = {'file': 'profiles/' + KERNEL_STATS, 'note': 'taken on other kernel sources / workload (%s, %s)' % (meta.get('csrc_sha16'), meta.get('workload'))}
+            else:
+                rows_ = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', KERNEL_STATS))))
+                steps_p = max(int(r['Calls']) for r in rows_ if 'adam_kernel' in r['Name'])
+                fam_ns = sum(float(r['TotalDurationNs']) for r in rows_ if 'conv3x3_igemm' in r['Name'])
+                wg_ns = sum(float(r['TotalDurationNs']) for r in rows_ if 'wgrad3x3_' in r['Name'])
+                pa = (fl / reps) / (fam_ns / steps_p * 1e-9) / 1e12
+                prof = {'file': 'profiles/' + KERNEL_STATS, 'steps': steps_p, 'family_ms_per_step': round(fam_ns / steps_p * 1e-6, 4),
+                        'achieved': round(pa, 2), 'live_over_profile': round(achieved / pa, 4)}
+                if wg_ns > 0 and wg_ms:
+                    pw = wg_fl / (wg_ns / steps_p * 1e-9) / 1e12
+                    prof_wg = {'file': 'profiles/' + KERNEL_STATS, 'family_ms_per_step': round(wg_ns / steps_p * 1e-6, 4), 'achieved': round(pw, 2),
+                               'live_over_profile': round(wg_fl / (wg_ms * 1e-3) / 1e12 / pw, 4)}
+        except FileNotFoundError:
+            prof = {'file': 'profiles/' + KERNEL_STATS, 'note': 'missing'}
+        except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError) as e:
+            prof = {'file': 'profiles/' + KERNEL_STATS, 'note': 'unusable (%s: %s)' % (type(e).__name__, e)}
         roof = dict(bound='mfma', kernel='conv3x3_igemm (forward incl. fused BN statistics + data-gradient launches)', achieved=round(achieved, 2),
                     peak=PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3, unit='TFLOP/s',
                     frac=round(achieved / (PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3), 4),
                     traffic=traffic, traffic_source=traffic_src, traffic_note=pmc_note,
                     algorithmic_bytes_per_launch=round(plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * 2.0 / 3.0 * B / max(len(cv) // reps, 1)),
                     launches_per_step=len(cv) // reps, avg_launch_ms=round(ms / len(cv), 4),
-                    flops_per_launch=fl / len(cv))
+                    flops_per_launch=fl / len(cv), family_ms_per_step=round(fam_ms, 4),
+                    timing='HIP events around 20 replays of a hipGraph holding the family\'s launches of one step', profile=prof)
+        peak_ = PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3
+        roof_wg = None
+        if wg_ms:
+            wa = wg_fl / (wg_ms * 1e-3) / 1e12
+            roof_wg = dict(bound='mfma', kernel='wgrad3x3 (weight-gradient kernels without their slab fold)', achieved=round(wa, 2), peak=peak_, unit='TFLOP/s',
+                           frac=round(wa / peak_, 4), launches_per_step=len(wg_calls), family_ms_per_step=round(wg_ms, 4), profile=prof_wg)
 
     # ---- the product's own loop: Model.fit on a SyntheticSAXGenerator held in memory (the reference trains with in_memory=True,
     # train_model.py:199-203): generator -> rank shard -> pinned ring -> copy stream -> replayed step, per-epoch logs.  Reported
@@ -269,6 +339,7 @@ def main():
             'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),
             'loss': loss, 'steps_executed_total': max(2, min(args.warmup, 3)) + args.warmup + args.steps + 3,
             'roofline': roof,
+            'roofline_wgrad': roof_wg if roof is not None else None,
             'kernels': per_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -62,6 +62,7 @@ class BaseGenerator:
         self.SIGMA = config.get('SIGMA', 1)
         self.INDICES = list(range(n_samples))
         self._epochs_seen = 0
+        self.samples_generated = 0          # samples this process has produced (data-parallel tests: B / world per step and rank)
         self.on_epoch_end()
 
     def __len__(self):
@@ -70,6 +71,16 @@ class BaseGenerator:
     def __getitem__(self, index):
         idxs = self.INDICES[index * self.BATCHSIZE:(index + 1) * self.BATCHSIZE]
         return self.__data_generation__(idxs)
+
+    def batch_slice(self, index, lo, hi):
+        """Samples lo..hi-1 of batch `index` only.  The reference is ONE process under MirroredStrategy (Unets.py:70-75): every
+        sample of the global batch is generated once (Generators.py:175-228) and Keras splits the batch over the replicas.  Here
+        every replica is a process, all of which agree on INDICES (seeded shuffles), so each asks for its own slice of the global
+        batch instead of generating all of it and discarding (world - 1) / world (Model.fit)."""
+        if not (0 <= lo <= hi <= self.BATCHSIZE):
+            raise IndexError('slice %d:%d of a batch of %d' % (lo, hi, self.BATCHSIZE))
+        base = index * self.BATCHSIZE
+        return self.__data_generation__(self.INDICES[base + lo:base + hi])
 
     def __iter__(self):
         for i in range(len(self)):
@@ -85,10 +96,11 @@ class BaseGenerator:
         self._epochs_seen += 1
 
     def __data_generation__(self, idxs):
-        x = np.empty((self.BATCHSIZE, *self.DIM, 1), dtype=np.float32)
-        y = np.empty((self.BATCHSIZE, *self.DIM, self.N_CLASSES), dtype=np.float32)
+        x = np.empty((len(idxs), *self.DIM, 1), dtype=np.float32)
+        y = np.empty((len(idxs), *self.DIM, self.N_CLASSES), dtype=np.float32)
         for i, ID in enumerate(idxs):
             x[i], y[i] = self.__preprocess_one_image__(i, int(ID))
+        self.samples_generated += len(idxs)
         return x, y
 
     def __preprocess_one_image__(self, i, ID):
@@ -144,6 +156,7 @@ class ArrayGenerator(BaseGenerator):
 
     def __data_generation__(self, idxs):
         idxs = np.asarray(idxs)
+        self.samples_generated += len(idxs)
         return self._x[idxs], (None if self._y is None else self._y[idxs])
 
 

@@ -163,11 +163,15 @@ class Model:
     # ---------------------------------------------------------------------------------------------
     # weights (Keras get_weights() order: conv kernel, bias; BN gamma, beta, moving_mean, moving_variance)
     # ---------------------------------------------------------------------------------------------
-    def get_weights(self):
-        """Keras order.  Data-parallel: BN moving statistics are read as the MEAN over the replicas (Keras reads a
-        MirroredStrategy BN variable that way) -- a collective, so every rank must call get_weights / save_weights."""
+    def get_weights(self, sync=True):
+        """Keras order.  Data-parallel with ``sync`` (the default): BN moving statistics are read as the MEAN over the replicas
+        (Keras reads a MirroredStrategy BN variable that way) -- a COLLECTIVE, so every rank must then call get_weights /
+        save_weights / evaluate together.  A caller on one rank only (`if rank == 0: model.get_weights(sync=False)`, a chief-only
+        callback) passes ``sync=False`` and reads this replica's moving statistics; everything trainable is identical on all
+        ranks anyway."""
         if self._params is not None:
-            self.sync_moving_statistics()
+            if sync:
+                self.sync_moving_statistics()
             self._weights = self._params.download()
         return [w.copy() for w in self._weights]
 
@@ -196,14 +200,15 @@ class Model:
             by_layer[ln].append(('%s/%s:0' % (ln, wn), i))
         return list(by_layer.items())
 
-    def save_weights(self, filepath, overwrite=True, save_format=None, **_):
+    def save_weights(self, filepath, overwrite=True, save_format=None, sync=True, **_):
         """Weights-only checkpoint (ModelCheckpoint(save_weights_only=True), KerasCallbacks.py:54-61).  ``*.h5`` / ``*.hdf5`` /
         ``*.keras`` (or save_format='h5') write the Keras-HDF5 layout ``model.load_weights`` of the reference reads
         (predict_model.py:75-76) through the in-tree HDF5 writer (keras_h5.py); ``*.npz`` keeps the NumPy container keyed
         '<layer>/<weight>:0'.  Data-parallel: BN moving statistics are mean-reduced over the replicas first (Keras
-        MirroredVariable aggregation MEAN) -- a collective every rank must enter -- and only rank 0 writes."""
+        MirroredVariable aggregation MEAN) -- a collective every rank must enter -- and only rank 0 writes; ``sync=False`` skips
+        the collective (a rank-0-only caller) and writes this replica's moving statistics."""
         import os
-        weights = self.get_weights()                                   # collective when data-parallel (replica mean of the BN statistics)
+        weights = self.get_weights(sync=sync)                          # collective when data-parallel (replica mean of the BN statistics)
         if self._dist()[0] != 0:
             return
         if not overwrite and os.path.exists(filepath):
@@ -387,9 +392,10 @@ class Model:
         vals = self._batch_logs(eng, kind, w_bce, w_dice).cpu().numpy().tolist()
         return dict(zip(self.metrics_names, vals)) if return_dict else vals
 
-    def test_on_batch(self, x, y, return_dict=False):
+    def test_on_batch(self, x, y, return_dict=False, sharded=False):
+        """`sharded`: (x, y) is already this rank's slice of the global batch (evaluate on a generator of this package)"""
         kind, w_bce, w_dice, _ = self._loss_spec()
-        x, y = self._shard(np.asarray(x), np.asarray(y))
+        x, y = (np.asarray(x), np.asarray(y)) if sharded else self._shard(np.asarray(x), np.asarray(y))
         eng = self._engine(x.shape[0])
         eng.load_input(x, y)
         eng.forward_eval()
@@ -458,12 +464,18 @@ class Model:
         statistics are mean-reduced over the replicas first (a collective: every rank calls evaluate)."""
         self.sync_moving_statistics()
         tot, cnt = None, 0
+        rank, world = self._dist()
+        local = (world > 1 and not isinstance(x, np.ndarray) and hasattr(x, 'batch_slice')
+                 and getattr(x, 'BATCHSIZE', 0) > 0 and x.BATCHSIZE % world == 0)       # rank-local batches, as in fit()
         if isinstance(x, np.ndarray):
             batches = [(x, y)]
+        elif local:
+            b = x.BATCHSIZE // world
+            batches = (x.batch_slice(i, rank * b, (rank + 1) * b) for i in range(len(x)))
         else:
             batches = (x[i] for i in range(len(x)))
         for xb, yb in batches:
-            v = np.asarray(self.test_on_batch(xb, yb))
+            v = np.asarray(self.test_on_batch(xb, yb, sharded=local))
             tot = v if tot is None else tot + v
             cnt += 1
         vals = (tot / max(cnt, 1)).tolist()
@@ -473,7 +485,8 @@ class Model:
     # fit (train_model.py:105-112)
     # ---------------------------------------------------------------------------------------------
     def _values_from_sums(self, s, n, kind, w_bce, w_dice):
-        """Per-batch loss + metric values from rows of folded sums ([steps,16] float64): what _batch_logs computes on the device."""
+        """Per-batch loss + metric values from rows of folded sums ([steps,16] float64; n = loss elements per step, scalar or
+        [steps]): what _batch_logs computes on the device."""
         dice_all = (2 * s[:, 2] + 1) / (s[:, 3] + s[:, 4] + 1)
         loss = s[:, 0] / n if kind == 'mse' else w_bce * s[:, 1] / n - w_dice * dice_all
         cols = [loss]
@@ -525,6 +538,7 @@ class Model:
             if shuffle:                                        # Keras shuffles the batch order of a Sequence; seeded: identical on every rank
                 order = np.random.default_rng([self.seed, epoch]).permutation(len(gen))
             hist = eng = None
+            counts = []                                        # loss elements of every step's OWN batch (a Sequence may end on a smaller one)
             for step, (eng, slot) in enumerate(self._staged_batches(gen, order[:steps], max_queue_size, workers)):
                 if hist is None:
                     hist = torch.zeros((steps, eng.sums.numel()), dtype=torch.float32, device=eng.sums.device)
@@ -532,6 +546,7 @@ class Model:
                     eng.feed(slot)
                 eng.train_step()
                 hist[step].copy_(eng.sums, non_blocking=True)
+                counts.append(self._loss_count(eng, kind, world))
                 self.optimizer.iterations += 1
                 cbs.on_train_batch_end(step)
             logs = OrderedDict()
@@ -539,7 +554,7 @@ class Model:
                 if world > 1:
                     import torch.distributed as dist
                     dist.all_reduce(hist)
-                vals = self._values_from_sums(hist.cpu().numpy().astype(np.float64), self._loss_count(eng, kind, world), kind, w_bce, w_dice)
+                vals = self._values_from_sums(hist.cpu().numpy().astype(np.float64)[:len(counts)], np.asarray(counts, np.float64), kind, w_bce, w_dice)
                 for k, val in zip(names, vals.mean(0).tolist()):
                     logs[k] = val
             if validation_data is not None:
@@ -568,28 +583,62 @@ class Model:
         q = queue.Queue(maxsize=depth)
         ring = self._rings                                     # batch size -> engine whose pinned ring exists (kept across epochs)
         ready = threading.Event()
+        cancel = threading.Event()                             # set when the training thread leaves early (exception, callback stop)
         stop = object()
         slots = depth + 3
         dev = self._device()
+        rank, world = self._dist()
+        # Rank-local batches: a generator of this package hands out any slice of a batch (BaseGenerator.batch_slice), and the seeded
+        # shuffles make every rank agree on what the global batch is, so a rank produces only ITS B / world samples -- as the
+        # reference's single MirroredStrategy process produces every sample once (Generators.py:175-228).  A foreign Sequence is
+        # asked for the whole batch, which is then sharded.
+        local = world > 1 and hasattr(gen, 'batch_slice') and getattr(gen, 'BATCHSIZE', 0) % world == 0 and getattr(gen, 'BATCHSIZE', 0) > 0
+        if local:
+            b = gen.BATCHSIZE // world
+            fetch = lambda i: gen.batch_slice(i, rank * b, (rank + 1) * b)            # noqa: E731
+        else:
+            fetch = gen.__getitem__
+
+        class _Cancelled(Exception):
+            pass
+
+        def put(item):
+            while True:
+                if cancel.is_set():
+                    raise _Cancelled()
+                try:
+                    q.put(item, timeout=0.1)
+                    return
+                except queue.Full:
+                    continue
 
         def work():
             try:
                 import torch
                 torch.cuda.set_device(dev)
-                for xb, yb in _prefetch(gen, order, depth, workers):
-                    xb, yb = self._shard(xb, yb)
+                for xb, yb in _prefetch(fetch, order, depth, workers, cancel):
+                    if not local:
+                        xb, yb = self._shard(xb, yb)
                     eng = ring.get(xb.shape[0])
                     if eng is None or eng.ring_slots() < slots:
                         ready.clear()
-                        q.put(('raw', xb, yb))
-                        ready.wait()                           # the training thread builds the engine for this batch size
+                        put(('raw', xb, yb))
+                        while not ready.wait(0.1):             # the training thread builds the engine for this batch size
+                            if cancel.is_set():
+                                raise _Cancelled()
                         continue
                     slot = eng.next_slot()
                     eng.stage_host_batch(slot, xb, yb)
-                    q.put(('pin', eng, slot))
+                    put(('pin', eng, slot))
+                put(stop)
+            except _Cancelled:
+                pass
             except BaseException as e:                         # surface generator errors in the training thread
-                q.put(e)
-            q.put(stop)
+                try:
+                    put(e)
+                    put(stop)
+                except _Cancelled:
+                    pass
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
@@ -611,8 +660,15 @@ class Model:
                     yield eng, None
                 else:
                     yield item[1], item[2]
-        finally:
+        finally:                                               # also on an exception / generator close in the training thread:
+            cancel.set()                                       # the stager must not keep pinned slots and the thread pool
             ready.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(0.05)
 
     def history_callback(self):
         from .KerasCallbacks import Callback
@@ -626,27 +682,35 @@ class Model:
         return _Hist()
 
 
-def _prefetch(gen, order, depth, workers=1):
-    """In-order iterator over ``gen[i] for i in order`` (called from the stager thread).  `workers` > 1 prepares that many
-    batches at a time on a thread pool (NumPy / SciPy release the GIL in their kernels) and still delivers them in order --
-    fit(max_queue_size=, workers=) of train_model.py:111."""
+def _prefetch(fetch, order, depth, workers=1, cancel=None):
+    """In-order iterator over ``fetch(i) for i in order`` (called from the stager thread; fetch = the generator's __getitem__ or
+    a rank's slice of it).  `workers` > 1 prepares that many batches at a time on a thread pool (NumPy / SciPy release the GIL in
+    their kernels) and still delivers them in order -- fit(max_queue_size=, workers=) of train_model.py:111.  `cancel` (an
+    Event) stops the submission of further batches; the pool is shut down when the iterator is closed."""
     depth = max(int(depth), 1)
     workers = max(int(workers or 1), 1)
     if workers > 1:
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=workers) as ex:
+        ex = ThreadPoolExecutor(max_workers=workers)
+        try:
             pending, it = deque(), iter(order)
             for i in it:
-                pending.append(ex.submit(gen.__getitem__, int(i)))
+                pending.append(ex.submit(fetch, int(i)))
                 if len(pending) >= max(depth, workers):
                     break
             while pending:
                 item = pending.popleft().result()              # re-raises a generator error
-                nxt = next(it, None)
+                nxt = None if (cancel is not None and cancel.is_set()) else next(it, None)
                 if nxt is not None:
-                    pending.append(ex.submit(gen.__getitem__, int(nxt)))
+                    pending.append(ex.submit(fetch, int(nxt)))
                 yield item
+        finally:
+            for f in pending:
+                f.cancel()
+            ex.shutdown(wait=True)
         return
     for i in order:
-        yield gen[int(i)]
+        if cancel is not None and cancel.is_set():
+            return
+        yield fetch(int(i))

@@ -91,7 +91,7 @@ def _variant_id(v):
 def test_fp32_training_steps_match_oracle(variant):
     """Three training steps on the fp32 device path against the float64 oracle: loss, heat-maps, EVERY parameter gradient, Adam
     and the BN moving statistics.  Gradient bound per tensor, and WHICH bound admitted it is recorded (BRANCH_REPORT, asserted
-    below and dumped to gpurun_out/r02_tolerance_branches.json):
+    below and dumped to gpurun_out/r03_tolerance_branches.json):
       tight  |g_dev - g_64|max <= max(3e-4 * |g_64|max, 5e-8)
       f32    ... <= |g_32 - g_64|max: no worse than the float32 CPU evaluation of the same graph (ill-conditioned BN backward)
       knife  ... <= 25 % of |g_64|max, only when the float64 oracle finds a ReLU / pooling decision inside fp32 noise
@@ -287,6 +287,26 @@ def test_bce_dice_class_form_gradient_is_the_sum_reduction():
         np.testing.assert_allclose(out['class'][1][k], g * 4096.0, rtol=2e-5, atol=1e-6 * float(np.abs(g).max()) * 4096.0, err_msg=str(k))
 
 
+def test_fit_logs_with_a_ragged_last_batch():
+    """A user Sequence whose last batch is smaller: the epoch's logged loss is the mean of the per-batch losses, each over ITS
+    element count (Keras' fit semantics; the logs drive ModelCheckpoint / ReduceLROnPlateau / EarlyStopping, KerasCallbacks.py:54-98)."""
+    cfg = _cfg(DIM=[32, 32], FILTERS=8)
+    x, y = O.synthetic_batch(10, cfg['DIM'], 2, seed=8)
+
+    class Seq:
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            sl = slice(4 * i, min(4 * i + 4, 10))
+            return x[sl], y[sl]
+    a, b = rvip.get_model(cfg, metrics=[]), rvip.get_model(cfg, metrics=[])
+    b.set_weights(a.get_weights())
+    hist = a.fit(Seq(), epochs=1, shuffle=False, verbose=0)
+    ref = [b.train_on_batch(*Seq()[i])[0] for i in range(3)]
+    assert abs(hist.history['loss'][0] - float(np.mean(ref))) < 1e-6, (hist.history['loss'], ref)
+
+
 def test_zz_tolerance_branch_report():
     """Dumps which gradient bound admitted every (variant, step, tensor) of test_fp32_training_steps_match_oracle."""
     if not BRANCH_REPORT:
@@ -294,7 +314,7 @@ def test_zz_tolerance_branch_report():
     import json
     out = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, 'r02_tolerance_branches.json'), 'w') as f:
+    with open(os.path.join(out, 'r03_tolerance_branches.json'), 'w') as f:
         json.dump(BRANCH_REPORT, f, indent=1)
     tot = {k: sum(v[k] for v in BRANCH_REPORT.values()) for k in ('tight', 'f32', 'knife', 'clean_steps', 'clean_tight', 'clean_total')}
     print('gradient tolerance branches:', tot)
@@ -717,28 +737,35 @@ def _dp_fit_worker(rank, world, port, path, q):
         gcfg = dict(DIM=[32, 32], BATCHSIZE=8, GAUS=True, SIGMA=2, SHUFFLE=True, SEED=7)
         train = rvip.Generators.SyntheticSAXGenerator(32, gcfg, in_memory=True)
         val = rvip.Generators.SyntheticSAXGenerator(8, dict(gcfg, SHUFFLE=False), in_memory=True)
-        seen = []
-        orig = train.__getitem__.__func__
+        seen, mine = [], []
+        orig = type(train).batch_slice
 
         class Spy(type(train)):
-            def __getitem__(self, i):
+            def __getitem__(self, i):                                   # fit() must not ask for whole batches when it can ask for slices
+                raise AssertionError('a rank generated a whole global batch')
+
+            def batch_slice(self, i, lo, hi):
                 seen.append(tuple(int(v) for v in self.INDICES[i * self.BATCHSIZE:(i + 1) * self.BATCHSIZE]))
-                return orig(self, i)
+                mine.append(tuple(int(v) for v in self.INDICES[i * self.BATCHSIZE + lo:i * self.BATCHSIZE + hi]))
+                return orig(self, i, lo, hi)
         train.__class__ = Spy
         model = rvip.get_model(cfg, metrics=[M.dice_coef_labels])
         cbs = rvip.KerasCallbacks.get_callbacks(cfg, train, val)
         hist = model.fit(x=train, validation_data=val, epochs=2, callbacks=cbs, verbose=0, max_queue_size=2)
         w = model.get_weights()                                          # collective: replica mean of the BN moving statistics
         local_mv = model._params.moving.detach().cpu().numpy().copy()
-        q.put((rank, seen, hist.history, [a.copy() for a in w], local_mv, os.path.exists(os.path.join(cfg['MODEL_PATH'], 'model.h5'))))
+        q.put((rank, seen, hist.history, [a.copy() for a in w], local_mv, os.path.exists(os.path.join(cfg['MODEL_PATH'], 'model.h5')),
+               mine, train.samples_generated))
     finally:
         dist.destroy_process_group()
 
 
 def test_two_rank_fit_is_rank_consistent(tmp_path):
     """fit() for 2 epochs on 2 ranks (gloo, both on this GPU) with BN and dropout on: both ranks draw the same global batches in the
-    same order although their process-global NumPy streams differ, train on different halves, and end with identical weights,
-    identical (replica-mean) BN moving statistics and identical epoch logs; only rank 0 writes the checkpoint."""
+    same order although their process-global NumPy streams differ, train on different halves -- each rank GENERATES only its half
+    (B / world samples per step: the reference's one MirroredStrategy process produces every sample once, Generators.py:175-228) --
+    and end with identical weights, identical (replica-mean) BN moving statistics and identical epoch logs; only rank 0 writes the
+    checkpoint."""
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -749,9 +776,11 @@ def test_two_rank_fit_is_rank_consistent(tmp_path):
     res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
     for p in procs:
         p.join(60)
-    (_, seen0, h0, w0, mv0, ck0), (_, seen1, h1, w1, mv1, ck1) = res
+    (_, seen0, h0, w0, mv0, ck0, mine0, n0), (_, seen1, h1, w1, mv1, ck1, mine1, n1) = res
     assert seen0 == seen1 and len(seen0) == 8 and sorted(sum(seen0[:4], ())) == list(range(32))      # same global batches, each sample once per epoch
     assert seen0[:4] != seen0[4:]                                                                     # ... reshuffled between the epochs
+    assert n0 == n1 == 8 * 4                                                                          # 8 steps x (batch 8 / 2 ranks) samples generated per rank
+    assert all(len(a) == 4 and a + b == g for a, b, g in zip(mine0, mine1, seen0))                    # the two halves of every global batch
     assert set(h0) == set(h1) and all(h0[k] == h1[k] for k in h0), (h0, h1)
     for a_, b_ in zip(w0, w1):
         np.testing.assert_array_equal(a_, b_)

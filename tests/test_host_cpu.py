@@ -372,9 +372,30 @@ def test_prefetch_delivers_batches_in_order_with_one_or_many_workers():
     order = np.random.default_rng(0).permutation(23)
     for workers in (1, 4):
         g = Gen()
-        got = [int(x[0, 0]) for x, _ in km._prefetch(g, order, 5, workers)]
+        got = [int(x[0, 0]) for x, _ in km._prefetch(g.__getitem__, order, 5, workers)]
         assert got == [int(i) for i in order] and sorted(g.seen) == list(range(23))
     with pytest.raises(ValueError):
-        list(km._prefetch(Gen(), [1, 99, 2], 2, 3))
+        list(km._prefetch(Gen().__getitem__, [1, 99, 2], 2, 3))
     with pytest.raises(ValueError):
-        list(km._prefetch(Gen(), [1, 99, 2], 2, 1))
+        list(km._prefetch(Gen().__getitem__, [1, 99, 2], 2, 1))
+    # a cancelled pipeline stops asking the generator for further batches (fit() leaving early must not leave the stager running)
+    for workers in (1, 3):
+        g, cancel = Gen(), threading.Event()
+        it = km._prefetch(g.__getitem__, list(range(23)), 2, workers, cancel)
+        next(it)
+        cancel.set()
+        rest = list(it)
+        assert len(g.seen) < 23 and len(rest) <= 3
+
+
+def test_generator_batch_slice_is_the_slice_of_the_batch():
+    """BaseGenerator.batch_slice (data-parallel fit: every rank generates only its B / world samples of the global batch)."""
+    gen = rvip.Generators.SyntheticSAXGenerator(24, dict(DIM=[32, 32], BATCHSIZE=8, GAUS=True, SIGMA=2, SHUFFLE=True, SEED=5))
+    x, y = gen[1]
+    assert gen.samples_generated == 8
+    parts = [gen.batch_slice(1, lo, lo + 2) for lo in range(0, 8, 2)]
+    assert gen.samples_generated == 16
+    np.testing.assert_array_equal(np.concatenate([p[0] for p in parts]), x)
+    np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), y)
+    with pytest.raises(IndexError):
+        gen.batch_slice(0, 4, 9)

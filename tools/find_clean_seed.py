@@ -29,7 +29,7 @@ for vi in which:
     masks = T._masks(layers, B, model.seed, 0)
     found = None
     for seed in range(LIMIT):
-        x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=seed)
+        x, y = T._batch(B, cfg, seed)                    # the test's own batches (image channels / mask classes of the variant)
         if kind[0] == 'mse':
             _, _, _, cache = ref.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', masks)
         else:
