@@ -56,13 +56,23 @@ def _flat_grads(grads):
 
 
 # Data seeds whose FIRST training step has no knife edge (no ReLU / pooling decision within fp32 noise; found on the CPU with the
-# float64 oracle alone by tools/find_clean_seed.py at 1.5x the test's margin, 600 seeds tried per variant).  Variants without an
-# entry have no such seed among the first 600 (a few thousand pre-activations per layer at a 3e-6 relative margin: roughly one
-# near-zero element per layer is the norm) and keep seed 3.
+# float64 oracle alone by tools/find_clean_seed.py at 1.5x the test's margin, up to 4 000 seeds per variant).  The chance of such a
+# step falls exponentially with the number of pre-activations (about 1.4e-5 per element at the 4.5e-6 relative margin): the
+# 48 x 40 / F = 12 / depth-5 / 3-D variants have none among 4 000 seeds at their size (12 - 40 knife elements per step) and keep
+# seed 3 there; each has a SMALLER twin below (same layer types and code paths, fewer elements) whose first step IS knife-free, so
+# that the tight bound is exercised -- and asserted, with clean_total > 0 -- for every graph family.
 CLEAN_SEEDS = {
     'default': 325,
+    'BN_FIRST=True': 994,
     'BATCH_NORMALISATION=False,ACTIVATION=elu': 0,
+    'MASK_CLASSES=4,LOSS_FUNCTION=bce_dice_loss': 240,
     'USE_UPSAMPLE=False': 238,
+    'IMG_CHANNELS=3': 52,
+    'DEPTH=3,DIM=[24, 40],LOSS_FUNCTION=bce_dice_loss': 1535,
+    'LOSS_FUNCTION=BcdDiceLoss_w_1.0_1.0,FILTERS=12,DIM=[16, 32]': 57,
+    'DEPTH=5,DIM=[32, 32],FILTERS=4,RVIP_PRECISION=fp32': 35,
+    'DIM=[2, 8, 8],M_POOL=[1, 2, 2],F_SIZE=[3, 3, 3],FILTERS=32,USE_UPSAMPLE=False': 2,
+    'DIM=[2, 8, 8],M_POOL=[1, 2, 2],F_SIZE=[3, 3, 3],FILTERS=32': 0,
 }
 
 VARIANTS = [
@@ -77,6 +87,12 @@ VARIANTS = [
     dict(DEPTH=5, DIM=[64, 64], FILTERS=4, RVIP_PRECISION='fp32'),   # cfg 4's depth (bottleneck 2x2), fp32: F % 4 == 0
     dict(DIM=[4, 32, 32], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32, USE_UPSAMPLE=False),   # Conv3DTranspose(3, strides (1, 2, 2)) decoder
     dict(DIM=[4, 32, 32], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32),   # cfg 5's graph (Conv3D, MaxPooling3D, UpSampling3D); 3-D runs on the LDS-DMA kernels only: concat halves must be whole 128-byte rows (F % 32 in fp32)
+    # smaller twins of the variants above that have no knife-free first step at their size (see CLEAN_SEEDS)
+    dict(DEPTH=3, DIM=[24, 40], LOSS_FUNCTION=M.bce_dice_loss),
+    dict(LOSS_FUNCTION=M.BceDiceLoss(), FILTERS=12, DIM=[16, 32]),
+    dict(DEPTH=5, DIM=[32, 32], FILTERS=4, RVIP_PRECISION='fp32'),
+    dict(DIM=[2, 8, 8], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32, USE_UPSAMPLE=False),
+    dict(DIM=[2, 8, 8], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3], FILTERS=32),
 ]
 
 
@@ -112,7 +128,8 @@ def test_fp32_training_steps_match_oracle(variant):
     wname = {0: 'kernel', 1: 'bias'}
     specs = model.plan.weight_specs()
     rep = BRANCH_REPORT.setdefault(_variant_id(variant), dict(tight=0, f32=0, knife=0, clean_steps=0, clean_tight=0, clean_total=0,
-                                                              worst_tight_ratio=0.0, knife_steps=[], detail=[]))
+                                                              worst_tight_ratio=0.0, knife_steps=[], detail=[],
+                                                              landmark_near_ties=0, mask_near_threshold=0, landmarks_total=0))
     for step in range(3):
         # Adam turns fp32 noise on near-zero gradients into O(lr) weight differences, so the oracle restarts every
         # step from the DEVICE weights; the optimiser arithmetic is checked separately on the device's gradients.
@@ -183,6 +200,8 @@ def test_fp32_training_steps_match_oracle(variant):
     # wherever the float64 oracle finds the comparison well-posed (no knife edge in that step), the tight bound must be the rule
     assert rep['clean_tight'] >= 0.9 * rep['clean_total'], 'tight gradient bound held on %d of %d tensors of knife-free steps: %s' % (
         rep['clean_tight'], rep['clean_total'], [d for d in rep['detail'] if d[2] != 'knife'][:8])
+    if _variant_id(variant) in CLEAN_SEEDS:
+        assert rep['clean_total'] > 0                                      # ... and the rule was really exercised for this graph
     torch.cuda.synchronize()
     assert model._params.step_count() == 3
     # inference after training: heat-maps 1e-3, argmax bit-exact, >0.5 masks identical
@@ -191,7 +210,13 @@ def test_fp32_training_steps_match_oracle(variant):
     pr = ref.predict(xt.astype(np.float64))
     assert pg.dtype == np.float32 and pg.shape == pr.shape
     assert np.abs(pg - pr).max() < 1e-3
-    _assert_landmarks_and_masks(pg, pr)
+    nd, nm = _assert_landmarks_and_masks(pg, pr)
+    # mismatches tolerated because the ORACLE's own two candidates tie within 2e-5 (every other mismatch fails inside the helper): reported
+    # per variant (profiles/r03_tolerance_branches.json).  After three steps from a random initialisation the tiny 3-D nets still predict
+    # almost flat heat-maps, so a near-tie is common there; the bit-exact claim is asserted on BASELINE config 1 (nd == 0, below).
+    rep['landmark_near_ties'], rep['mask_near_threshold'] = nd, nm
+    rep['landmarks_total'] = int(np.prod(pg.shape[:-3])) * pg.shape[-1]
+    assert nd <= rep['landmarks_total'] // 2, (nd, rep['landmarks_total'])
     idx, mask = model.predict_landmarks(xt[:3])
     np.testing.assert_array_equal(idx, O.landmark_argmax(pg[:3]))
     np.testing.assert_array_equal(mask.astype(bool), O.threshold_mask(pg[:3]))
@@ -316,7 +341,8 @@ def test_zz_tolerance_branch_report():
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, 'r03_tolerance_branches.json'), 'w') as f:
         json.dump(BRANCH_REPORT, f, indent=1)
-    tot = {k: sum(v[k] for v in BRANCH_REPORT.values()) for k in ('tight', 'f32', 'knife', 'clean_steps', 'clean_tight', 'clean_total')}
+    tot = {k: sum(v[k] for v in BRANCH_REPORT.values()) for k in ('tight', 'f32', 'knife', 'clean_steps', 'clean_tight', 'clean_total',
+                                                                  'landmark_near_ties', 'mask_near_threshold', 'landmarks_total')}
     print('gradient tolerance branches:', tot)
     assert tot['clean_steps'] >= 3 and tot['clean_tight'] >= 0.9 * tot['clean_total']
 
