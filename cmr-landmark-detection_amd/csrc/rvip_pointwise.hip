@@ -1447,7 +1447,7 @@ extern "C" int rvip_bn_bwd_reduce(const rvip_bnbwd_desc* d, void* stream) {
 
 // ---- stage 1 of the BatchNormalization backward from the consumers' by-products (include/rvip_hip.h: rvip_bn_bwd_coef) ----
 namespace rvip {
-struct CoefSrc { const float* rows; int nrows, stride, offset; };
+struct CoefSrc { const void* rows; int nrows, stride, offset; };      // t1: float rows, t2: double rows
 struct CoefArgs {
     CoefSrc t1[2], t2[2];
     const float* gamma; const float* beta; const float* mean; const float* invstd;
@@ -1486,14 +1486,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(CoefArgs a) {
             for (int q = 0; q < 2; ++q) {
                 const CoefSrc src = k == 0 ? a.t1[q] : a.t2[q];
                 if (!src.rows) continue;
-                const float* base = src.rows + src.offset + ch;
-                int b = g;
-                for (; b + 96 < src.nrows; b += 128) {
-                    const float v0 = base[(size_t)b * src.stride], v1 = base[(size_t)(b + 32) * src.stride];
-                    const float v2 = base[(size_t)(b + 64) * src.stride], v3 = base[(size_t)(b + 96) * src.stride];
-                    s[k] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+                if (k == 0) {
+                    const float* base = reinterpret_cast<const float*>(src.rows) + src.offset + ch;
+                    int b = g;
+                    for (; b + 96 < src.nrows; b += 128) {
+                        const float v0 = base[(size_t)b * src.stride], v1 = base[(size_t)(b + 32) * src.stride];
+                        const float v2 = base[(size_t)(b + 64) * src.stride], v3 = base[(size_t)(b + 96) * src.stride];
+                        s[k] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+                    }
+                    for (; b < src.nrows; b += 32) s[k] += (double)base[(size_t)b * src.stride];
+                } else {
+                    const double* base = reinterpret_cast<const double*>(src.rows) + src.offset + ch;
+                    for (int b = g; b < src.nrows; b += 32) s[k] += base[(size_t)b * src.stride];
                 }
-                for (; b < src.nrows; b += 32) s[k] += (double)base[(size_t)b * src.stride];
             }
         }
     }

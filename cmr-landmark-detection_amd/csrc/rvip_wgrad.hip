@@ -688,14 +688,20 @@ static int launch_wgrad_fold(const float* slab, int nsplit, long long count, flo
 template <typename T, int G, int U>
 __global__ __launch_bounds__(32 * G) void wgrad_fold_dot_kernel(const float4* __restrict__ slab, int nsplit, long long count4, float4* __restrict__ dw,
                                                                 const float4* __restrict__ w, int cout4, int cin, int nrow, int lw, int nchunk,
-                                                                float* __restrict__ rows) {
+                                                                double* __restrict__ rows) {
+    // The dot product is carried in DOUBLE from the slabs on: sum W*dW is a small difference of large terms whenever the
+    // gradient reaching the producer is mostly common-mode (BatchNormalization removes that part), and float partial sums over
+    // the 9 * Cout terms of a channel would lose to that cancellation what the pass over (g, xhat) it replaces does not.  dw
+    // itself is the float sum in the plain fold's order (bit-identical to wgrad_fold_kernel).
     __shared__ float4 sh[G][32];
+    __shared__ double shd[G][32][4];
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int rpw = 32 / lw, rl = e / lw, l = e - rl * lw;
     const int chunk = blockIdx.x % nchunk, row = (blockIdx.x / nchunk) * rpw + rl, col4 = chunk * 32 + l;
     const bool valid = row < nrow && col4 < cout4;
     const long long i = (long long)row * cout4 + col4;
     float4 acc = {0.f, 0.f, 0.f, 0.f};
+    double da[4] = {0.0, 0.0, 0.0, 0.0};
     if (valid) {
         for (int k0 = g; k0 < nsplit; k0 += G * U) {
             float4 v[U];
@@ -705,20 +711,30 @@ __global__ __launch_bounds__(32 * G) void wgrad_fold_dot_kernel(const float4* __
                 v[u] = k < nsplit ? slab[(size_t)k * count4 + i] : float4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            for (int u = 0; u < U; ++u) {
+                acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                da[0] += (double)v[u].x; da[1] += (double)v[u].y; da[2] += (double)v[u].z; da[3] += (double)v[u].w;
+            }
         }
     }
     sh[g][e] = acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) shd[g][e][q] = da[q];
     __syncthreads();
     if (g >= 2) return;                                   // the first wave (element lanes 0..31 twice) finishes
-    float p = 0.f;
+    double p = 0.0;
     if (g == 0 && valid) {
         float4 t = sh[0][e];
+        double d[4] = {shd[0][e][0], shd[0][e][1], shd[0][e][2], shd[0][e][3]};
 #pragma unroll
-        for (int gg = 1; gg < G; ++gg) { t.x += sh[gg][e].x; t.y += sh[gg][e].y; t.z += sh[gg][e].z; t.w += sh[gg][e].w; }
+        for (int gg = 1; gg < G; ++gg) {
+            t.x += sh[gg][e].x; t.y += sh[gg][e].y; t.z += sh[gg][e].z; t.w += sh[gg][e].w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] += shd[gg][e][q];
+        }
         dw[i] = t;
         const float4 wv = w[i];
-        p = fmaf(Vec<T>::round(wv.x), t.x, fmaf(Vec<T>::round(wv.y), t.y, fmaf(Vec<T>::round(wv.z), t.z, Vec<T>::round(wv.w) * t.w)));
+        p = (double)Vec<T>::round(wv.x) * d[0] + (double)Vec<T>::round(wv.y) * d[1] + (double)Vec<T>::round(wv.z) * d[2] + (double)Vec<T>::round(wv.w) * d[3];
     }
     for (int o = 1; o < lw; o <<= 1) p += __shfl_xor(p, o);        // lw is a power of two <= 32: stays inside the row's lanes
     if (g == 0 && l == 0 && row < nrow) {
@@ -740,7 +756,7 @@ static DotGeom dot_geometry(int taps, int cin, int cout) {
 }
 
 template <typename T>
-static int launch_wgrad_fold_dot(const float* slab, int nsplit, int cin, int cout, float* dw, const float* w, float* rows, hipStream_t s) {
+static int launch_wgrad_fold_dot(const float* slab, int nsplit, int cin, int cout, float* dw, const float* w, double* rows, hipStream_t s) {
     const long long count = 9LL * cin * cout;
     if (cout % 4 || ((uintptr_t)slab & 15) || ((uintptr_t)dw & 15) || ((uintptr_t)w & 15)) return RVIP_EINVAL;
     const DotGeom g = dot_geometry(9, cin, cout);
@@ -877,7 +893,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     if ((kd != 1 && kd != 3) || d->n % depth) return RVIP_EINVAL;
     if (d->dot_rows) {
         if (!d->w_master || d->defer_fold) return RVIP_EINVAL;
-        if (d->dot_rows_bytes < (size_t)rvip_conv3x3_wgrad_dot_rows(d) * (d->c0 + d->c1) * sizeof(float)) return RVIP_EWORKSPACE;
+        if (d->dot_rows_bytes < (size_t)rvip_conv3x3_wgrad_dot_rows(d) * (d->c0 + d->c1) * sizeof(double) || ((uintptr_t)d->dot_rows & 7)) return RVIP_EWORKSPACE;
     }
     const long long esz = RVIP_ESZ(d->dtype);
     const long long x0b = (long long)a.n * (a.h >> a.up0) * (a.w >> a.up0) * a.c0 * esz, x1b = (long long)a.n * a.h * a.w * a.c1 * esz;

@@ -582,9 +582,9 @@ class Engine:
                     nr = L.rvip_conv3x3_fwd_sums_rows(C.byref(dg))
                     sums_rows[c.conv] = (torch.zeros(nr * c.cin, dtype=torch.float32, device=self.ws.device), nr)
                     nd = L.rvip_conv3x3_wgrad_dot_rows(C.byref(wg))
-                    dbuf = torch.zeros(nd * c.cin, dtype=torch.float32, device=self.ws.device)
+                    dbuf = torch.zeros(nd * c.cin, dtype=torch.float64, device=self.ws.device)
                     dot_rows[c.conv] = (dbuf, nd)
-                    wg.w_master, wg.dot_rows, wg.dot_rows_bytes = P.p(c.conv, 'kernel').value, dbuf.data_ptr(), dbuf.numel() * 4
+                    wg.w_master, wg.dot_rows, wg.dot_rows_bytes = P.p(c.conv, 'kernel').value, dbuf.data_ptr(), dbuf.numel() * 8
                 if p.drop and p.drop[1] > 0:          # Dropout backward rides in the consumer's data-gradient epilogue
                     dg.gdrop_rate, dg.gdrop_state, dg.gdrop_layer_id = p.drop[1], state.value, p.drop[2]
         for c in plan.stages:                   # a split result whose first half nobody sums (the up-conv has no BatchNormalization)

@@ -166,12 +166,12 @@ typedef struct rvip_wgrad3x3_desc {
      * together with other layers', with rvip_fold_rows_batch(..., wide = 1). */
     int32_t      defer_fold;
     /* dot_rows != NULL (ABI 5; needs w_master, excludes defer_fold): the fold of the slabs also writes
-     * rvip_conv3x3_wgrad_dot_rows(d) partial rows [rows][C0+C1] whose column sums are  T2[i] = sum_{t,o} Wr[t][i][o] * dw[t][i][o],
+     * rvip_conv3x3_wgrad_dot_rows(d) partial rows [rows][C0+C1] of DOUBLES whose column sums are  T2[i] = sum_{t,o} Wr[t][i][o] * dw[t][i][o],
      * Wr = w_master rounded to `dtype` (what the data gradient multiplies with).  Because the conv is linear in its input X,
      * T2[i] = sum_pixels X[.,i] * dX[.,i]: the `sum g*y` term of the BatchNormalization backward of whichever stage produced
      * channel i of X, without a pass over g and y (rvip_bn_bwd_coef). */
     const float* w_master;            /* [taps][C0+C1][Cout] fp32, the layer's HWIO kernel */
-    float*       dot_rows; size_t dot_rows_bytes;
+    double*      dot_rows; size_t dot_rows_bytes;     /* double: the sum cancels heavily when the gradient is mostly common-mode */
 } rvip_wgrad3x3_desc;
 
 size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout);
@@ -306,7 +306,7 @@ int rvip_bn_bwd_rows(long long rows, int c, int dtype);
  * described by `fallback`, the stage's rvip_bn_bwd_reduce descriptor (dy = the gradient the apply pass will read; drop_rate 0
  * when the consumer's data gradient already applied the Dropout backward) -- slowly (one workgroup per 32 channels), inside the
  * same launch; flags[ceil(C/32)] reports which blocks did (1).  Training from the Keras initialisation never takes that route. */
-typedef struct rvip_bncoef_src { const float* rows; int32_t nrows; int32_t stride; int32_t offset; int32_t reserved; } rvip_bncoef_src;
+typedef struct rvip_bncoef_src { const void* rows; int32_t nrows; int32_t stride; int32_t offset; int32_t reserved; } rvip_bncoef_src;   /* t1: float rows, t2: double rows; stride / offset in elements */
 typedef struct rvip_bncoef_desc {
     rvip_bncoef_src t1[2]; rvip_bncoef_src t2[2];      /* rows == NULL: unused */
     const float* gamma; const float* beta; const float* mean; const float* invstd;

@@ -120,10 +120,11 @@ def test_wgrad_dot_rows(shape, dtype):
         if dot:
             nr = L.rvip_conv3x3_wgrad_dot_rows(C.byref(g))
             assert nr == 9 * -(-co // 128)
-            rows = torch.full((nr, ci), 7.0, dtype=torch.float32, device=dev())
-            g.w_master, g.dot_rows, g.dot_rows_bytes = wm.data_ptr(), rows.data_ptr(), rows.numel() * 4
+            rows = torch.full((nr, ci), 7.0, dtype=torch.float64, device=dev())
+            g.w_master, g.dot_rows, g.dot_rows_bytes = wm.data_ptr(), rows.data_ptr(), rows.numel() * 8
         N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
-        return down(dw), (down(rows) if dot else None)
+        torch.cuda.synchronize()
+        return down(dw), (rows.cpu().numpy() if dot else None)
     dw0, _ = run(False)
     dw1, rows = run(True)
     np.testing.assert_array_equal(dw0, dw1)
@@ -220,8 +221,8 @@ def test_bn_bwd_coef_equals_the_reduction_pass(dtype, rate):
     g.n, g.h, g.w, g.cout, g.dtype = n, h, w, co, ndt(dtype)
     g.workspace, g.workspace_bytes = k['ws'].data_ptr(), k['wsb']
     nd = L.rvip_conv3x3_wgrad_dot_rows(C.byref(g))
-    drows = torch.empty((nd, c), dtype=torch.float32, device=dev())
-    g.w_master, g.dot_rows, g.dot_rows_bytes = k['wm'].data_ptr(), drows.data_ptr(), drows.numel() * 4
+    drows = torch.empty((nd, c), dtype=torch.float64, device=dev())
+    g.w_master, g.dot_rows, g.dot_rows_bytes = k['wm'].data_ptr(), drows.data_ptr(), drows.numel() * 8
     N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
     g2 = torch.empty((n, h, w, c), dtype=T, device=dev())
     dst = conv_desc(k['dz2'], co, 0, None, 0, k['wd'], None, g2, None, 0, n, h, w, c, 0, dtype)
@@ -268,6 +269,7 @@ def test_bn_bwd_coef_flags_small_gamma_and_refuses_bad_arguments():
     gam[40] = 1e-4                                                   # one channel of the second 32-channel block
     k['gd'].copy_(torch.from_numpy(gam))
     rows = torch.ones((4, c), dtype=torch.float32, device=dev())
+    rows2 = torch.ones((4, c), dtype=torch.float64, device=dev())
     o = _outputs(c)
     out = [o['dgamma'], o['dbeta'], o['coef']]
     gy = torch.zeros((k['n'], k['h'], k['w'], c), dtype=torch.float32, device=dev())
@@ -276,7 +278,7 @@ def test_bn_bwd_coef_flags_small_gamma_and_refuses_bad_arguments():
     cd = N.BnCoefDesc()
     cd.fallback = C.pointer(fb)
     cd.t1[0].rows, cd.t1[0].nrows, cd.t1[0].stride, cd.t1[0].offset = rows.data_ptr(), 4, c, 0
-    cd.t2[0].rows, cd.t2[0].nrows, cd.t2[0].stride, cd.t2[0].offset = rows.data_ptr(), 4, c, 0
+    cd.t2[0].rows, cd.t2[0].nrows, cd.t2[0].stride, cd.t2[0].offset = rows2.data_ptr(), 4, c, 0
     cd.gamma, cd.beta, cd.mean, cd.invstd = k['gd'].data_ptr(), k['bd'].data_ptr(), k['mean'].data_ptr(), k['invstd'].data_ptr()
     cd.dgamma, cd.dbeta, cd.coef, cd.flags = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), flags.data_ptr()
     cd.count, cd.c, cd.min_gamma, cd.max_beta_ratio = k['rows'], c, 1.0 / 64, 64.0

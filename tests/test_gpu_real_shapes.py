@@ -242,8 +242,8 @@ def test_real_layer_shape_column_sums_and_dot_rows(idx, dtype):
         rows_t = None
         if dot:
             nd = L.rvip_conv3x3_wgrad_dot_rows(C.byref(g))
-            rows_t = torch.full((nd, ci), 7.0, dtype=torch.float32, device=dev())
-            g.w_master, g.dot_rows, g.dot_rows_bytes = wm.data_ptr(), rows_t.data_ptr(), rows_t.numel() * 4
+            rows_t = torch.full((nd, ci), 7.0, dtype=torch.float64, device=dev())
+            g.w_master, g.dot_rows, g.dot_rows_bytes = wm.data_ptr(), rows_t.data_ptr(), rows_t.numel() * 8
         N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
         torch.cuda.synchronize()
         return dw, rows_t
@@ -254,7 +254,8 @@ def test_real_layer_shape_column_sums_and_dot_rows(idx, dtype):
     if c1:
         xin = np.concatenate([xin, k['x1']], -1)
     ident = (xin.astype(np.float64) * k['dx']).sum((0, 1, 2))               # sum_pixels X * dX per input channel (float64)
-    t2 = down(rows_t).astype(np.float64).sum(0)
+    torch.cuda.synchronize()
+    t2 = rows_t.cpu().numpy().sum(0)
     scale = (np.abs(k['wt'].astype(np.float64)) * np.abs(k['dw'])).sum((0, 1, 3)).max()
     assert np.abs(t2 - ident).max() <= 2e-5 * scale * max(1.0, np.sqrt(n * h * w_ / 4096.0)), (name, np.abs(t2 - ident).max() / scale)
 
@@ -503,8 +504,8 @@ def test_real_shape_conv3d(idx, dtype):
     g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
     wm = f32(k['wt'])
     nd = L.rvip_conv3x3_wgrad_dot_rows(C.byref(g))
-    rows_t = torch.full((nd, ci), 7.0, dtype=torch.float32, device=dev())
-    g.w_master, g.dot_rows, g.dot_rows_bytes = wm.data_ptr(), rows_t.data_ptr(), rows_t.numel() * 4
+    rows_t = torch.full((nd, ci), 7.0, dtype=torch.float64, device=dev())
+    g.w_master, g.dot_rows, g.dot_rows_bytes = wm.data_ptr(), rows_t.data_ptr(), rows_t.numel() * 8
     N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
     scale = float(np.abs(k['dw']).max())
     assert np.abs(down(dw) - k['dw']).max() <= 2e-5 * scale * max(1.0, np.sqrt(n * h * h / 4096.0)), (name, np.abs(down(dw) - k['dw']).max() / scale)
@@ -512,6 +513,7 @@ def test_real_shape_conv3d(idx, dtype):
     if c1:
         xin = np.concatenate([xin, k['x1']], -1)
     ident = (xin.astype(np.float64) * k['dx']).sum((0, 1, 2, 3))
-    t2 = down(rows_t).astype(np.float64).sum(0)
+    torch.cuda.synchronize()
+    t2 = rows_t.cpu().numpy().sum(0)
     s2 = (np.abs(k['wt'].astype(np.float64)) * np.abs(k['dw'])).sum((0, 1, 2, 4)).max()
     assert np.abs(t2 - ident).max() <= 2e-5 * s2 * max(1.0, np.sqrt(n * h * h / 4096.0)), (name, np.abs(t2 - ident).max() / s2)
