@@ -333,7 +333,7 @@ __device__ __forceinline__ void epilogue_down2(f32x16 (&acc)[NCT][NPT], int pbas
                 else t += __shfl_xor(t, 16);
                 v[r] = t + __shfl_xor(t, 1);
             }
-            if constexpr (STATS == 2) {              // column sums of what is stored (the kept lanes' block sums)
+            if constexpr (STATS >= 2) {              // column sums of what is stored (the kept lanes' block sums)
                 float qs[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) qs[r] = keep ? Vec<T>::round(v[r]) : 0.f;
@@ -402,7 +402,7 @@ __device__ __forceinline__ float lane_channel_sum(const float (&a)[16], int j) {
 }
 
 // STATS: 0 none; 1 BatchNormalization statistics of the stored output (sum, sum of squares: forward launches); 2 column sums only,
-// for data-gradient launches (with the 2x2-sum / channel-split epilogues and the Dropout backward): rows [gridDim.x][cout]
+// for data-gradient launches (with the 2x2-sum / channel-split epilogues): rows [gridDim.x][cout]; 3 = 2 + the Dropout backward
 template <typename T, int TW, int NCT, int NPIX, int STATS, int TAPS = 9, int NCW = 4>
 __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 a) {
     static_assert(TAPS == 9 || TAPS == 4, "taps");
@@ -610,7 +610,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) st_sum[ct] = st_sq[ct] = 0.f;
     uint32_t gkey = 0;
-    if constexpr (STATS == 2) { if (a.gdrop) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer); }
+    if constexpr (STATS == 3) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer);
 
     int it = 0;
     for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
@@ -701,7 +701,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                             acc[ct][pt][r] = 0.f;
                             v[r] = actf(t);
                         }
-                        if (STATS == 2 && a.gdrop) {     // Dropout backward on the result (wave-uniform)
+                        if constexpr (STATS == 3) {      // Dropout backward on the result
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 float u[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
@@ -743,6 +743,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
             }
         };
         if (a.down2) epilogue_down2<T, TW, NCT, NPT, STATS>(acc, wv * (NPT * 32), j, hf, n, ty0, tx0, co0, a, ry, st_sum);
+        else if constexpr (STATS >= 2) epilogue([](float t) { return t; });      // data gradients carry no activation (host-checked)
         else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
         else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
         else epilogue([&](float t) { return act_fwd(t, a.act); });
@@ -792,7 +793,7 @@ __device__ __forceinline__ float lane16_channel_sum(const float (&a)[4], int i16
     return e + swz<1>(e);
 }
 // STATS: 0 none; 1 BatchNormalization statistics of the stored output (sum, sum of squares: forward launches); 2 column sums only,
-// for data-gradient launches (with the 2x2-sum / channel-split epilogues and the Dropout backward): rows [gridDim.x][cout]
+// for data-gradient launches (with the 2x2-sum / channel-split epilogues): rows [gridDim.x][cout]; 3 = 2 + the Dropout backward
 template <typename T, int TW, int NCT, int NPIX, int STATS, int TAPS = 9, int NCW = 4>
 __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs2 a) {
     static_assert(sizeof(T) == 2, "16-bit storage types");
@@ -1002,7 +1003,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) st_sum[cb] = st_sq[cb] = 0.f;
     uint32_t gkey = 0;
-    if constexpr (STATS == 2) { if (a.gdrop) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer); }
+    if constexpr (STATS == 3) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer);
 
     int it = 0;
     for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
@@ -1078,7 +1079,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                 // column sums (STATS == 2): of the fp32 values in front of the storage rounding, only for the channel pairs somebody
                 // reads (sums_from: the first half of a split result belongs to a stage without BatchNormalization), and without the
                 // per-pixel validity select when the whole tile lies inside the image -- all wave-uniform
-                const bool need_sums = STATS == 2 && co0 + cp * 32 + 32 > a.sums_from;
+                const bool need_sums = STATS >= 2 && co0 + cp * 32 + 32 > a.sums_from;
                 const bool interior = ty0 + TH <= a.h && tx0 + TW <= a.w;
 #pragma unroll
                 for (int q = 0; q < NPB / 2; ++q) {
@@ -1098,8 +1099,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                             float v[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { v[r] = actf(acc[cb][blk][r]); acc[cb][blk][r] = bias_r[cb][r]; }
-                            if constexpr (STATS == 2) {      // Dropout backward on the result (wave-uniform test)
-                                if (a.gdrop) gdrop4(v, pix, a.cout, co0 + cb * 16 + 4 * kq, gkey, a.g_thr, a.g_inv_keep);
+                            if constexpr (STATS == 3) gdrop4(v, pix, a.cout, co0 + cb * 16 + 4 * kq, gkey, a.g_thr, a.g_inv_keep);      // Dropout backward on the result
+                            if constexpr (STATS >= 2) {
                                 if (need_sums) {
                                     if (interior) {
 #pragma unroll
@@ -1136,7 +1137,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                         st_sq[2 * cp + c2] += lane16_channel_sum(qq[c2], i16);
                     }
                 }
-                if constexpr (STATS == 2) {
+                if constexpr (STATS >= 2) {
                     if (need_sums) {
                         st_sum[2 * cp] += lane16_channel_sum(qs[0], i16);
                         st_sum[2 * cp + 1] += lane16_channel_sum(qs[1], i16);
@@ -1175,20 +1176,21 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                     const unsigned w00 = Vec<T>::pack2(v[0][0], v[0][1]), w01 = Vec<T>::pack2(v[0][2], v[0][3]);
                     const unsigned w10 = Vec<T>::pack2(v[1][0], v[1][1]), w11 = Vec<T>::pack2(v[1][2], v[1][3]);
                     store_cbpair(cp, w00, w01, w10, w11, pix, keep);
-                    if constexpr (STATS == 2) {                                // column sums of the block sums (fp32, in front of the rounding)
+                    if constexpr (STATS >= 2) {                                // column sums of the block sums (fp32, in front of the rounding)
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) qd[c2][r] += keep ? v[c2][r] : 0.f;
                     }
                 }
-                if constexpr (STATS == 2) {
+                if constexpr (STATS >= 2) {
                     st_sum[2 * cp] += lane16_channel_sum(qd[0], i16);
                     st_sum[2 * cp + 1] += lane16_channel_sum(qd[1], i16);
                 }
             }
         };
         if (a.down2) epilogue_down2_16();
+        else if constexpr (STATS >= 2) epilogue([](float t) { return t; });      // data gradients carry no activation (host-checked)
         else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
         else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
         else epilogue([&](float t) { return act_fwd(t, a.act); });
@@ -1266,6 +1268,8 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, 2, TAPS, NCW>()),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, 3, TAPS, NCW>()),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         }
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
         attr_lds = LDS_MAX;
@@ -1282,7 +1286,8 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (dry) { used = true; return RVIP_OK; }
     if (stats) {
         if constexpr (TAPS == 9) {
-            if (smode == 2) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 2, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
+            if (smode == 2 && b.gdrop) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 3, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
+            else if (smode == 2) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 2, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
             else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 1, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
         } else return RVIP_EUNSUPPORTED;
     } else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 0, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
@@ -1767,6 +1772,7 @@ extern "C" int rvip_conv3x3_fwd_sums(const rvip_conv3x3_desc* d, float* sums_ws,
     if (rc) return rc;
     const int rows = rvip_conv3x3_fwd_sums_rows(d);
     if (!sums_ws || rows <= 0) return RVIP_EUNSUPPORTED;
+    if (d->act != RVIP_ACT_NONE || d->bias) return RVIP_EINVAL;          // a data gradient: no bias, no activation
     if (sums_ws_bytes < (size_t)rows * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
     if (d->gdrop_rate != 0.f) {                       // Dropout backward in the epilogue
         if (d->gdrop_rate < 0.f || d->gdrop_rate >= 1.f || !d->gdrop_state || d->y1 || d->down2 || (d->cout & 7)) return RVIP_EINVAL;
