@@ -35,7 +35,7 @@ class Conv3x3Desc(C.Structure):
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('act', C.c_int32), ('dtype', C.c_int32),
                 ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32), ('subpix', C.c_int32), ('stream_in', C.c_int32),
-                ('gdrop_rate', C.c_float), ('gdrop_state', vp), ('gdrop_layer_id', C.c_int32), ('sums_from', C.c_int32)]
+                ('mask_bits', vp), ('mask_channels', C.c_int32), ('mask_scale', C.c_float), ('sign_bits', vp), ('sums_from', C.c_int32)]
 
 
 class PackEntry(C.Structure):
@@ -61,7 +61,7 @@ class ApplyDesc(C.Structure):
                 ('drop_rate', C.c_float), ('mask', vp), ('state', vp), ('layer_id', C.c_int32),
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('c', C.c_int32),
                 ('dtype', C.c_int32),
-                ('argmax', vp)]
+                ('argmax', vp), ('keep_bits', vp)]
 
 
 class BnBwdDesc(C.Structure):
@@ -93,7 +93,7 @@ class BnCoefDesc(C.Structure):
 
 
 class FoldEntry(C.Structure):
-    _fields_ = [('src', vp), ('dst', vp), ('nrows', C.c_int32), ('reserved', C.c_int32), ('width', C.c_longlong)]
+    _fields_ = [('src', vp), ('dst', vp), ('nrows', C.c_int32), ('stride', C.c_int32), ('width', C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/rvip_hip.h declares
@@ -102,6 +102,7 @@ SIGNATURES = {
     'rvip_build_info': (C.c_char_p, []),
     'rvip_last_hip_error': (C.c_int, []),
     'rvip_conv3x3_fwd': (C.c_int, [C.POINTER(Conv3x3Desc), vp]),
+    'rvip_conv3x3_sign_bits_ok': (C.c_int, [C.POINTER(Conv3x3Desc)]),
     'rvip_conv3x3_fwd_stats_rows': (C.c_int, [C.POINTER(Conv3x3Desc)]),
     'rvip_conv3x3_fwd_stats': (C.c_int, [C.POINTER(Conv3x3Desc), vp, C.c_size_t, vp]),
     'rvip_conv3x3_fwd_sums_rows': (C.c_int, [C.POINTER(Conv3x3Desc)]),

@@ -50,8 +50,10 @@ struct ConvArgs {
     int down2;                                // store the 2x2 block sums of the result at half resolution (gradient of UpSampling2D)
     int subpix;                               // UpSampling2D -> conv as four 2x2-tap phase convolutions on the low-resolution input
     int nt_in;                                // non-temporal input reads (last reader of x0)
-    // statistics launches of a data gradient whose output crosses a Dropout layer backwards: store / sum keep ? g * inv_keep : 0
-    int gdrop; float g_inv_keep; uint32_t g_thr; const uint32_t* g_state; int g_layer;
+    // sums launches of a data gradient whose result is gated element-wise (Dropout backward: keep bits x 1/(1-rate); ReLU backward of a
+    // BN-less stage: sign bits of its forward output): bit planes [C/32][N*H*W] of one 32-bit word per pixel, first mbits_c channels
+    const uint32_t* mbits; int mbits_c; float mscale;
+    uint32_t* sbits;                          // forward launches: write the sign bits (stored value > 0) of the result in that layout
     int sums_from;
 };
 
@@ -287,19 +289,15 @@ struct ConvArgs2 {
     int nt_in;                               // input pieces with the non-temporal hint
     int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
-    int gdrop; float g_inv_keep; uint32_t g_thr; const uint32_t* g_state; int g_layer;      // see ConvArgs
-    int sums_from;                           // STATS == 2: columns below this channel are not needed (left unwritten or partial)
+    const uint32_t* mbits; unsigned mbits_bytes; int mbits_c; float mscale; int lds_mb_off;      // see ConvArgs; STATS == 3 kernels
+    uint32_t* sbits; unsigned sbits_bytes;   // STATS == 0 kernels
+    int sums_from;                           // STATS >= 2: columns below this channel are not needed (left unwritten or partial)
 };
 
-// Dropout backward on four consecutive channels of one pixel (STATS launches with gdrop): the keep bits of the counter stream the
-// forward rvip_bn_apply used -- one hash per PAIR of elements, pair index = (pixel * C + channel) / 2 (dropout_keep in rvip_common.h).
-__device__ __forceinline__ void gdrop4(float (&v)[4], unsigned pix, int cout, int co, uint32_t key, uint32_t thr, float inv_keep) {
-    const uint32_t pr = pix * (uint32_t)(cout >> 1) + (uint32_t)(co >> 1);
-    const uint32_t h0 = hash32(pr ^ key), h1 = hash32((pr + 1u) ^ key);
-    v[0] = (h0 & 0xffffu) < thr ? v[0] * inv_keep : 0.f;
-    v[1] = (h0 >> 16) < thr ? v[1] * inv_keep : 0.f;
-    v[2] = (h1 & 0xffffu) < thr ? v[2] * inv_keep : 0.f;
-    v[3] = (h1 >> 16) < thr ? v[3] * inv_keep : 0.f;
+// Gate four consecutive channels of one pixel by four bits of a mask word (STATS == 3): v = bit ? v * scale : 0
+__device__ __forceinline__ void gate4(float (&v)[4], unsigned nib, float scale) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? v[r] * scale : 0.f;
 }
 
 // Epilogue of the data gradient of an UpSampling2D -> conv pair (KerasLayers.py:756-758): the gradient w.r.t. the
@@ -471,6 +469,14 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
         unsigned t0[QI], t1[QI];                         // prepared tile: per-piece offsets (border test folded in)
         int p_nmod = 0, p_tb0 = 0, p_tb1 = 0;
         const int img0_bytes = h0 * w0 * a.c0 * (int)sizeof(T), img1_bytes = a.h * a.w * a.c1 * (int)sizeof(T);
+        // STATS == 3: the mask words of the tile's OUTPUT pixels, one 32-channel plane per channel tile, [TH][TW] words per plane, are
+        // one 1 KiB piece per loader wave (NCT * NPIX / 256 <= 4 pieces), double-buffered by tile parity; issued with chunk 0 of the tile
+        constexpr int MB_PLANE = TH * TW * 4, NPM = MB_PLANE / 1024, MB_TILE = NCT * MB_PLANE, MB_LPR = TW / 4;
+        const bool mb_mine = STATS == 3 && lwv < NCT * NPM && co0 + (lwv / NPM) * 32 < a.mbits_c;
+        const int mb_row = (lwv % NPM) * (64 / MB_LPR) + lane / MB_LPR, mb_x = (lane % MB_LPR) * 4;
+        const i32x4 rsm = make_rsrc(STATS == 3 ? (const void*)a.mbits : (const void*)a.x0, STATS == 3 ? a.mbits_bytes : 0u);
+        unsigned p_mb = OOB;
+        int mb_par = 0;
         auto prep_tile = [&](int tile) __attribute__((always_inline)) {
             unsigned bx = (unsigned)tile;
             const unsigned tx_i = bx % (unsigned)a.tiles_x; bx /= (unsigned)a.tiles_x;
@@ -480,6 +486,10 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
             p_nmod = a.depth > 1 ? n_out % a.depth : 0;
             p_tb0 = ((n_out * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 * (int)sizeof(T);
             p_tb1 = ((n_out * a.h + ty0) * a.w + tx0) * a.c1 * (int)sizeof(T);
+            if constexpr (STATS == 3) {
+                const bool ok = mb_mine && ty0 + mb_row < a.h && tx0 + mb_x < a.w;
+                p_mb = ok ? (unsigned)(((co0 / 32 + lwv / NPM) * a.n * a.h + n_out * a.h + ty0 + mb_row) * a.w + tx0 + mb_x) * 4u : OOB;
+            }
 #pragma unroll
             for (int i = 0; i < QI; ++i) {
                 const int gy = ty0 + ihy[i], gx = tx0 + ihx[i];
@@ -520,6 +530,12 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
             const int crem = dok ? (from0 ? a.c0 : a.c1) - cb : 0;
             const unsigned li0 = lds_base + stage * IN_BYTES + lwv * 1024;                      // + i * 4096 per piece
             const unsigned base = (unsigned)((from0 ? p_tb0 + dsh * img0_bytes : p_tb1 + dsh * img1_bytes) + cb * (int)sizeof(T));
+            if constexpr (STATS == 3) {
+                if (kc == 0) {                               // first chunk of a tile: its mask words ride along (wave-uniform)
+                    if (lwv < NCT * NPM) dma16(rsm, p_mb, lds_base + a.lds_mb_off + mb_par * MB_TILE + lwv * 1024);
+                    mb_par ^= 1;
+                }
+            }
             if (crem >= KCE && !a.nt_in) {                   // full chunk inside the volume: offset = prepared + base
                 if (from0) {
 #pragma unroll
@@ -609,11 +625,13 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
     float st_sum[NCT], st_sq[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) st_sum[ct] = st_sq[ct] = 0.f;
-    uint32_t gkey = 0;
-    if constexpr (STATS == 3) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer);
+    constexpr int MB_PLANE = TH * TW * 4, MB_TILE = NCT * MB_PLANE;
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 0 && a.sbits ? (void*)a.sbits : (void*)a.y), 0,
+                                                                          STATS == 0 && a.sbits ? a.sbits_bytes : 0u, 0x00020000);
+    int mb_par = 0;
 
     int it = 0;
-    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x, mb_par ^= 1) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
@@ -701,12 +719,15 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                             acc[ct][pt][r] = 0.f;
                             v[r] = actf(t);
                         }
-                        if constexpr (STATS == 3) {      // Dropout backward on the result
+                        if constexpr (STATS == 3) {      // gate by the tile's mask words (Dropout / ReLU backward), wave-uniform per channel tile
+                            if (co0 + ct * 32 < a.mbits_c) {
+                                const unsigned word = *reinterpret_cast<const unsigned*>(smem + a.lds_mb_off + mb_par * MB_TILE + ct * MB_PLANE + P * 4);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                float u[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-                                gdrop4(u, pix, a.cout, co0 + ct * 32 + 8 * q + 4 * hf, gkey, a.g_thr, a.g_inv_keep);
-                                v[4 * q] = u[0]; v[4 * q + 1] = u[1]; v[4 * q + 2] = u[2]; v[4 * q + 3] = u[3];
+                                for (int q = 0; q < 4; ++q) {
+                                    float u[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                                    gate4(u, (word >> (8 * q + 4 * hf)) & 15u, a.mscale);
+                                    v[4 * q] = u[0]; v[4 * q + 1] = u[1]; v[4 * q + 2] = u[2]; v[4 * q + 3] = u[3];
+                                }
                             }
                         }
 #pragma unroll
@@ -738,6 +759,17 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                             v[r] = actf(t);
                         }
                         store_tile(ct, v, pix, pix_ok);
+                        if constexpr (STATS == 0) {
+                            if (a.sbits) {                   // sign bits of what was stored: word = 32 channels of one pixel, plane = 32-channel block
+                                unsigned word = 0;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) word |= (Vec<T>::round(v[r]) > 0.f ? 1u : 0u) << (8 * (r >> 2) + 4 * hf + (r & 3));
+                                word |= (unsigned)__shfl_xor((int)word, 32);
+                                const int cbase = co0 + ct * 32;
+                                const unsigned off = (pix_ok && !hf && cbase < a.cout) ? ((unsigned)(cbase / 32) * (unsigned)((TAPS == 4 ? 4 : 1) * a.n * a.h * a.w) + pix) * 4u : OOB;
+                                __builtin_amdgcn_raw_buffer_store_b32(word, rsb, off, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -862,6 +894,14 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
         unsigned t0[QI], t1[QI];                         // prepared tile: per-piece offsets (border test folded in)
         int p_nmod = 0, p_tb0 = 0, p_tb1 = 0;
         const int img0_bytes = h0 * w0 * a.c0 * (int)sizeof(T), img1_bytes = a.h * a.w * a.c1 * (int)sizeof(T);
+        // STATS == 3: the mask words of the tile's OUTPUT pixels, one 32-channel plane per channel tile, [TH][TW] words per plane, are
+        // one 1 KiB piece per loader wave (NCT * NPIX / 256 <= 4 pieces), double-buffered by tile parity; issued with chunk 0 of the tile
+        constexpr int MB_PLANE = TH * TW * 4, NPM = MB_PLANE / 1024, MB_TILE = NCT * MB_PLANE, MB_LPR = TW / 4;
+        const bool mb_mine = STATS == 3 && lwv < NCT * NPM && co0 + (lwv / NPM) * 32 < a.mbits_c;
+        const int mb_row = (lwv % NPM) * (64 / MB_LPR) + lane / MB_LPR, mb_x = (lane % MB_LPR) * 4;
+        const i32x4 rsm = make_rsrc(STATS == 3 ? (const void*)a.mbits : (const void*)a.x0, STATS == 3 ? a.mbits_bytes : 0u);
+        unsigned p_mb = OOB;
+        int mb_par = 0;
         auto prep_tile = [&](int tile) __attribute__((always_inline)) {
             unsigned bx = (unsigned)tile;
             const unsigned tx_i = bx % (unsigned)a.tiles_x; bx /= (unsigned)a.tiles_x;
@@ -871,6 +911,10 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             p_nmod = a.depth > 1 ? n_out % a.depth : 0;
             p_tb0 = ((n_out * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 * (int)sizeof(T);
             p_tb1 = ((n_out * a.h + ty0) * a.w + tx0) * a.c1 * (int)sizeof(T);
+            if constexpr (STATS == 3) {
+                const bool ok = mb_mine && ty0 + mb_row < a.h && tx0 + mb_x < a.w;
+                p_mb = ok ? (unsigned)(((co0 / 32 + lwv / NPM) * a.n * a.h + n_out * a.h + ty0 + mb_row) * a.w + tx0 + mb_x) * 4u : OOB;
+            }
 #pragma unroll
             for (int i = 0; i < QI; ++i) {
                 const int gy = ty0 + ihy[i], gx = tx0 + ihx[i];
@@ -911,6 +955,12 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             const int crem = dok ? (from0 ? a.c0 : a.c1) - cb : 0;
             const unsigned li0 = lds_base + stage * IN_BYTES + lwv * 1024;                      // + i * 4096 per piece
             const unsigned base = (unsigned)((from0 ? p_tb0 + dsh * img0_bytes : p_tb1 + dsh * img1_bytes) + cb * (int)sizeof(T));
+            if constexpr (STATS == 3) {
+                if (kc == 0) {                               // first chunk of a tile: its mask words ride along (wave-uniform)
+                    if (lwv < NCT * NPM) dma16(rsm, p_mb, lds_base + a.lds_mb_off + mb_par * MB_TILE + lwv * 1024);
+                    mb_par ^= 1;
+                }
+            }
             if (crem >= KCE && !a.nt_in) {                   // full chunk inside the volume: offset = prepared + base
                 if (from0) {
 #pragma unroll
@@ -1002,11 +1052,13 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     float st_sum[NCB], st_sq[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) st_sum[cb] = st_sq[cb] = 0.f;
-    uint32_t gkey = 0;
-    if constexpr (STATS == 3) gkey = dropout_key(a.g_state[RVIP_STATE_SEED], a.g_state[RVIP_STATE_STEP], (uint32_t)a.g_layer);
+    constexpr int MB_PLANE = TH * TW * 4, MB_TILE = NCT * MB_PLANE;
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 0 && a.sbits ? (void*)a.sbits : (void*)a.y), 0,
+                                                                          STATS == 0 && a.sbits ? a.sbits_bytes : 0u, 0x00020000);
+    int mb_par = 0;
 
     int it = 0;
-    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x, mb_par ^= 1) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
@@ -1081,6 +1133,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                 // per-pixel validity select when the whole tile lies inside the image -- all wave-uniform
                 const bool need_sums = STATS >= 2 && co0 + cp * 32 + 32 > a.sums_from;
                 const bool interior = ty0 + TH <= a.h && tx0 + TW <= a.w;
+                const bool gated = STATS == 3 && co0 + cp * 32 < a.mbits_c;      // this channel pair is gated by the tile's mask words
 #pragma unroll
                 for (int q = 0; q < NPB / 2; ++q) {
                     unsigned pk[2][2][2];                                       // [pixel block of the pair][channel block A / B][word]
@@ -1093,13 +1146,26 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                         ok[s2] = gy < a.h && gx < a.w;
                         const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gy + pa) * 2 * a.w + 2 * gx + pb)
                                                        : (unsigned)((n * a.h + gy) * a.w + gx);
+                        unsigned mword = 0, sword = 0;
+                        if constexpr (STATS == 3) {
+                            if (gated) mword = *reinterpret_cast<const unsigned*>(smem + a.lds_mb_off + mb_par * MB_TILE + cp * MB_PLANE +
+                                                                                  ((row0 + blk / BPR) * TW + (blk % BPR) * 16 + i16) * 4);
+                        }
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2) {
                             const int cb = 2 * cp + c2;
                             float v[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { v[r] = actf(acc[cb][blk][r]); acc[cb][blk][r] = bias_r[cb][r]; }
-                            if constexpr (STATS == 3) gdrop4(v, pix, a.cout, co0 + cb * 16 + 4 * kq, gkey, a.g_thr, a.g_inv_keep);      // Dropout backward on the result
+                            if constexpr (STATS == 3) {      // Dropout / ReLU backward on the result: four bits of the pixel's mask word
+                                if (gated) gate4(v, (mword >> (16 * c2 + 4 * kq)) & 15u, a.mscale);
+                            }
+                            if constexpr (STATS == 0) {      // sign bits of what is stored (forward of a stage whose ReLU backward will be gated)
+                                if (a.sbits) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) sword |= (Vec<T>::round(v[r]) > 0.f ? 1u : 0u) << (16 * c2 + 4 * kq + r);
+                                }
+                            }
                             if constexpr (STATS >= 2) {
                                 if (need_sums) {
                                     if (interior) {
@@ -1115,6 +1181,15 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                             pk[s2][c2][1] = Vec<T>::pack2(v[2], v[3]);
                         }
                         store_cbpair(cp, pk[s2][0][0], pk[s2][0][1], pk[s2][1][0], pk[s2][1][1], pix, ok[s2]);
+                        if constexpr (STATS == 0) {
+                            if (a.sbits) {                   // the four kq lanes of a pixel hold a byte each of its 32-channel word
+                                sword |= (unsigned)__shfl_xor((int)sword, 16);
+                                sword |= (unsigned)__shfl_xor((int)sword, 32);
+                                const int cbase = co0 + cp * 32;
+                                const unsigned off = (ok[s2] && kq == 0 && cbase < a.cout) ? ((unsigned)(cbase / 32) * (unsigned)((TAPS == 4 ? 4 : 1) * a.n * a.h * a.w) + pix) * 4u : OOB;
+                                __builtin_amdgcn_raw_buffer_store_b32(sword, rsb, off, 0, 0);
+                            }
+                        }
                     }
                     if constexpr (STATS == 1) {                                 // statistics of what is stored: the packed words, widened
 #pragma unroll
@@ -1251,13 +1326,21 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.wp_bytes = (unsigned)wpb; b.y_bytes = (unsigned)yb; b.y1_bytes = (unsigned)y1b;
     b.c0 = a0.c0; b.c1 = a0.c1; b.up0 = a0.up0; b.csplit = a0.csplit; b.zs = a0.zs; b.depth = a0.depth; b.kd = a0.kd; b.down2 = a0.down2; b.subpix = a0.subpix; b.nt_in = a0.nt_in;
     b.n = a0.n; b.h = a0.h; b.w = a0.w; b.cin = a0.cin; b.cout = a0.cout; b.act = a0.act;
-    b.gdrop = (stats && smode == 2) ? a0.gdrop : 0; b.sums_from = a0.sums_from; b.g_inv_keep = a0.g_inv_keep; b.g_thr = a0.g_thr; b.g_state = a0.g_state; b.g_layer = a0.g_layer;
+    b.sums_from = a0.sums_from;
+    const bool gated = stats && smode == 2 && a0.mbits;
+    b.mbits = gated ? a0.mbits : nullptr; b.mbits_c = gated ? a0.mbits_c : 0; b.mscale = a0.mscale;
+    b.mbits_bytes = gated ? (unsigned)((long long)cdiv(a0.mbits_c, 32) * npx * 4) : 0u;
+    b.sbits = (!stats && a0.sbits) ? a0.sbits : nullptr;
+    b.sbits_bytes = b.sbits ? (unsigned)((long long)cdiv(a0.cout, 32) * (TAPS == 4 ? npx * 4 : npx) * 4) : 0u;
+    if ((gated || b.sbits) && (a0.cout % 8 || a0.down2 || (gated && a0.mbits_c % 32 && a0.mbits_c != a0.cout))) return RVIP_OK;      // (not served: the caller sees used == false)
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
-    const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 <= LDS_MAX;
+    const int mb_bytes = gated ? 2 * NCT * TH * TW * 4 : 0;      // two tiles of mask words behind the bias table
+    const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 + mb_bytes <= LDS_MAX;
     b.wres = res ? nchunks : 0;
     b.lds_bias_off = 2 * IN_BYTES + (res ? nchunks : 2) * W_BYTES;
-    const int lds = b.lds_bias_off + 256;
+    b.lds_mb_off = b.lds_bias_off + 256;
+    const int lds = b.lds_bias_off + 256 + mb_bytes;
     if (lds > LDS_MAX) return RVIP_OK;
     static std::atomic<int> attr_lds{0};             // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!dry && lds > attr_lds) {
@@ -1286,7 +1369,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (dry) { used = true; return RVIP_OK; }
     if (stats) {
         if constexpr (TAPS == 9) {
-            if (smode == 2 && b.gdrop) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 3, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
+            if (smode == 2 && gated) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 3, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
             else if (smode == 2) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 2, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
             else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 1, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
         } else return RVIP_EUNSUPPORTED;
@@ -1705,7 +1788,7 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     if (a.down2 && (d->y1 || d->bias || d->act != RVIP_ACT_NONE || ((d->h | d->w) & 1))) return RVIP_EINVAL;
     a.nt_in = d->stream_in ? 1 : 0;
     a.subpix = d->subpix ? 1 : 0;
-    a.gdrop = 0; a.g_inv_keep = 1.f; a.g_thr = 65536u; a.g_state = nullptr; a.g_layer = 0;
+    a.mbits = nullptr; a.mbits_c = 0; a.mscale = 1.f; a.sbits = nullptr;
     a.sums_from = (d->sums_from > 0 && d->sums_from % 32 == 0) ? d->sums_from : 0;
     if (a.subpix) {                      // UpSampling2D -> conv as four phase convolutions on the low-resolution grid
         if (d->up0 != 1 || d->c1 || d->y1 || a.kd != 1 || a.down2) return RVIP_EINVAL;
@@ -1719,14 +1802,29 @@ extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
     ConvArgs a;
     int rc0 = conv_args_from_desc(d, a);
     if (rc0) return rc0;
+    if (d->mask_bits) return RVIP_EINVAL;                                  // (rvip_conv3x3_fwd_sums)
+    if (d->sign_bits) {
+        if (d->y1 || d->down2 || d->cout % 8) return RVIP_EINVAL;
+        a.sbits = d->sign_bits;
+    }
     hipStream_t s = (hipStream_t)stream;
     {
         bool used = false;
         const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, s, used, nullptr, nullptr, false, !a.subpix); });
         if (rc || used) return rc;
     }
-    if (a.kd > 1 || a.down2 || a.subpix) return RVIP_EUNSUPPORTED;        // the register-staged fallback is 2-D only and has the plain epilogue
+    if (a.kd > 1 || a.down2 || a.subpix || a.sbits) return RVIP_EUNSUPPORTED;        // the register-staged fallback is 2-D only and has the plain epilogue
     return by_dtype(d->dtype, [&](auto t) { return dispatch_igemm<decltype(t)>(a, s); });
+}
+
+// 1 if rvip_conv3x3_fwd writes d->sign_bits for this launch (the LDS-DMA kernels serve it), else 0
+extern "C" int rvip_conv3x3_sign_bits_ok(const rvip_conv3x3_desc* d) {
+    ConvArgs a;
+    if (conv_args_from_desc(d, a) != RVIP_OK || !d->sign_bits || d->y1 || d->down2 || d->cout % 8) return 0;
+    a.sbits = d->sign_bits;
+    bool used = false;
+    const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, nullptr, nullptr, true, !a.subpix); });
+    return (rc == RVIP_OK && used) ? 1 : 0;
 }
 
 // Number of partial-statistics rows rvip_conv3x3_fwd_stats will write for this shape (0 = this shape is served by the
@@ -1747,7 +1845,7 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
     if (rc) return rc;
     const int rows = rvip_conv3x3_fwd_stats_rows(d);
     if (!stats_ws || rows <= 0) return RVIP_EUNSUPPORTED;
-    if (d->gdrop_rate != 0.f) return RVIP_EINVAL;     // (rvip_conv3x3_fwd_sums)
+    if (d->mask_bits || d->sign_bits) return RVIP_EINVAL;     // (rvip_conv3x3_fwd_sums / rvip_conv3x3_fwd)
     if (stats_ws_bytes < (size_t)rows * 2 * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
     bool used = false;
     hipStream_t s = (hipStream_t)stream;
@@ -1760,8 +1858,10 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
 extern "C" int rvip_conv3x3_fwd_sums_rows(const rvip_conv3x3_desc* d) {
     ConvArgs a;
     if (conv_args_from_desc(d, a) != RVIP_OK || d->subpix) return 0;
+    if (d->mask_bits) { a.mbits = d->mask_bits; a.mbits_c = d->mask_channels; a.mscale = d->mask_scale; }
     bool used = false; int rows = 0;
-    const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, nullptr, &rows, true, true, 2); });
+    static float dummy;                                   // dry run: only tells the dispatcher that partial rows are wanted
+    const int rc = by_dtype(d->dtype, [&](auto t) { return dispatch_igemm_ws<decltype(t), true>(a, nullptr, used, &dummy, &rows, true, true, 2); });
     return (rc == RVIP_OK && used) ? rows : 0;
 }
 
@@ -1774,10 +1874,10 @@ extern "C" int rvip_conv3x3_fwd_sums(const rvip_conv3x3_desc* d, float* sums_ws,
     if (!sums_ws || rows <= 0) return RVIP_EUNSUPPORTED;
     if (d->act != RVIP_ACT_NONE || d->bias) return RVIP_EINVAL;          // a data gradient: no bias, no activation
     if (sums_ws_bytes < (size_t)rows * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
-    if (d->gdrop_rate != 0.f) {                       // Dropout backward in the epilogue
-        if (d->gdrop_rate < 0.f || d->gdrop_rate >= 1.f || !d->gdrop_state || d->y1 || d->down2 || (d->cout & 7)) return RVIP_EINVAL;
-        a.gdrop = 1; a.g_inv_keep = 1.f / (1.f - d->gdrop_rate); a.g_thr = dropout_thr(d->gdrop_rate);
-        a.g_state = d->gdrop_state; a.g_layer = d->gdrop_layer_id;
+    if (d->sign_bits) return RVIP_EINVAL;
+    if (d->mask_bits) {                               // the result is gated element-wise by bit planes (Dropout / ReLU backward)
+        if (d->mask_channels <= 0 || (d->mask_channels % 32 && d->mask_channels != d->cout) || d->mask_channels > d->cout || d->down2 || !(d->mask_scale > 0.f)) return RVIP_EINVAL;
+        a.mbits = d->mask_bits; a.mbits_c = d->mask_channels; a.mscale = d->mask_scale;
     }
     bool used = false;
     hipStream_t s = (hipStream_t)stream;

@@ -163,7 +163,7 @@ static int launch_fold_k(const float* ws, int nblk, int width, int K, Post post,
 // Deferred folds, batched: dst[i] = sum over r of src[r * width + i] for a TABLE of reductions in one launch (blockIdx.y =
 // entry).  The bias gradients (bn_bwd_apply) and weight gradients (wgrad slabs) are only read by the optimiser, so their
 // ~40 single-purpose fold launches per step collapse into a few.  Fixed summation order per entry -> reproducible.
-struct FoldEntry { const float* src; float* dst; int nrows; int pad; long long width; };
+struct FoldEntry { const float* src; float* dst; int nrows; int stride; long long width; };      // stride: floats between rows (0 = width)
 
 // narrow rows (C floats), many rows: 1024 threads = 32 columns x 32 row groups, double accumulation
 __global__ __launch_bounds__(1024) void fold_batch_narrow(const FoldEntry* __restrict__ tab) {
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(1024) void fold_batch_narrow(const FoldEntry* __res
     if ((long long)blockIdx.x * 32 >= en.width) return;
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const long long col = (long long)blockIdx.x * 32 + c;
+    const size_t rstride = en.stride > 0 ? (size_t)en.stride : (size_t)en.width;
     double s = 0.0;
     if (col < en.width) {
         for (int b0 = g; b0 < en.nrows; b0 += 32 * 8) {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(1024) void fold_batch_narrow(const FoldEntry* __res
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int b = b0 + u * 32;
-                v[u] = b < en.nrows ? en.src[(size_t)b * en.width + col] : 0.f;
+                v[u] = b < en.nrows ? en.src[(size_t)b * rstride + col] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; u += 4) s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
@@ -309,6 +310,7 @@ __global__ void bn_infer_coeffs_kernel(const float* gamma, const float* beta, co
 struct ApplyArgs {
     const unsigned char* z; unsigned char* y; unsigned char* pooled;
     uint16_t* argmax;          // pooled + column-split kernel only: [windows][C / VE], 2 bits per channel = 2 * row + col of the first maximum
+    uint8_t* keep_bits;        // un-pooled kernel with dropout: bit planes [C/32][rows] of 32-bit words, bit (c & 31) = element kept (rvip_hip.h)
     const float* scale; const float* shift;
     int act; float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
     int n, h, w, c;
@@ -318,24 +320,28 @@ struct ApplyArgs {
 // configurations; -1 = read the descriptor.  With the descriptor's values the compiler keeps the `switch (act)` and the mode tests
 // inside the element loop (a chain of scalar compares and branches per value -- these kernels sit at the VALU / issue limit of an
 // HBM stream); the launchers pick a specialised instantiation for what the reference's default graph uses and the generic one otherwise.
+// returns the keep bits of the VE elements (bit e = kept; all ones without dropout)
 template <typename T, int VE, int ACT = -1, int DROP = -1>
-__device__ __forceinline__ void apply_xform(const ApplyArgs& a, size_t e0, const float (&sc)[VE], const float (&sh)[VE],
-                                            uint32_t key, float (&v)[VE]) {
+__device__ __forceinline__ unsigned apply_xform(const ApplyArgs& a, size_t e0, const float (&sc)[VE], const float (&sh)[VE],
+                                                uint32_t key, float (&v)[VE]) {
     const int act = ACT < 0 ? a.act : ACT;
     const bool drop = DROP < 0 ? a.drop != 0 : DROP > 0, has_mask = DROP < 0 ? a.mask != nullptr : DROP == 2;
+    unsigned kb = (1u << VE) - 1u;
 #pragma unroll
     for (int e = 0; e < VE; ++e) v[e] = act_fwd(fmaf(v[e], sc[e], sh[e]), act);
     if (drop) {
+        kb = 0;
         if (has_mask) {
 #pragma unroll
-            for (int e = 0; e < VE; ++e) v[e] = a.mask[e0 + e] ? v[e] * a.inv_keep : 0.f;
+            for (int e = 0; e < VE; ++e) { const bool k = a.mask[e0 + e] != 0; v[e] = k ? v[e] * a.inv_keep : 0.f; kb |= (k ? 1u : 0u) << e; }
         } else {
             bool keep[VE];
             dropout_keep<VE>(key, e0, a.thr, keep);
 #pragma unroll
-            for (int e = 0; e < VE; ++e) v[e] = keep[e] ? v[e] * a.inv_keep : 0.f;
+            for (int e = 0; e < VE; ++e) { v[e] = keep[e] ? v[e] * a.inv_keep : 0.f; kb |= (keep[e] ? 1u : 0u) << e; }
         }
     }
+    return kb;
 }
 
 // thread = (row slot, channel vector): the channel vector is fixed per thread, so scale/shift live in registers;
@@ -367,9 +373,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                if (!ok[u]) continue;
-                apply_xform<T, VE, ACT, DROP>(a, e0[u], sc, sh, key, v[u]);
-                Vec<T>::store(a.y + e0[u] * sizeof(T), v[u]);
+                // (no early `continue`: the lane exchange below needs every lane of the wave)
+                unsigned kb = 0;
+                if (ok[u]) {
+                    kb = apply_xform<T, VE, ACT, DROP>(a, e0[u], sc, sh, key, v[u]);
+                    Vec<T>::store(a.y + e0[u] * sizeof(T), v[u]);
+                }
+                if (a.keep_bits) {                          // wave-uniform: the Dropout backward of the consumer's data gradient reads these
+                    const long long r = (g + u * G) * rpi + prow;
+                    if constexpr (VE == 8) {                // a byte per thread: channels 8 cv .. 8 cv + 7 = byte (cv & 3) of plane cv / 4
+                        if (ok[u]) a.keep_bits[((size_t)(cv >> 2) * rows + r) * 4 + (cv & 3)] = (uint8_t)kb;
+                    } else {                                // VE = 4: two adjacent channel vectors (lanes cv, cv ^ 1) make a byte
+                        const unsigned other = (unsigned)__shfl_xor((int)kb, 1);
+                        if (ok[u] && !(cv & 1)) a.keep_bits[((size_t)(cv >> 3) * rows + r) * 4 + ((cv >> 1) & 3)] = (uint8_t)(kb | (other << 4));
+                    }
+                }
             }
         }
     } else {
@@ -1338,6 +1356,11 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     a.mask = d->mask; a.state = d->state; a.layer_id = d->layer_id; a.drop = drop;
     a.n = d->n; a.h = d->h; a.w = d->w; a.c = d->c;
     a.argmax = nullptr;
+    a.keep_bits = nullptr;
+    if (d->keep_bits) {
+        if (d->pooled || !drop || d->c % 8) return RVIP_EINVAL;
+        a.keep_bits = d->keep_bits;
+    }
     const int cg = d->c / ve;
     if (cg > 256) return RVIP_EINVAL;
     const int rpi = 256 / cg;

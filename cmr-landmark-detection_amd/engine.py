@@ -347,6 +347,21 @@ class Engine:
         self.fuse_head = bool(last.bn and not last.pool and not (last.drop and last.drop[1] > 0) and last.y == plan.head['src']
                               and cg_ <= 64 and (cg_ & (cg_ - 1)) == 0 and os.environ.get('RVIP_FUSE_HEAD', '1') != '0')
         last_apply = None
+        # who reads what: tensor name -> producing stage, stage -> [(consumer stage, 0 = as src0 / 1 = as the skip half)]
+        producer = {}
+        for st in plan.stages:
+            producer[st.y] = st
+            if st.pool:
+                producer[st.pooled] = st
+        consumers = {st.conv: [] for st in plan.stages}
+        for st in plan.stages:
+            for which, src in ((0, st.src0), (1, st.src1)):
+                if src and src in producer:
+                    consumers[producer[src].conv].append((st, which))
+        alg_on = os.environ.get('RVIP_BNBWD_ALGEBRAIC', '1') != '0'
+        upact_on = alg_on and os.environ.get('RVIP_FUSE_UPACT', '1') != '0'
+        self.sign_bits, self.keep_bits = {}, {}
+        apply_train = {}                        # stage -> its training-mode rvip_apply_desc (the backward plan may attach keep_bits)
         for st in plan.stages:
             rows = n * st.h * st.w
             z, y = self.act[st.z], self.act[st.y]
@@ -378,6 +393,18 @@ class Engine:
                     d.w_packed, d.subpix = P.subpix[st.conv].data_ptr(), 1
                 self._keep.append(d)
                 call = (L.rvip_conv3x3_fwd, (C.byref(d),))
+                # A stage without BatchNormalization (the up-conv: conv -> ReLU, KerasLayers.py:758) whose only reader is a conv: its
+                # ReLU backward can ride in that reader's data-gradient epilogue if the forward launch leaves the sign bits of what it
+                # stored (1/16 of the tensor).  The training launch gets them; whether they are used is decided with the backward plan.
+                if (upact_on and not st.bn and st.act_conv == 'relu' and not st.act_post and not st.pool and not (st.drop and st.drop[1] > 0)
+                        and st.cout % 8 == 0 and len(consumers[st.conv]) == 1 and consumers[st.conv][0][1] == 0 and consumers[st.conv][0][0].src1):
+                    dtr = N.Conv3x3Desc.from_buffer_copy(d)
+                    sb = torch.zeros(-(-st.cout // 32) * rows, dtype=torch.int32, device=self.ws.device)
+                    dtr.sign_bits = sb.data_ptr()
+                    if L.rvip_conv3x3_sign_bits_ok(C.byref(dtr)):
+                        self._keep.append(dtr)
+                        self.sign_bits[st.conv] = sb
+                        call_train = (L.rvip_conv3x3_fwd, (C.byref(dtr),))
             # ---- BN statistics / coefficients ----
             fused_rows = 0
             fuse_stats = st.bn and os.environ.get('RVIP_FUSE_STATS', '1') != '0'
@@ -396,7 +423,7 @@ class Engine:
                     P.mv(st.bn, 'moving_mean'), P.mv(st.bn, 'moving_variance'), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), unbiased,
                     self._bn(st, 'mean'), self._bn(st, 'invstd'), self._bn(st, 'scale'), self._bn(st, 'shift'))))
             else:
-                fwd_t.append(call)
+                fwd_t.append(call_train if st.conv in self.sign_bits else call)
             fwd_i.append(call)
             if st.bn:
                 if fused_rows <= 0:
@@ -427,6 +454,8 @@ class Engine:
                     if training and st.pool and st.conv in self.argmax:
                         a.argmax = self.argmax[st.conv].data_ptr()        # MaxPooling backward folds into the BN-backward passes
                     self._keep.append(a)
+                    if training:
+                        apply_train[st.conv] = a
                     if training and st is last and self.fuse_head:
                         last_apply = a                      # consumed by rvip_bn_apply_head below
                     elif not training and not (st.bn or st.act_post or st.drop or st.pool):
@@ -495,8 +524,10 @@ class Engine:
                 if not entries:
                     continue
                 tab = (N.FoldEntry * len(entries))()
-                for i, (src, dst, nrows, width) in enumerate(entries):
+                for i, ent in enumerate(entries):
+                    src, dst, nrows, width = ent[:4]
                     tab[i].src, tab[i].dst, tab[i].nrows, tab[i].width = src.data_ptr(), dst.value, nrows, width
+                    tab[i].stride = ent[4] if len(ent) > 4 else 0
                 tabd = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.ws.device)
                 self._fold_bufs.append(tabd)
                 bwd.label = 'deferred folds (%s, %d layers)' % ('weight gradients' if is_wide else 'bias gradients', len(entries))
@@ -542,17 +573,11 @@ class Engine:
         # epilogues, Dropout backward included) and  sum g*y = sum W * dW  of the consumers (read off their weight gradients while the
         # split-K slabs are folded).  The 2 x tensor re-read of rvip_bn_bwd_reduce disappears; a 32-channel block with an ill-conditioned
         # gamma / beta takes the exact route inside rvip_bn_bwd_coef itself.
-        alg_on = os.environ.get('RVIP_BNBWD_ALGEBRAIC', '1') != '0'
-        producer = {}
-        for st in plan.stages:
-            producer[st.y] = st
-            if st.pool:
-                producer[st.pooled] = st
-        consumers = {st.conv: [] for st in plan.stages}
-        for st in plan.stages:
-            for which, src in ((0, st.src0), (1, st.src1)):
-                if src and src in producer:
-                    consumers[producer[src].conv].append((st, which))
+        def gated_probe(c, channels):
+            """rows of the consumer's data gradient when its first `channels` result channels are gated by bit planes (0: not served)"""
+            probe = N.Conv3x3Desc.from_buffer_copy(dg_desc[c.conv])
+            probe.mask_bits, probe.mask_channels, probe.mask_scale = self.ws.data_ptr(), channels, 1.0
+            return L.rvip_conv3x3_fwd_sums_rows(C.byref(probe))
 
         def algebraic_ok(p):
             if not alg_on or not p.bn or p.act_post or (p is last and self.fuse_head):
@@ -566,7 +591,7 @@ class Engine:
                     return False
                 if L.rvip_conv3x3_fwd_sums_rows(C.byref(dg_desc[c.conv])) <= 0:
                     return False
-                if dropping and (c.cin % 8):
+                if dropping and (c.cin % 8 or gated_probe(c, c.cin) <= 0):      # Dropout backward: the keep bits gate the consumer's data gradient
                     return False
             return True
         self.algebraic = {p.conv for p in plan.stages if algebraic_ok(p)}
@@ -585,10 +610,29 @@ class Engine:
                     dbuf = torch.zeros(nd * c.cin, dtype=torch.float64, device=self.ws.device)
                     dot_rows[c.conv] = (dbuf, nd)
                     wg.w_master, wg.dot_rows, wg.dot_rows_bytes = P.p(c.conv, 'kernel').value, dbuf.data_ptr(), dbuf.numel() * 8
-                if p.drop and p.drop[1] > 0:          # Dropout backward rides in the consumer's data-gradient epilogue
-                    dg.gdrop_rate, dg.gdrop_state, dg.gdrop_layer_id = p.drop[1], state.value, p.drop[2]
-        for c in plan.stages:                   # a split result whose first half nobody sums (the up-conv has no BatchNormalization)
-            if c.conv in sums_rows and c.src1 and not (c.src0 in producer and producer[c.src0].conv in self.algebraic):
+                if p.drop and p.drop[1] > 0:          # Dropout backward rides in the consumer's data-gradient epilogue: the forward
+                    kb = torch.zeros(-(-p.cout // 32) * n * p.h * p.w, dtype=torch.int32, device=self.ws.device)      # pass leaves its keep bits
+                    self.keep_bits[p.conv] = kb
+                    apply_train[p.conv].keep_bits = kb.data_ptr()
+                    dg.mask_bits, dg.mask_channels, dg.mask_scale = kb.data_ptr(), p.cout, 1.0 / (1.0 - p.drop[1])
+        # ReLU backward of the BN-less stages whose forward launch left sign bits: gate the x0 half of the reader's data gradient, which
+        # then IS the stage's conv-output gradient (no rvip_bn_bwd_apply pass for the stage; its bias gradient = the column sums)
+        self.upact = {}
+        for u in plan.stages:
+            if u.conv not in self.sign_bits:
+                continue
+            c = consumers[u.conv][0][0]
+            if c.conv not in dg_desc or c.up0 or not c.src1 or c.c0 != u.cout or gated_probe(c, c.c0) <= 0:
+                continue
+            dg = dg_desc[c.conv]
+            if c.conv not in sums_rows:
+                nr = L.rvip_conv3x3_fwd_sums_rows(C.byref(dg))
+                sums_rows[c.conv] = (torch.zeros(nr * c.cin, dtype=torch.float32, device=self.ws.device), nr)
+            dg.mask_bits, dg.mask_channels, dg.mask_scale = self.sign_bits[u.conv].data_ptr(), c.c0, 1.0
+            dg.y = self.dz[u.z].data_ptr()
+            self.upact[u.conv] = c
+        for c in plan.stages:                   # a split result whose first half nobody sums (a BN-less up-conv whose ReLU backward is a pass of its own)
+            if c.conv in sums_rows and c.src1 and not (c.src0 in producer and (producer[c.src0].conv in self.algebraic or producer[c.src0].conv in self.upact)):
                 dg_desc[c.conv].sums_from = c.c0
         self._alg_bufs['sums'], self._alg_bufs['dots'] = sums_rows, dot_rows
         min_gamma = float(os.environ.get('RVIP_BNBWD_MIN_GAMMA', 1.0 / 64))
@@ -647,6 +691,17 @@ class Engine:
                 bwd.append((L.rvip_bn_bwd_reduce_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'], P.g(hd['conv'], 'kernel'),
                                                         P.g(hd['conv'], 'bias'))))
                 bwd.append((L.rvip_bn_bwd_apply_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'])))
+            elif st.conv in self.upact:              # dz was written, ReLU backward applied, by the reader's data gradient; bias gradient = its column sums
+                c = self.upact[st.conv]
+                sbuf_, nr = sums_rows[c.conv]
+                if defer:
+                    narrow[-1] = (sbuf_, P.g(st.conv, 'bias'), nr, st.cout, c.cin)
+                else:
+                    tab1 = (N.FoldEntry * 1)()
+                    tab1[0].src, tab1[0].dst, tab1[0].nrows, tab1[0].stride, tab1[0].width = sbuf_.data_ptr(), P.g(st.conv, 'bias').value, nr, c.cin, st.cout
+                    tabd1 = torch.frombuffer(bytearray(bytes(tab1)), dtype=torch.uint8).to(self.ws.device)
+                    self._fold_bufs.append(tabd1)
+                    bwd.append((L.rvip_fold_rows_batch, (_ptr(tabd1), 1, C.c_longlong(st.cout), 0)))
             else:
                 if alg:
                     cd = N.BnCoefDesc()

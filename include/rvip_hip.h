@@ -100,17 +100,26 @@ typedef struct rvip_conv3x3_desc {
     /* stream_in != 0: hint that this launch is the last reader of x0 for a while (e.g. the data gradient reading dz):
      * its input is fetched with the non-temporal cache policy. */
     int32_t      stream_in;
-    /* rvip_conv3x3_fwd_sums only (ABI 5): the result is the gradient reaching the OUTPUT of a Dropout layer (KerasLayers.py:718,772)
-     * and what is stored -- and summed -- is the gradient at its INPUT: keep ? g / (1 - gdrop_rate) : 0 with the keep bits of the
-     * counter stream (gdrop_state, gdrop_layer_id: the Dropout layer's id, element index = position in y).  The BN-backward apply
-     * pass of the producer stage then runs without dropout.  0 = none; not with y1 / down2. */
-    float        gdrop_rate; const uint32_t* gdrop_state; int32_t gdrop_layer_id;
+    /* Bit planes (ABI 5): one 32-bit word per pixel and 32-channel block, laid out [C/32][N*H*W], bit (c & 31) of word
+     * [c / 32][pixel] = channel c of that pixel.
+     * mask_bits (rvip_conv3x3_fwd_sums only): the first mask_channels (a multiple of 32) channels of the result are gated element-wise,
+     * v = bit ? v * mask_scale : 0, before they are stored and summed.  Two uses: the Dropout backward (KerasLayers.py:718,772) when
+     * the result is the gradient reaching a Dropout layer's output -- bits = the keep bits rvip_bn_apply wrote in the forward pass
+     * (rvip_apply_desc.keep_bits), scale = 1 / (1 - rate) -- and the ReLU backward of a stage without BatchNormalization (the
+     * up-conv, KerasLayers.py:758): bits = sign_bits of its forward launch, scale = 1; the stage then needs no rvip_bn_bwd_apply
+     * pass at all.  The loader waves stage the words of every pixel tile through LDS; not with down2.
+     * sign_bits (rvip_conv3x3_fwd only; Cout % 32 == 0, no y1 / down2): the launch also writes, per stored value, whether it is
+     * > 0, in that layout ([Cout/32][N*H*W]; H, W of the full-resolution result for subpix).  rvip_conv3x3_sign_bits_ok(d) tells
+     * whether the launch is served by a kernel that does (the register-staged fallback does not). */
+    const uint32_t* mask_bits; int32_t mask_channels; float mask_scale;
+    uint32_t*    sign_bits;
     /* rvip_conv3x3_fwd_sums only: the caller reads columns >= sums_from of the partial rows only (a multiple of 32; e.g. csplit when
      * the first half of a split result belongs to a stage without BatchNormalization); the columns below are unspecified. */
     int32_t      sums_from;
 } rvip_conv3x3_desc;
 
 int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
+int rvip_conv3x3_sign_bits_ok(const rvip_conv3x3_desc* d);
 
 /* The same convolution with the BatchNormalization statistics of its (stored) output fused into the epilogue:
  * writes rvip_conv3x3_fwd_stats_rows(d) partial rows [rows][2][cout] (per-channel sum, sum of squares) to stats_ws;
@@ -120,7 +129,7 @@ int rvip_conv3x3_fwd_stats_rows(const rvip_conv3x3_desc* d);
 int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_ws, size_t stats_ws_bytes, void* stream);
 /* ABI 5, for data-gradient launches: the convolution with the per-channel SUMS of its stored result as rvip_conv3x3_fwd_sums_rows(d)
  * partial rows [rows][cout] (of the fp32 values in front of the storage rounding) -- also with y1 (channel c of the virtual [y, y1] row is column c), with down2 (sums of the stored 2x2
- * block sums) and with gdrop_rate.  Added over the rows, column c is the `T1 = sum g` term of the BatchNormalization backward of
+ * block sums) and with mask_bits.  Added over the rows, column c is the `T1 = sum g` term of the BatchNormalization backward of
  * the stage that produced channel c of this launch's result tensor (rvip_bn_bwd_coef).  rows == 0: fallback kernel, no sums. */
 int rvip_conv3x3_fwd_sums_rows(const rvip_conv3x3_desc* d);
 int rvip_conv3x3_fwd_sums(const rvip_conv3x3_desc* d, float* sums_ws, size_t sums_ws_bytes, void* stream);
@@ -183,7 +192,7 @@ int    rvip_conv3x3_wgrad_dot_rows(const rvip_wgrad3x3_desc* d);
  * dst[i] = sum_r src[r*width + i], r < nrows, for `entries` records of a DEVICE table in ONE launch, fixed order.
  * wide = 0: rows of C floats (double accumulation; rvip_bn_bwd_apply with bias_rows); wide = 1: rows of 9*Cin*Cout
  * floats, width % 4 == 0, 16-byte aligned (rvip_conv3x3_wgrad with defer_fold).  max_width = max over the entries. */
-typedef struct rvip_fold_entry { const float* src; float* dst; int32_t nrows; int32_t reserved; long long width; } rvip_fold_entry;
+typedef struct rvip_fold_entry { const float* src; float* dst; int32_t nrows; int32_t stride; long long width; } rvip_fold_entry;   /* stride (narrow folds): floats between rows, 0 = width */
 int rvip_fold_rows_batch(const void* table, int entries, long long max_width, int wide, void* stream);
 
 /* First layer, Cin = 1 (bandwidth-bound, no MFMA): y = act(conv3x3(x[N,H,W,1]) + bias); weights are
@@ -258,6 +267,9 @@ typedef struct rvip_apply_desc {
      * (2*row + col) of the FIRST maximum of the 2x2 window of y, i.e. what rvip_maxpool2x2_bwd would find; lets the BN-backward
      * passes of the stage take (dpooled, argmax, skip gradient) instead of a materialised gradient */
     uint16_t*    argmax;
+    /* un-pooled pass with dropout, C % 8 == 0 (ABI 5): also write the keep bits as bit planes [ceil(C/32)][n*h*w] of 32-bit words
+     * (bit (c & 31) of word [c / 32][pixel] = element kept), for rvip_conv3x3_desc.mask_bits of the consumer's data gradient */
+    uint8_t*     keep_bits;
 } rvip_apply_desc;
 int rvip_bn_apply(const rvip_apply_desc* d, void* stream);
 int rvip_bn_apply_argmax_ok(int c, int dtype);

@@ -22,6 +22,22 @@ pytestmark = pytest.mark.gpu
 N = rvip._native
 
 
+def bit_planes(flags):
+    """bool [n, h, w, C] -> the bit-plane layout of include/rvip_hip.h: uint32 [ceil(C/32)][n*h*w], bit (c & 31) of word [c / 32][pixel]"""
+    c = flags.shape[-1]
+    f = flags.reshape(-1, c).astype(np.uint64)
+    out = np.zeros((-(-c // 32), f.shape[0]), np.uint64)
+    for ch in range(c):
+        out[ch // 32] |= f[:, ch] << np.uint64(ch % 32)
+    return out.astype(np.uint32)
+
+
+def planes_to_flags(words, shape):
+    n, h, w, c = shape
+    words = np.asarray(words, np.uint32).reshape(-(-c // 32), n * h * w)
+    return np.stack([(words[ch // 32] >> np.uint32(ch % 32)) & 1 for ch in range(c)], -1).reshape(shape).astype(bool)
+
+
 def _sums_launch(d, cols):
     L = N.lib()
     rows = L.rvip_conv3x3_fwd_sums_rows(C.byref(d))
@@ -63,15 +79,17 @@ def test_dgrad_epilogue_column_sums(shape, dtype, mode):
     N.call('rvip_conv3x3_fwd', C.byref(desc(ya, y1a)), stream())
     yb, y1b = out()
     d = desc(yb, y1b)
-    state = torch.zeros(8, dtype=torch.int32, device=dev())
-    state[N.STATE_SEED], state[N.STATE_STEP] = 99, 5
     rate, lid = 0.3, 4
-    if mode == 'dropout':
-        d.gdrop_rate, d.gdrop_state, d.gdrop_layer_id = rate, state.data_ptr(), lid
+    if mode == 'dropout':                       # gate every channel by the keep bits of a Dropout layer (what rvip_bn_apply leaves behind)
+        keep = ds.keep_mask((n, h, w, ci), rate, 99, 5, lid).astype(bool)
+        kbits = torch.from_numpy(bit_planes(keep).view(np.int32)).to(dev())
+        d.mask_bits, d.mask_channels, d.mask_scale = kbits.data_ptr(), ci, 1.0 / (1.0 - rate)
+    if mode == 'split':                         # ... or only the first half of a split result (the ReLU backward of a BN-less stage)
+        gate = rng.random((n, h, w, 32)) < 0.6
+        gbits = torch.from_numpy(bit_planes(gate).view(np.int32)).to(dev())
     rows = _sums_launch(d, ci)
     stored = down(yb) if y1b is None else np.concatenate([down(yb), down(y1b)], -1)
     if mode == 'dropout':
-        keep = ds.keep_mask((n, h, w, ci), rate, 99, 5, lid).astype(bool)
         rdx, _, _ = O.conv2d_same_bwd(np.zeros((n, h, w, ci)), wt.astype(np.float64), dy.astype(np.float64))
         close(stored, rdx * keep / np.float32(1 - rate), dtype, 'masked data gradient')
         assert not stored[~keep].any()                              # dropped positions are exact zeros
@@ -90,6 +108,16 @@ def test_dgrad_epilogue_column_sums(shape, dtype, mode):
         d2.sums_from = 32
         rows2 = _sums_launch(d2, ci)
         np.testing.assert_array_equal(rows2[:, 32:], rows[:, 32:])
+        # the first half gated by bit planes: stored = plain where the bit is set, exact zero elsewhere; the second half untouched
+        yd, y1d = out()
+        d3 = desc(yd, y1d)
+        d3.mask_bits, d3.mask_channels, d3.mask_scale = gbits.data_ptr(), 32, 1.0
+        rows3 = _sums_launch(d3, ci)
+        np.testing.assert_array_equal(down(yd), np.where(gate, down(ya), 0.0))
+        np.testing.assert_array_equal(down(y1d), down(y1a))
+        want3 = np.where(gate, down(ya).astype(np.float64), 0.0).reshape(-1, 32).sum(0)
+        assert np.abs(rows3[:, :32].sum(0) - want3).max() <= rel * np.abs(down(ya).astype(np.float64)).reshape(-1, 32).sum(0).max() + 1e-6
+        np.testing.assert_array_equal(rows3[:, 32:], rows[:, 32:])
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
@@ -169,7 +197,14 @@ def _bn_chain(dtype, rate, n=2, h=24, w=40, c=32, co=64, seed=3, gamma_scale=1.0
     a.scale, a.shift, a.act = k['scale'].data_ptr(), k['shift'].data_ptr(), 0
     a.drop_rate, a.mask, a.state, a.layer_id = rate, None, state.data_ptr(), k['lid']
     a.n, a.h, a.w, a.c, a.dtype = n, h, w, c, ndt(dtype)
+    if rate:
+        k['kbits'] = torch.full((-(-c // 32) * rows,), -1, dtype=torch.int32, device=dev())
+        a.keep_bits = k['kbits'].data_ptr()
     N.call('rvip_bn_apply', C.byref(a), stream())
+    if rate:                                    # the keep bits the forward pass leaves = the counter stream's mask
+        keep = ds.keep_mask((n, h, w, c), rate, 77, 3, k['lid']).astype(bool)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(planes_to_flags(k['kbits'].cpu().numpy().view(np.uint32), (n, h, w, c)), keep)
     k['y'] = y
     k['wd'] = pack(wt, dtype)[1]
     return k
@@ -227,7 +262,7 @@ def test_bn_bwd_coef_equals_the_reduction_pass(dtype, rate):
     g2 = torch.empty((n, h, w, c), dtype=T, device=dev())
     dst = conv_desc(k['dz2'], co, 0, None, 0, k['wd'], None, g2, None, 0, n, h, w, c, 0, dtype)
     if rate:
-        dst.gdrop_rate, dst.gdrop_state, dst.gdrop_layer_id = rate, k['state'].data_ptr(), k['lid']
+        dst.mask_bits, dst.mask_channels, dst.mask_scale = k['kbits'].data_ptr(), c, 1.0 / (1.0 - rate)
     nr = L.rvip_conv3x3_fwd_sums_rows(C.byref(dst))
     srows = torch.empty((nr, c), dtype=torch.float32, device=dev())
     N.call('rvip_conv3x3_fwd_sums', C.byref(dst), P(srows), C.c_size_t(srows.numel() * 4), stream())
@@ -293,3 +328,32 @@ def test_bn_bwd_coef_flags_small_gamma_and_refuses_bad_arguments():
     assert L.rvip_bn_bwd_coef(C.byref(cd), stream()) == -1
     cd.t1[0].stride, cd.fallback = c, None
     assert L.rvip_bn_bwd_coef(C.byref(cd), stream()) == -1
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(2, 24, 40, 32, 32, 0), (1, 16, 16, 16, 40, 0), (2, 40, 72, 64, 64, 0), (2, 24, 40, 16, 8, 2)])
+def test_forward_sign_bits(shape, dtype):
+    """rvip_conv3x3_fwd with sign_bits: the stored tensor is unchanged and bit (c & 31) of word [c / 32][pixel] says whether the stored
+    value is > 0 -- what the ReLU backward of the stage needs (plain 9-tap launches here, incl. the zero-stuffed Conv2DTranspose read;
+    the sub-pixel form is covered at the real up-conv shapes in test_gpu_real_shapes.py)."""
+    n, h, w, ci, co, up0 = shape
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()) % 1000)
+    hs, ws_ = (h // 2, w // 2) if up0 else (h, w)
+    x = rnd(rng.standard_normal((n, hs, ws_, ci)), dtype)
+    wt = rnd(rng.standard_normal((3, 3, ci, co)) * 0.2, dtype)
+    b = rng.standard_normal(co).astype(np.float32)
+    xd, bd = up(x, dtype), f32(b)
+    wf, _ = pack(wt, dtype)
+    ya = torch.empty((n, h, w, co), dtype=tdt(dtype), device=dev())
+    da = conv_desc(xd, ci, up0, None, 0, wf, bd, ya, None, 0, n, h, w, co, N.ACT['relu'], dtype)
+    N.call('rvip_conv3x3_fwd', C.byref(da), stream())
+    yb = torch.empty_like(ya)
+    db = conv_desc(xd, ci, up0, None, 0, wf, bd, yb, None, 0, n, h, w, co, N.ACT['relu'], dtype)
+    sb = torch.full((-(-co // 32) * n * h * w,), -1, dtype=torch.int32, device=dev())
+    db.sign_bits = sb.data_ptr()
+    assert N.lib().rvip_conv3x3_sign_bits_ok(C.byref(db)) == 1
+    N.call('rvip_conv3x3_fwd', C.byref(db), stream())
+    assert torch.equal(ya, yb)
+    flags = planes_to_flags(sb.cpu().numpy().view(np.uint32), (n, h, w, co))
+    np.testing.assert_array_equal(flags, down(yb) > 0)
+    assert 0.2 < flags.mean() < 0.8

@@ -175,6 +175,7 @@ def test_real_layer_shape_fwd_stats_dgrad_wgrad(idx, dtype):
 # the up-convs, the Conv2DTranspose decoder, the pooled stages with their window argmax, and config 5's Conv3D layers.
 # ------------------------------------------------------------------------------------------------------------------------------
 ds = __import__('importlib').import_module('cmr-landmark-detection_amd.dropout_stream')
+from test_gpu_bnbwd_algebraic import bit_planes, planes_to_flags      # noqa: E402
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
@@ -195,11 +196,14 @@ def test_real_layer_shape_column_sums_and_dot_rows(idx, dtype):
     rate, lid = 0.3, 2
     modes = ['split'] if c1 else (['down2'] if up0 else ['plain', 'dropout'])
     for mode in modes:
-        if mode == 'split':
+        if mode == 'split':                    # as the engine launches it: the up-conv half gated by that stage's sign bits (its ReLU backward)
             g0, g1 = torch.empty((n, h, w_, c0), dtype=T, device=dev()), torch.empty((n, h, w_, c1), dtype=T, device=dev())
             d2 = conv_desc(dyd, co, 0, None, 0, wd, None, g0, g1, c0, n, h, w_, ci, 0, dtype)
-            d2.sums_from = c0
-            want = k['dx']
+            gate = np.random.default_rng(77 + idx).random((n, h, w_, c0)) < 0.6
+            gbits = torch.from_numpy(bit_planes(gate).view(np.int32)).to(dev())
+            d2.mask_bits, d2.mask_channels, d2.mask_scale = gbits.data_ptr(), c0, 1.0
+            want = k['dx'].copy()
+            want[..., :c0] *= gate
         elif mode == 'down2':
             g0, g1 = torch.empty((n, h // 2, w_ // 2, c0), dtype=T, device=dev()), None
             d2 = conv_desc(dyd, co, 0, None, 0, wd, None, g0, None, 0, n, h, w_, ci, 0, dtype)
@@ -210,9 +214,10 @@ def test_real_layer_shape_column_sums_and_dot_rows(idx, dtype):
             d2 = conv_desc(dyd, co, 0, None, 0, wd, None, g0, None, 0, n, h, w_, ci, 0, dtype)
             want = k['dx']
             if mode == 'dropout':
-                d2.gdrop_rate, d2.gdrop_state, d2.gdrop_layer_id = rate, state.data_ptr(), lid
-                keep = ds.keep_mask((n, h, w_, ci), rate, 4242, 11, lid).astype(np.float64)
-                want = want * keep / np.float32(1 - rate)
+                keepb = ds.keep_mask((n, h, w_, ci), rate, 4242, 11, lid).astype(bool)
+                kbits = torch.from_numpy(bit_planes(keepb).view(np.int32)).to(dev())
+                d2.mask_bits, d2.mask_channels, d2.mask_scale = kbits.data_ptr(), ci, 1.0 / (1.0 - rate)
+                want = want * keepb / np.float32(1 - rate)
         rows = L.rvip_conv3x3_fwd_sums_rows(C.byref(d2))
         assert rows > 0, 'the real shapes must take the fused column-sum path'
         buf = torch.full((rows, ci), 7.0, dtype=torch.float32, device=dev())
@@ -221,7 +226,7 @@ def test_real_layer_shape_column_sums_and_dot_rows(idx, dtype):
         close(stored, want, dtype, '%s dgrad (%s)' % (name, mode))
         got = down(buf).astype(np.float64).sum(0)
         ref = want.reshape(-1, ci).sum(0)
-        lo = c0 if mode == 'split' else 0                                   # sums_from: the first half's columns are unspecified
+        lo = 0
         tol = 2e-5 * np.abs(want).reshape(-1, ci).sum(0).max()
         assert np.abs(got[lo:] - ref[lo:]).max() <= tol, (name, mode, np.abs(got[lo:] - ref[lo:]).max(), tol)
     # weight gradient with the dot rows
@@ -277,8 +282,12 @@ def test_real_shape_upconv_subpixel_form(idx, dtype):
     y = torch.full((n, h, h, co), 9.0, dtype=tdt(dtype), device=dev())
     d = conv_desc(lod, c0, 1, None, 0, wph, bd, y, None, 0, n, h, h, co, N.ACT['relu'], dtype)
     d.subpix = 1
+    sbits = torch.full((-(-co // 32) * n * h * h,), -1, dtype=torch.int32, device=dev())      # the training launch also leaves the sign bits
+    d.sign_bits = sbits.data_ptr()
+    assert N.lib().rvip_conv3x3_sign_bits_ok(C.byref(d)) == 1
     N.call('rvip_conv3x3_fwd', C.byref(d), stream())
     got = down(y)
+    np.testing.assert_array_equal(planes_to_flags(sbits.cpu().numpy().view(np.uint32), (n, h, h, co)), got > 0)
     scale = float(np.abs(k['fwd']).max())
     tol = (2.0 ** -6 if dtype != 'f32' else 2e-5) * scale                   # 16-bit: + one rounding of the summed taps
     assert np.abs(got - k['fwd']).max() <= tol, (name, np.abs(got - k['fwd']).max() / scale)
