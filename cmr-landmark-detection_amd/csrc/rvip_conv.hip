@@ -725,7 +725,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     float u[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-                                    gate4(u, (word >> (8 * q + 4 * hf)) & 15u, a.mscale);
+                                    gate4(u, (word >> (8 * (2 * (q & 1) + hf) + 4 * (q >> 1))) & 15u, a.mscale);      // channels 8q + 4hf + i: rvip_bit_of_channel
                                     v[4 * q] = u[0]; v[4 * q + 1] = u[1]; v[4 * q + 2] = u[2]; v[4 * q + 3] = u[3];
                                 }
                             }
@@ -763,7 +763,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
                             if (a.sbits) {                   // sign bits of what was stored: word = 32 channels of one pixel, plane = 32-channel block
                                 unsigned word = 0;
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) word |= (Vec<T>::round(v[r]) > 0.f ? 1u : 0u) << (8 * (r >> 2) + 4 * hf + (r & 3));
+                                for (int r = 0; r < 16; ++r) word |= (Vec<T>::round(v[r]) > 0.f ? 1u : 0u) << (8 * (2 * ((r >> 2) & 1) + hf) + 4 * (r >> 3) + (r & 3));
                                 word |= (unsigned)__shfl_xor((int)word, 32);
                                 const int cbase = co0 + ct * 32;
                                 const unsigned off = (pix_ok && !hf && cbase < a.cout) ? ((unsigned)(cbase / 32) * (unsigned)((TAPS == 4 ? 4 : 1) * a.n * a.h * a.w) + pix) * 4u : OOB;
@@ -1158,12 +1158,12 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { v[r] = actf(acc[cb][blk][r]); acc[cb][blk][r] = bias_r[cb][r]; }
                             if constexpr (STATS == 3) {      // Dropout / ReLU backward on the result: four bits of the pixel's mask word
-                                if (gated) gate4(v, (mword >> (16 * c2 + 4 * kq)) & 15u, a.mscale);
+                                if (gated) gate4(v, (mword >> (8 * kq + 4 * c2)) & 15u, a.mscale);
                             }
                             if constexpr (STATS == 0) {      // sign bits of what is stored (forward of a stage whose ReLU backward will be gated)
                                 if (a.sbits) {
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r) sword |= (Vec<T>::round(v[r]) > 0.f ? 1u : 0u) << (16 * c2 + 4 * kq + r);
+                                    for (int r = 0; r < 4; ++r) sword |= (Vec<T>::round(v[r]) > 0.f ? 1u : 0u) << (4 * c2 + r);
                                 }
                             }
                             if constexpr (STATS >= 2) {
@@ -1182,12 +1182,10 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                         }
                         store_cbpair(cp, pk[s2][0][0], pk[s2][0][1], pk[s2][1][0], pk[s2][1][1], pix, ok[s2]);
                         if constexpr (STATS == 0) {
-                            if (a.sbits) {                   // the four kq lanes of a pixel hold a byte each of its 32-channel word
-                                sword |= (unsigned)__shfl_xor((int)sword, 16);
-                                sword |= (unsigned)__shfl_xor((int)sword, 32);
+                            if (a.sbits) {                   // the four kq lanes of a pixel hold one byte each of its 32-channel word (rvip_bit_of_channel)
                                 const int cbase = co0 + cp * 32;
-                                const unsigned off = (ok[s2] && kq == 0 && cbase < a.cout) ? ((unsigned)(cbase / 32) * (unsigned)((TAPS == 4 ? 4 : 1) * a.n * a.h * a.w) + pix) * 4u : OOB;
-                                __builtin_amdgcn_raw_buffer_store_b32(sword, rsb, off, 0, 0);
+                                const unsigned off = (ok[s2] && cbase < a.cout) ? ((unsigned)(cbase / 32) * (unsigned)((TAPS == 4 ? 4 : 1) * a.n * a.h * a.w) + pix) * 4u + (unsigned)kq : OOB;
+                                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sword, rsb, off, 0, 0);
                             }
                         }
                     }

@@ -380,13 +380,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
                     Vec<T>::store(a.y + e0[u] * sizeof(T), v[u]);
                 }
                 if (a.keep_bits) {                          // wave-uniform: the Dropout backward of the consumer's data gradient reads these
+                    // word of a pixel and 32-channel block: channel c sits at bit 8 * ((c & 15) >> 2) + 4 * (c >> 4) + (c & 3)
+                    // (rvip_hip.h: the order in which the MFMA epilogue's lanes hold a pixel's channels).  Every thread places its
+                    // bits in a word; the threads of a block (adjacent lanes: cv = tid % cg) OR their words; the first one stores.
                     const long long r = (g + u * G) * rpi + prow;
-                    if constexpr (VE == 8) {                // a byte per thread: channels 8 cv .. 8 cv + 7 = byte (cv & 3) of plane cv / 4
-                        if (ok[u]) a.keep_bits[((size_t)(cv >> 2) * rows + r) * 4 + (cv & 3)] = (uint8_t)kb;
-                    } else {                                // VE = 4: two adjacent channel vectors (lanes cv, cv ^ 1) make a byte
-                        const unsigned other = (unsigned)__shfl_xor((int)kb, 1);
-                        if (ok[u] && !(cv & 1)) a.keep_bits[((size_t)(cv >> 3) * rows + r) * 4 + ((cv >> 1) & 3)] = (uint8_t)(kb | (other << 4));
+                    unsigned word = 0;
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        const int c = (cv * VE + e) & 31;
+                        word |= ((kb >> e) & 1u) << (8 * ((c & 15) >> 2) + 4 * (c >> 4) + (c & 3));
                     }
+                    constexpr int TPB = 32 / VE;            // threads per 32-channel block: 4 (16-bit types) or 8 (f32)
+#pragma unroll
+                    for (int o = 1; o < TPB; o <<= 1) { if (o < cg) word |= (unsigned)__shfl_xor((int)word, o); }      // (C = 8 / 16: a partial block)
+                    if (ok[u] && !(cv & (TPB - 1))) reinterpret_cast<uint32_t*>(a.keep_bits)[(size_t)(cv / TPB) * rows + r] = word;
                 }
             }
         }
@@ -1358,7 +1365,7 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     a.argmax = nullptr;
     a.keep_bits = nullptr;
     if (d->keep_bits) {
-        if (d->pooled || !drop || d->c % 8) return RVIP_EINVAL;
+        if (d->pooled || !drop || d->c % 8 || ((d->c % 32) && (32 % d->c)) || ((uintptr_t)d->keep_bits & 3)) return RVIP_EINVAL;      // whole 32-channel blocks, or one partial block of 8 / 16
         a.keep_bits = d->keep_bits;
     }
     const int cg = d->c / ve;

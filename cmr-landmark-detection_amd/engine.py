@@ -586,6 +586,8 @@ class Engine:
             dropping = bool(p.drop and p.drop[1] > 0)
             if not cl or len(cl) > 2 or (dropping and (p.drop[0] in self.masks or p.pool or len(cl) != 1)):
                 return False
+            if dropping and not (p.cout % 32 == 0 or p.cout in (8, 16)):      # keep bits: whole 32-channel blocks, or one partial block
+                return False
             for c, which in cl:
                 if c.conv not in dg_desc or c.up0 == 2 or (c.up0 == 1 and not fuse_down_on) or (dropping and (c.src1 or c.up0)):
                     return False

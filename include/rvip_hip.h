@@ -55,6 +55,7 @@ extern "C" {
 #define RVIP_STATE_SEED   2     /* dropout seed */
 #define RVIP_STATE_WORDS  8
 
+#define RVIP_BIT_OF_CHANNEL(c) (8 * (((c) & 15) >> 2) + 4 * (((c) & 31) >> 4) + ((c) & 3))      /* bit planes of rvip_conv3x3_desc / rvip_apply_desc */
 #define RVIP_ABI_VERSION 5   /* what rvip_abi_version() of a matching library returns; _native.py checks it at every load */
 int         rvip_abi_version(void);
 const char* rvip_build_info(void);          /* "gfx950 ..." */
@@ -100,8 +101,10 @@ typedef struct rvip_conv3x3_desc {
     /* stream_in != 0: hint that this launch is the last reader of x0 for a while (e.g. the data gradient reading dz):
      * its input is fetched with the non-temporal cache policy. */
     int32_t      stream_in;
-    /* Bit planes (ABI 5): one 32-bit word per pixel and 32-channel block, laid out [C/32][N*H*W], bit (c & 31) of word
-     * [c / 32][pixel] = channel c of that pixel.
+    /* Bit planes (ABI 5): one 32-bit word per pixel and 32-channel block, laid out [ceil(C/32)][N*H*W]; channel c of a pixel is bit
+     * RVIP_BIT_OF_CHANNEL(c) of word [c / 32][pixel] -- the order in which the four lanes of a pixel hold its channels in the MFMA
+     * epilogue (byte k of the word = channels 4k..4k+3 in its low and 16+4k..16+4k+3 in its high nibble), so that a lane writes and
+     * reads one byte / one nibble without a lane exchange.
      * mask_bits (rvip_conv3x3_fwd_sums only): the first mask_channels (a multiple of 32) channels of the result are gated element-wise,
      * v = bit ? v * mask_scale : 0, before they are stored and summed.  Two uses: the Dropout backward (KerasLayers.py:718,772) when
      * the result is the gradient reaching a Dropout layer's output -- bits = the keep bits rvip_bn_apply wrote in the forward pass
@@ -268,7 +271,7 @@ typedef struct rvip_apply_desc {
      * passes of the stage take (dpooled, argmax, skip gradient) instead of a materialised gradient */
     uint16_t*    argmax;
     /* un-pooled pass with dropout, C % 8 == 0 (ABI 5): also write the keep bits as bit planes [ceil(C/32)][n*h*w] of 32-bit words
-     * (bit (c & 31) of word [c / 32][pixel] = element kept), for rvip_conv3x3_desc.mask_bits of the consumer's data gradient */
+     * (bit RVIP_BIT_OF_CHANNEL(c) of word [c / 32][pixel] = element kept), for rvip_conv3x3_desc.mask_bits of the consumer's data gradient */
     uint8_t*     keep_bits;
 } rvip_apply_desc;
 int rvip_bn_apply(const rvip_apply_desc* d, void* stream);

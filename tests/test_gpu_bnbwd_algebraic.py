@@ -22,20 +22,25 @@ pytestmark = pytest.mark.gpu
 N = rvip._native
 
 
+def _bit(c):
+    """RVIP_BIT_OF_CHANNEL of include/rvip_hip.h"""
+    return 8 * ((c & 15) >> 2) + 4 * ((c & 31) >> 4) + (c & 3)
+
+
 def bit_planes(flags):
-    """bool [n, h, w, C] -> the bit-plane layout of include/rvip_hip.h: uint32 [ceil(C/32)][n*h*w], bit (c & 31) of word [c / 32][pixel]"""
+    """bool [n, h, w, C] -> the bit-plane layout of include/rvip_hip.h: uint32 [ceil(C/32)][n*h*w]"""
     c = flags.shape[-1]
     f = flags.reshape(-1, c).astype(np.uint64)
     out = np.zeros((-(-c // 32), f.shape[0]), np.uint64)
     for ch in range(c):
-        out[ch // 32] |= f[:, ch] << np.uint64(ch % 32)
+        out[ch // 32] |= f[:, ch] << np.uint64(_bit(ch))
     return out.astype(np.uint32)
 
 
 def planes_to_flags(words, shape):
     n, h, w, c = shape
     words = np.asarray(words, np.uint32).reshape(-(-c // 32), n * h * w)
-    return np.stack([(words[ch // 32] >> np.uint32(ch % 32)) & 1 for ch in range(c)], -1).reshape(shape).astype(bool)
+    return np.stack([(words[ch // 32] >> np.uint32(_bit(ch))) & 1 for ch in range(c)], -1).reshape(shape).astype(bool)
 
 
 def _sums_launch(d, cols):
