@@ -294,10 +294,17 @@ struct ConvArgs2 {
     int sums_from;                           // STATS >= 2: columns below this channel are not needed (left unwritten or partial)
 };
 
-// Gate four consecutive channels of one pixel by four bits of a mask word (STATS == 3): v = bit ? v * scale : 0
+// Gate four consecutive channels of one pixel by four bits of a mask word (STATS == 3): v = bit ? v * scale : 0.  The bit is
+// sign-extended to a word (v_bfe_i32) and ANDed onto the value: two instructions per value, plus the multiply when scale != 1
+// (Dropout backward; the ReLU gate has scale 1 -- wave-uniform).
 __device__ __forceinline__ void gate4(float (&v)[4], unsigned nib, float scale) {
+    const bool scaled = scale != 1.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? v[r] * scale : 0.f;
+    for (int r = 0; r < 4; ++r) {
+        const int m = __builtin_amdgcn_sbfe((int)nib, r, 1);              // 0 or -1
+        const float g = __builtin_bit_cast(float, __builtin_bit_cast(int, v[r]) & m);
+        v[r] = scaled ? g * scale : g;
+    }
 }
 
 // Epilogue of the data gradient of an UpSampling2D -> conv pair (KerasLayers.py:756-758): the gradient w.r.t. the
