@@ -443,6 +443,42 @@ def test_bf16_path_at_the_real_channel_widths_matches_bf16_storage_emulation():
         assert rel < 0.8 * rel_x + 0.03 and rel < 0.9 * rel_ex + 0.03, (lname, rel, rel_x, rel_ex)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_backward_routes_agree(precision, monkeypatch):
+    """One training step's gradients through the three backward schedules the engine can build: the default (BN backward from the
+    consumers' by-products, Dropout / up-conv ReLU backward as bit-plane gates), the same with every channel block forced down the
+    exact in-kernel route of rvip_bn_bwd_coef (RVIP_BNBWD_MIN_GAMMA huge), and round 2's schedule (RVIP_BNBWD_ALGEBRAIC=0: reduction
+    pass, separate apply pass for the up-convs).  Same weights, same batch, same dropout stream: fp32 agrees to summation order,
+    bf16 to its storage rounding."""
+    cfg = _cfg(RVIP_PRECISION=precision, FILTERS=32, DEPTH=3, DIM=[64, 64])
+    x, y = O.synthetic_batch(4, cfg['DIM'], 2, seed=12)
+    got = {}
+    for route, env in (('default', {}), ('exact', {'RVIP_BNBWD_MIN_GAMMA': '1e9'}), ('round2', {'RVIP_BNBWD_ALGEBRAIC': '0'})):
+        for k in ('RVIP_BNBWD_MIN_GAMMA', 'RVIP_BNBWD_ALGEBRAIC'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = rvip.get_model(cfg, metrics=[])
+        eng = model._engine(4)
+        assert bool(eng.algebraic) == (route != 'round2') and bool(eng.upact) == (route != 'round2')
+        eng.load_input(x, y)
+        eng.forward(training=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        flags = [int(f.sum().item()) for f in eng.bn_flags.values()]
+        assert (all(flags) if route == 'exact' else not any(flags)), (route, flags)
+        got[route] = (float(eng.loss.item()), model._params.grads_host())
+    assert got['default'][0] == got['exact'][0] == got['round2'][0]                 # the forward pass is the same launch list
+    tol = 2e-4 if precision == 'fp32' else 0.06
+    for other in ('exact', 'round2'):
+        for k, g in got['default'][1].items():
+            ref = got[other][1][k]
+            scale = float(np.abs(ref).max())
+            if scale < 1e-12:
+                continue
+            assert np.abs(g - ref).max() <= tol * scale + 1e-9, (precision, other, k, float(np.abs(g - ref).max()), scale)
+
+
 def test_full_size_step_is_deterministic_and_finite():
     """BASELINE.json configs[1] shape (256x256, F=32, depth 4, batch 32, bf16): size-independent properties --
     two identical steps from identical state give bit-identical loss, heat-maps and gradients; a further step
