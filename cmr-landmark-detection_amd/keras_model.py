@@ -528,55 +528,69 @@ class Model:
         self.stop_training = False
         cbs.on_train_begin()
         names = self.metrics_names
-        for epoch in range(initial_epoch, epochs):
-            if self.stop_training:
-                break
-            cbs.on_epoch_begin(epoch)
-            t0 = time.time()
-            steps = len(gen) if steps_per_epoch is None else min(steps_per_epoch, len(gen))
-            order = np.arange(len(gen))
-            if shuffle:                                        # Keras shuffles the batch order of a Sequence; seeded: identical on every rank
-                order = np.random.default_rng([self.seed, epoch]).permutation(len(gen))
-            hist = eng = None
-            counts = []                                        # loss elements of every step's OWN batch (a Sequence may end on a smaller one)
-            for step, (eng, slot) in enumerate(self._staged_batches(gen, order[:steps], max_queue_size, workers)):
-                if hist is None:
-                    hist = torch.zeros((steps, eng.sums.numel()), dtype=torch.float32, device=eng.sums.device)
-                if slot is not None:
-                    eng.feed(slot)
-                eng.train_step()
-                hist[step].copy_(eng.sums, non_blocking=True)
-                counts.append(self._loss_count(eng, kind, world))
-                self.optimizer.iterations += 1
-                cbs.on_train_batch_end(step)
-            logs = OrderedDict()
-            if hist is not None:
-                if world > 1:
-                    import torch.distributed as dist
-                    dist.all_reduce(hist)
-                vals = self._values_from_sums(hist.cpu().numpy().astype(np.float64)[:len(counts)], np.asarray(counts, np.float64), kind, w_bce, w_dice)
-                for k, val in zip(names, vals.mean(0).tolist()):
-                    logs[k] = val
-            if validation_data is not None:
-                if isinstance(validation_data, (tuple, list)):
-                    v = self.evaluate(validation_data[0], validation_data[1])
-                else:
-                    v = self.evaluate(validation_data)
-                for k, val in zip(names, v):
-                    logs['val_' + k] = val
-            cbs.on_epoch_end(epoch, logs)
-            if hasattr(gen, 'on_epoch_end'):
-                gen.on_epoch_end()
-            if verbose and rank == 0:
-                dt = time.time() - t0
-                print('Epoch %d/%d - %.1fs - %.0fms/step - %s' % (
-                    epoch + 1, epochs, dt, 1e3 * dt / max(steps, 1), ' - '.join('%s: %.4f' % kv for kv in logs.items())))
+
+        def epoch_orders():
+            """per epoch: the batch order (Keras shuffles the batch order of a Sequence; seeded: identical on every rank), evaluated when the
+            stager gets there (len(gen) may change in on_epoch_end)"""
+            for ep in range(initial_epoch, epochs):
+                steps = len(gen) if steps_per_epoch is None else min(steps_per_epoch, len(gen))
+                order = np.arange(len(gen))
+                if shuffle:
+                    order = np.random.default_rng([self.seed, ep]).permutation(len(gen))
+                yield order[:steps]
+        staged = self._staged_batches(gen, epoch_orders(), max_queue_size, workers)
+        try:
+            for epoch in range(initial_epoch, epochs):
+                if self.stop_training:
+                    break
+                cbs.on_epoch_begin(epoch)
+                t0 = time.time()
+                steps = len(gen) if steps_per_epoch is None else min(steps_per_epoch, len(gen))
+                hist = eng = None
+                counts = []                                        # loss elements of every step's OWN batch (a Sequence may end on a smaller one)
+                for step, (eng, slot) in enumerate(staged.epoch()):
+                    if hist is None:
+                        hist = torch.zeros((steps, eng.sums.numel()), dtype=torch.float32, device=eng.sums.device)
+                    if slot is not None:
+                        eng.feed(slot)
+                    eng.train_step()
+                    hist[step].copy_(eng.sums, non_blocking=True)
+                    counts.append(self._loss_count(eng, kind, world))
+                    self.optimizer.iterations += 1
+                    cbs.on_train_batch_end(step)
+                logs = OrderedDict()
+                if hist is not None:
+                    if world > 1:
+                        import torch.distributed as dist
+                        dist.all_reduce(hist)
+                    vals = self._values_from_sums(hist.cpu().numpy().astype(np.float64)[:len(counts)], np.asarray(counts, np.float64), kind, w_bce, w_dice)
+                    for k, val in zip(names, vals.mean(0).tolist()):
+                        logs[k] = val
+                if validation_data is not None:
+                    if isinstance(validation_data, (tuple, list)):
+                        v = self.evaluate(validation_data[0], validation_data[1])
+                    else:
+                        v = self.evaluate(validation_data)
+                    for k, val in zip(names, v):
+                        logs['val_' + k] = val
+                cbs.on_epoch_end(epoch, logs)
+                if verbose and rank == 0:
+                    dt = time.time() - t0
+                    print('Epoch %d/%d - %.1fs - %.0fms/step - %s' % (
+                        epoch + 1, epochs, dt, 1e3 * dt / max(steps, 1), ' - '.join('%s: %.4f' % kv for kv in logs.items())))
+        finally:                                               # also when a callback stopped the training or raised: drop what was prefetched
+            staged.close()
         cbs.on_train_end()
         torch.cuda.synchronize()
         return self.history
 
-    def _staged_batches(self, gen, order, depth, workers):
-        """Yields (engine, pinned slot | None) per batch of `order`.  A stager thread takes the generator's batches in order
+    def _staged_batches(self, gen, orders, depth, workers):
+        """Starts the stager thread and returns an object whose epoch() iterates (engine, pinned slot | None) over the batches of the
+        next entry of `orders` (an iterable of per-epoch batch orders, evaluated lazily in the stager thread) and which must be
+        close()d.  Between two epochs the stager calls the generator's on_epoch_end() -- as soon as the epoch's last batch has been
+        PRODUCED, as Keras' OrderedEnqueuer does from its own thread (workers >= 1: the reference's fit call) -- and goes on with the
+        next epoch's batches while the training thread still consumes the queue and reads out the epoch.  The
+        stager thread takes the generator's batches in order
         (produced by `workers` threads when > 1), shards them by rank and copies them into the engine's pinned ring; the very
         first batch of a batch size is loaded directly (it creates the engine and its ring)."""
         depth = max(int(depth), 1)
@@ -616,21 +630,24 @@ class Model:
             try:
                 import torch
                 torch.cuda.set_device(dev)
-                for xb, yb in _prefetch(fetch, order, depth, workers, cancel):
-                    if not local:
-                        xb, yb = self._shard(xb, yb)
-                    eng = ring.get(xb.shape[0])
-                    if eng is None or eng.ring_slots() < slots:
-                        ready.clear()
-                        put(('raw', xb, yb))
-                        while not ready.wait(0.1):             # the training thread builds the engine for this batch size
-                            if cancel.is_set():
-                                raise _Cancelled()
-                        continue
-                    slot = eng.next_slot()
-                    eng.stage_host_batch(slot, xb, yb)
-                    put(('pin', eng, slot))
-                put(stop)
+                for order in orders:
+                    for xb, yb in _prefetch(fetch, order, depth, workers, cancel):
+                        if not local:
+                            xb, yb = self._shard(xb, yb)
+                        eng = ring.get(xb.shape[0])
+                        if eng is None or eng.ring_slots() < slots:
+                            ready.clear()
+                            put(('raw', xb, yb))
+                            while not ready.wait(0.1):         # the training thread builds the engine for this batch size
+                                if cancel.is_set():
+                                    raise _Cancelled()
+                            continue
+                        slot = eng.next_slot()
+                        eng.stage_host_batch(slot, xb, yb)
+                        put(('pin', eng, slot))
+                    put(stop)                                  # end of this epoch's batches
+                    if hasattr(gen, 'on_epoch_end'):
+                        gen.on_epoch_end()
             except _Cancelled:
                 pass
             except BaseException as e:                         # surface generator errors in the training thread
@@ -641,34 +658,40 @@ class Model:
                     pass
 
         th = threading.Thread(target=work, daemon=True)
-        th.start()
-        try:
-            while True:
-                item = q.get()
-                if item is stop:
-                    break
-                if isinstance(item, BaseException):
-                    raise item
-                if item[0] == 'raw':
-                    _, xb, yb = item
-                    eng = self._engine(xb.shape[0])
-                    eng.alloc_input_ring(slots)
-                    eng.load_input(xb, yb)
-                    if eng.ring_slots() >= slots:
-                        ring[xb.shape[0]] = eng
-                    ready.set()
-                    yield eng, None
-                else:
-                    yield item[1], item[2]
-        finally:                                               # also on an exception / generator close in the training thread:
-            cancel.set()                                       # the stager must not keep pinned slots and the thread pool
-            ready.set()
-            while th.is_alive():
-                try:
-                    q.get_nowait()
-                except queue.Empty:
-                    pass
-                th.join(0.05)
+        th.start()                                             # (now: fit() starts the next epoch's stager before it turns to this epoch's logs)
+        model = self
+
+        class _Staged:
+            def close(self_):                                  # also on an exception / an early stop in the training thread:
+                cancel.set()                                   # the stager must not keep pinned slots and the thread pool
+                ready.set()
+                while th.is_alive():
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        pass
+                    th.join(0.05)
+
+            def epoch(self_):
+                """the batches of the next epoch (up to the stager's end-of-epoch mark)"""
+                while True:
+                    item = q.get()
+                    if item is stop:
+                        return
+                    if isinstance(item, BaseException):
+                        raise item
+                    if item[0] == 'raw':
+                        _, xb, yb = item
+                        eng = model._engine(xb.shape[0])
+                        eng.alloc_input_ring(slots)
+                        eng.load_input(xb, yb)
+                        if eng.ring_slots() >= slots:
+                            ring[xb.shape[0]] = eng
+                        ready.set()
+                        yield eng, None
+                    else:
+                        yield item[1], item[2]
+        return _Staged()
 
     def history_callback(self):
         from .KerasCallbacks import Callback
