@@ -144,6 +144,22 @@ def test_struct_layouts_match_header(tmp_path):
             assert got[(cname, f)] == getattr(cls, f).offset, (cname, f)
 
 
+def test_bit_plane_order_of_the_header(tmp_path):
+    """RVIP_BIT_OF_CHANNEL (the bit-plane layout rvip_bn_apply / rvip_conv3x3_fwd write and rvip_conv3x3_fwd_sums reads) is a permutation of
+    the 32 bits of a word, byte k = channels 4k..4k+3 (low nibble) and 16+4k..16+4k+3 (high nibble), and it is what the GPU tests' host
+    helper uses."""
+    import subprocess
+    src = tmp_path / 'bits.c'
+    src.write_text('#include <stdio.h>\n#include "rvip_hip.h"\nint main(void){for(int c=0;c<64;++c)printf("%d\\n",RVIP_BIT_OF_CHANNEL(c));return 0;}\n')
+    exe = str(tmp_path / 'bits')
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', exe])
+    got = [int(v) for v in subprocess.check_output([exe]).decode().split()]
+    want = [8 * ((c & 15) >> 2) + 4 * ((c & 31) >> 4) + (c & 3) for c in range(64)]
+    assert got == want and sorted(got[:32]) == list(range(32)) and got[32:] == got[:32]
+    for k in range(4):
+        assert sorted(got[4 * k:4 * k + 4]) == [8 * k + i for i in range(4)] and sorted(got[16 + 4 * k:20 + 4 * k]) == [8 * k + 4 + i for i in range(4)]
+
+
 def test_weights_roundtrip_and_order(tmp_path):
     m = rvip.create_unet(_cfg())
     w = m.get_weights()
