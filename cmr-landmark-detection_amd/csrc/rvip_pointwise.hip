@@ -384,15 +384,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
                     // (rvip_hip.h: the order in which the MFMA epilogue's lanes hold a pixel's channels).  Every thread places its
                     // bits in a word; the threads of a block (adjacent lanes: cv = tid % cg) OR their words; the first one stores.
                     const long long r = (g + u * G) * rpi + prow;
-                    unsigned word = 0;
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) {
-                        const int c = (cv * VE + e) & 31;
-                        word |= ((kb >> e) & 1u) << (8 * ((c & 15) >> 2) + 4 * (c >> 4) + (c & 3));
-                    }
                     constexpr int TPB = 32 / VE;            // threads per 32-channel block: 4 (16-bit types) or 8 (f32)
-#pragma unroll
-                    for (int o = 1; o < TPB; o <<= 1) { if (o < cg) word |= (unsigned)__shfl_xor((int)word, o); }      // (C = 8 / 16: a partial block)
+                    const int m = cv & (TPB - 1);           // this thread's channels are VE * m .. VE * m + VE - 1 of the block
+                    unsigned word;                          // (two shifts instead of a loop over the bits: RVIP_BIT_OF_CHANNEL is nibble-wise)
+                    if constexpr (VE == 8) word = ((kb & 15u) | ((kb >> 4) << 8)) << (16 * (m & 1) + 4 * (m >> 1));
+                    else word = kb << (8 * (m & 3) + 4 * (m >> 2));
+                    if (cg > 1) word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xB1, 0xF, 0xF, true);      // lane ^ 1 (quad permute)
+                    if (cg > 2) word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x4E, 0xF, 0xF, true);      // lane ^ 2
+                    if constexpr (TPB == 8) { if (cg > 4) word |= (unsigned)__shfl_xor((int)word, 4); }               // (C = 8 / 16: a partial block)
                     if (ok[u] && !(cv & (TPB - 1))) reinterpret_cast<uint32_t*>(a.keep_bits)[(size_t)(cv / TPB) * rows + r] = word;
                 }
             }
