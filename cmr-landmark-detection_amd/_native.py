@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RVIP_LIB') or os.path.join(_HERE, 'librvip_hip.so')     # RVIP_LIB: A/B another build of the same ABI
 
-EXPECTED_ABI = 5          # RVIP_ABI_VERSION of include/rvip_hip.h (tests/test_host_cpu.py holds the two together)
+EXPECTED_ABI = 6          # RVIP_ABI_VERSION of include/rvip_hip.h (tests/test_host_cpu.py holds the two together)
 F32, BF16, F16 = 0, 1, 2
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'elu': 2, 'sigmoid': 3}
 LOSS_MSE, LOSS_BCE_DICE = 0, 1
@@ -92,6 +92,14 @@ class BnCoefDesc(C.Structure):
                 ('min_gamma', C.c_float), ('max_beta_ratio', C.c_float)]
 
 
+class HeadCoefDesc(C.Structure):
+    _fields_ = [('bn', C.POINTER(BnBwdDesc)), ('beta', vp),
+                ('head_w', vp), ('dlogit', vp), ('k', C.c_int32), ('nrows', C.c_int32),
+                ('mse_rows', vp), ('head_dw', vp), ('head_db', vp),
+                ('sums', vp), ('loss_out', vp), ('inv_count', C.c_float),
+                ('flags', vp), ('min_gamma', C.c_float), ('max_beta_ratio', C.c_float)]
+
+
 class FoldEntry(C.Structure):
     _fields_ = [('src', vp), ('dst', vp), ('nrows', C.c_int32), ('stride', C.c_int32), ('width', C.c_longlong)]
 
@@ -142,6 +150,10 @@ SIGNATURES = {
     'rvip_upsample2x_bwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_head_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'rvip_bn_apply_head': (C.c_int, [C.POINTER(ApplyDesc), vp, vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp]),
+    'rvip_bn_apply_head_mse_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_int]),
+    'rvip_bn_apply_head_mse': (C.c_int, [C.POINTER(ApplyDesc), vp, vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float,
+                                         vp, C.c_size_t, vp, C.c_size_t, vp]),
+    'rvip_head_mse_coef': (C.c_int, [C.POINTER(HeadCoefDesc), vp]),
     'rvip_bn_bwd_reduce_head': (C.c_int, [C.POINTER(BnBwdDesc), vp, vp, C.c_int, vp, vp, vp]),
     'rvip_bn_bwd_apply_head': (C.c_int, [C.POINTER(BnBwdDesc), vp, vp, C.c_int, vp]),
     'rvip_head_grad': (C.c_int, [vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]),

@@ -933,9 +933,12 @@ struct HeadFuse { const float* w; const float* b; const float* dlogit; int k; };
 
 // KK = class capacity of the instantiation (2 for the reference's two heat-maps): half the shuffles and logit registers of the
 // MAXK-sized form; the target values of the round are loaded with its z rows, not after the arithmetic that depends on them.
-template <typename T, int KK, int SPEC = 0>
+// MSE = 1 (include/rvip_hip.h: rvip_bn_apply_head_mse): the MSE logit gradient d = 2 (p - t) inv_count p (1 - p) [* dscale] is
+// written here, and S_kk[c] = sum y[c] * d[kk], Q_kk = sum d[kk] are accumulated while y is in registers -> mse.rows[block][KK + 1][C].
+struct HeadMse { float* dlogit; float* rows; float inv_count, dscale; };
+template <typename T, int KK, int SPEC = 0, int MSE = 0>
 __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFuse hd, float* __restrict__ pred, const float* __restrict__ yt,
-                                                            long long rows, long long chunk, int reduce, float* __restrict__ ws) {
+                                                            long long rows, long long chunk, int reduce, float* __restrict__ ws, HeadMse mse) {
     constexpr int VE = Vec<T>::VE, U = 2;
     __shared__ float red[4][16];
     const int tid = threadIdx.x, k = hd.k;
@@ -953,6 +956,12 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
     float s[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) s[i] = 0.f;
+    static_assert(!MSE || KK <= VE, "the Q row holds one column per class");
+    float hp[MSE ? KK + 1 : 1][VE];
+#pragma unroll
+    for (int q = 0; q < (MSE ? KK + 1 : 1); ++q)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) hp[q][e] = 0.f;
     for (long long rb = r0 + prow; rb < r1; rb += (long long)U * rpi) {
         float v[U][VE], tv[U];
 #pragma unroll
@@ -968,14 +977,19 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long r = rb + (long long)u * rpi;
-            float lg[KK];
+            float lg[KK], yv[MSE ? VE : 1], dl[MSE ? KK : 1];
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) lg[kk] = 0.f;
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
                 const float y = Vec<T>::round(act_fwd(fmaf(v[u][e], sc[e], sh[e]), SPEC ? RVIP_ACT_NONE : a.act));   // what rvip_bn_apply would have stored
+                if constexpr (MSE) yv[e] = y;
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) lg[kk] = fmaf(y, wr[e][kk], lg[kk]);
+            }
+            if constexpr (MSE) {
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) dl[kk] = 0.f;
             }
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
@@ -987,8 +1001,8 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
                 }
                 lg[kk] += bias[kk];
             }
-            if (r >= r1) continue;
-            for (int kk = cgi; kk < k; kk += cg) {
+            if (!MSE && r >= r1) continue;
+            for (int kk = cgi; kk < k && r < r1; kk += cg) {
                 float zl = lg[0];
 #pragma unroll
                 for (int q = 1; q < KK; ++q) zl = (kk == q) ? lg[q] : zl;
@@ -999,6 +1013,13 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
                 if (yt) {
                     const float t = kk == cgi ? tv[u] : yt[(size_t)r * k + kk];
                     const float d = pv - t;
+                    if constexpr (MSE) {
+                        float dd = 2.f * (pv - t) * mse.inv_count * pv * (1.f - pv);          // rvip_head_grad's expression, then rvip_scale_f32's
+                        if (mse.dscale != 1.f) dd *= mse.dscale;
+                        mse.dlogit[(size_t)r * k + kk] = dd;
+#pragma unroll
+                        for (int q = 0; q < KK; ++q) dl[q] = (kk == q) ? dd : dl[q];
+                    }
                     s[0] = fmaf(d, d, s[0]);
                     if (kk >= k - 3) {
                         s[1] += fmaxf(zl, 0.f) - zl * t + __logf(1.f + e_);
@@ -1008,7 +1029,26 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
                     if (kk == k - 1) { s[8] = fmaf(t, pv, s[8]); s[9] += t; s[10] += pv; }
                 }
             }
+            if constexpr (MSE) {
+                // every class was finished by exactly one lane of the pixel: a sum over its cg lanes hands d[.] to all of them
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    if (cg == 4) {
+                        dl[kk] += lane_xor2_dpp(dl[kk]);
+                        dl[kk] += lane_xor1_dpp(dl[kk]);
+                    } else {
+                        for (int o = cg >> 1; o > 0; o >>= 1) dl[kk] += __shfl_xor(dl[kk], o);
+                    }
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) hp[kk][e] = fmaf(yv[e], dl[kk], hp[kk][e]);
+                    if (cgi == 0) hp[KK][kk] += dl[kk];
+                }
+            }
         }
+    }
+    if constexpr (MSE) {
+        __shared__ float fold_lds[256 * VE];
+        block_fold<KK + 1, VE>(hp, true, tid, a.c, rpi, fold_lds, mse.rows + (size_t)blockIdx.x * (KK + 1) * a.c);
     }
     if (!reduce) return;
 #pragma unroll
@@ -1484,7 +1524,8 @@ struct CoefArgs {
     double n; int c; float min_gamma, max_beta_ratio;
     BnBwdArgs fb;                                  // the stage's classic descriptor: the exact route of an ill-conditioned block
 };
-__device__ __forceinline__ void coef_store(const CoefArgs& a, int ch, double t1, double tx) {
+template <typename A>
+__device__ __forceinline__ void coef_store(const A& a, int ch, double t1, double tx) {
     a.dbeta[ch] = (float)t1;
     a.dgamma[ch] = (float)tx;
     const float gm = a.gamma[ch], is = a.invstd[ch], mu = a.mean[ch];
@@ -1579,6 +1620,143 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(CoefArgs a) {
             gy_issue<T, VE, -1, false>(f, rr, cgi, cg, e0, raw);
             gy_finish<T, VE, -1>(f, raw, gv);
             xform_g<T, VE>(f, e0, cgi * VE, key, z, gv);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { part[0][e] += gv[e]; part[1][e] = fmaf(gv[e], (z[e] - mu[e]) * is[e], part[1][e]); }
+        }
+    }
+    double tot[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VE; ++e) part_lds[slot][cv * VE + e] = part[k][e];
+        __syncthreads();
+        double acc = 0.0;
+        for (int r = g; r < NS; r += 32) acc += (double)part_lds[r][c];
+        sh[k][g][c] = acc;
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int gg = 0; gg < 32; ++gg) tot[k] += sh[k][gg][c];
+        }
+    }
+    if (g == 0 && ch < a.c) coef_store(a, ch, tot[0], tot[1]);
+}
+
+// ---- the same for the last stage under the MSE head (include/rvip_hip.h: rvip_head_mse_coef): the rows come from the forward pass ----
+struct HeadCoefArgs {
+    const float* rows; int nrows;                  // [nrows][3][C]: S_0, S_1, (Q_0, Q_1, ...)
+    const float* w; const float* dlogit; int k;
+    float* head_dw; float* head_db;
+    const float* sums; float* loss_out; float inv_count;
+    const unsigned char* z; long long px;          // the exact route streams these
+    const float* gamma; const float* beta; const float* mean; const float* invstd;
+    float* dgamma; float* dbeta; float* coef; int* flags;
+    double n; int c; float min_gamma, max_beta_ratio;
+};
+template <typename T>
+__global__ __launch_bounds__(1024) void head_mse_coef_kernel(HeadCoefArgs a) {
+    constexpr int VE = Vec<T>::VE, NV = 32 / VE, NS = 1024 / NV, KK = 2;
+    __shared__ double sh[KK + 1][32][32];
+    __shared__ float part_lds[NS][32];
+    __shared__ int bad[32];
+    __shared__ int sbad;
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int ch = blockIdx.x * 32 + c;
+    const size_t rs = (size_t)(KK + 1) * a.c;
+    double s[KK + 1];
+#pragma unroll
+    for (int q = 0; q <= KK; ++q) s[q] = 0.0;
+    if (ch < a.c) {
+        const float* base = a.rows + ch;
+        int b = g;
+        for (; b + 96 < a.nrows; b += 128) {
+            float v[4][KK];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) v[u][kk] = base[(size_t)(b + 32 * u) * rs + (size_t)kk * a.c];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) s[kk] += ((double)v[0][kk] + (double)v[1][kk]) + ((double)v[2][kk] + (double)v[3][kk]);
+        }
+        for (; b < a.nrows; b += 32) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) s[kk] += (double)base[(size_t)b * rs + (size_t)kk * a.c];
+        }
+    }
+    if (c < KK) {                                   // every workgroup folds the Q row itself (T1 of each channel needs all of it)
+        const float* qb = a.rows + (size_t)KK * a.c + c;
+        int b = g;
+        for (; b + 96 < a.nrows; b += 128) {
+            const float v0 = qb[(size_t)b * rs], v1 = qb[(size_t)(b + 32) * rs], v2 = qb[(size_t)(b + 64) * rs], v3 = qb[(size_t)(b + 96) * rs];
+            s[KK] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < a.nrows; b += 32) s[KK] += (double)qb[(size_t)b * rs];
+    }
+#pragma unroll
+    for (int q = 0; q <= KK; ++q) sh[q][g][c] = s[q];
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+    float gm = 1.f, bt = 0.f;
+    if (g == 0) {
+        double S[KK], Q[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            S[kk] = Q[kk] = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < 32; ++gg) { S[kk] += sh[kk][gg][c]; Q[kk] += sh[KK][gg][kk]; }
+        }
+        int isbad = 0;
+        if (ch < a.c) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                if (kk < a.k) {
+                    const double w = (double)a.w[ch * a.k + kk];
+                    t1 += w * Q[kk]; t2 += w * S[kk];
+                    a.head_dw[ch * a.k + kk] = (float)S[kk];
+                }
+            }
+            gm = a.gamma[ch]; bt = a.beta ? a.beta[ch] : 0.f;
+            isbad = !(fabsf(gm) >= a.min_gamma && fabsf(bt) <= a.max_beta_ratio * fabsf(gm));
+        }
+        if (blockIdx.x == 0 && c == 0) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+                if (kk < a.k) a.head_db[kk] = (float)Q[kk];
+            if (a.loss_out) a.loss_out[0] = a.sums[0] * a.inv_count;
+        }
+        bad[c] = isbad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int any = 0;
+        for (int i = 0; i < 32; ++i) any |= bad[i];
+        a.flags[blockIdx.x] = any;
+        sbad = any;
+    }
+    __syncthreads();
+    if (!sbad) {
+        if (g == 0 && ch < a.c) coef_store(a, ch, t1, (t2 - (double)bt * t1) / (double)gm);
+        return;
+    }
+    // ---------------- exact route for this block: sum g and sum g*xhat over every pixel, as rvip_bn_bwd_reduce_head computes them ----------------
+    const int cv = threadIdx.x % NV, slot = threadIdx.x / NV, cgi = blockIdx.x * NV + cv, cg = a.c / VE;
+    const bool active = cgi < cg;
+    const HeadFuse hd{a.w, nullptr, a.dlogit, a.k};
+    float part[2][VE], mu[VE], is[VE], wr[VE][KK];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        part[0][e] = part[1][e] = 0.f;
+        mu[e] = active ? a.mean[cgi * VE + e] : 0.f;
+        is[e] = active ? a.invstd[cgi * VE + e] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) wr[e][kk] = (active && kk < a.k) ? a.w[(cgi * VE + e) * a.k + kk] : 0.f;
+    }
+    if (active) {
+        for (long long rr = slot; rr < a.px; rr += NS) {
+            float z[VE], gv[VE], d[KK];
+            Vec<T>::load(a.z + ((size_t)rr * a.c + cgi * VE) * sizeof(T), z);
+            head_grad_vec<T, VE, KK>(hd, rr, wr, d, gv);
 #pragma unroll
             for (int e = 0; e < VE; ++e) { part[0][e] += gv[e]; part[1][e] = fmaf(gv[e], (z[e] - mu[e]) * is[e], part[1][e]); }
         }
@@ -1782,9 +1960,9 @@ extern "C" int rvip_bn_apply_head(const rvip_apply_desc* d, const float* head_w,
     HeadFuse hd{head_w, head_b, nullptr, k};
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
-        if (k <= 2 && a.act == RVIP_ACT_NONE) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
-        else if (k <= 2) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
-        else hipLaunchKernelGGL((bn_apply_head_kernel<T, RVIP_MAXK>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws);
+        if (k <= 2 && a.act == RVIP_ACT_NONE) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws, HeadMse{});
+        else if (k <= 2) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws, HeadMse{});
+        else hipLaunchKernelGGL((bn_apply_head_kernel<T, RVIP_MAXK>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws, HeadMse{});
         return 0;
     });
     int rc = check_launch();
@@ -1861,6 +2039,77 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     if (rc || defer) return rc;
     PostSum p{d->dbias};
     return launch_fold<1, PostSum>(ws, g.nblk, d->c, p, s);
+}
+
+// The MSE form of the fused last stage (include/rvip_hip.h, ABI 6): same grid as rvip_bn_apply_head.
+static long long head_fwd_blocks(long long rows, long long* chunk_out) {
+    long long nb = cdiv(rows, 256 * 4);
+    if (nb > 1024) nb = 1024;
+    const long long chunk = cdiv(rows, nb);
+    if (chunk_out) *chunk_out = chunk;
+    return cdiv(rows, chunk);
+}
+
+extern "C" int rvip_bn_apply_head_mse_rows(long long rows, int c, int dtype, int k) {
+    if (!RVIP_DT_OK(dtype) || rows <= 0 || c <= 0 || c % RVIP_VE(dtype) || k <= 0 || k > 2) return 0;
+    const int cg = c / RVIP_VE(dtype);
+    if (cg > 64 || (cg & (cg - 1))) return 0;
+    return (int)head_fwd_blocks(rows, nullptr);
+}
+
+extern "C" int rvip_bn_apply_head_mse(const rvip_apply_desc* d, const float* head_w, const float* head_b, int k, float* pred,
+                                      const float* y_true, float* sums, float* dlogit, float inv_count, float dscale,
+                                      float* mse_rows, size_t mse_rows_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!d || !d->z || !head_w || !pred || !y_true || !sums || !workspace || !dlogit || !mse_rows || !RVIP_DT_OK(d->dtype) || k <= 0) return RVIP_EINVAL;
+    const int ve = RVIP_VE(d->dtype);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->c % ve || d->drop_rate > 0.f || !(inv_count > 0.f) || !(dscale > 0.f)) return RVIP_EINVAL;
+    const int cg = d->c / ve;
+    if (k > 2 || d->act != RVIP_ACT_NONE || cg > 64 || (cg & (cg - 1))) return RVIP_EUNSUPPORTED;
+    ApplyArgs a;
+    a.z = (const unsigned char*)d->z; a.y = nullptr; a.pooled = nullptr; a.argmax = nullptr;
+    a.scale = d->scale; a.shift = d->shift; a.act = d->act;
+    a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;
+    a.n = d->n; a.h = d->h; a.w = d->w; a.c = d->c;
+    const long long rows = (long long)d->n * d->h * d->w;
+    long long chunk;
+    const long long nb = head_fwd_blocks(rows, &chunk);
+    if (workspace_bytes < (size_t)nb * 16 * sizeof(float) || mse_rows_bytes < (size_t)nb * 3 * d->c * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    HeadFuse hd{head_w, head_b, nullptr, k};
+    HeadMse mse{dlogit, mse_rows, inv_count, dscale};
+    by_dtype(d->dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, 1, ws, mse);
+        return 0;
+    });
+    int rc = check_launch();
+    if (rc) return rc;
+    PostHeadSums p{sums};
+    return launch_fold<1, PostHeadSums>(ws, (int)nb, 16, p, s);
+}
+
+extern "C" int rvip_head_mse_coef(const rvip_headcoef_desc* d, void* stream) {
+    (void)hipGetLastError();
+    if (!d || !d->bn || !d->head_w || !d->dlogit || !d->mse_rows || !d->head_dw || !d->head_db || !d->flags || d->nrows <= 0) return RVIP_EINVAL;
+    const rvip_bnbwd_desc* b = d->bn;
+    if (!b->z || !RVIP_DT_OK(b->dtype) || b->c <= 0 || b->c % RVIP_VE(b->dtype) || b->rows <= 0) return RVIP_EINVAL;
+    if (!b->gamma || !b->mean || !b->invstd || !b->dgamma || !b->dbeta || !b->coef || b->drop_rate > 0.f) return RVIP_EINVAL;
+    if (!(d->min_gamma > 0.f) || !(d->max_beta_ratio > 0.f) || (d->loss_out && !d->sums)) return RVIP_EINVAL;
+    if (d->k <= 0 || d->k > 2 || b->act != RVIP_ACT_RELU || b->act_after_bn) return RVIP_EUNSUPPORTED;
+    HeadCoefArgs a;
+    a.rows = d->mse_rows; a.nrows = d->nrows; a.w = d->head_w; a.dlogit = d->dlogit; a.k = d->k;
+    a.head_dw = d->head_dw; a.head_db = d->head_db; a.sums = d->sums; a.loss_out = d->loss_out; a.inv_count = d->inv_count;
+    a.z = (const unsigned char*)b->z; a.px = b->rows;
+    a.gamma = b->gamma; a.beta = d->beta; a.mean = b->mean; a.invstd = b->invstd;
+    a.dgamma = b->dgamma; a.dbeta = b->dbeta; a.coef = b->coef; a.flags = d->flags;
+    a.n = (double)b->rows; a.c = b->c; a.min_gamma = d->min_gamma; a.max_beta_ratio = d->max_beta_ratio;
+    by_dtype(b->dtype, [&](auto t) {
+        hipLaunchKernelGGL(head_mse_coef_kernel<decltype(t)>, dim3((unsigned)cdiv(b->c, 32)), dim3(1024), 0, (hipStream_t)stream, a);
+        return 0;
+    });
+    return check_launch();
 }
 
 extern "C" int rvip_head_grad(const float* pred, const float* y_true, const float* sums, float* dlogit, float* loss_out,

@@ -347,6 +347,11 @@ class Engine:
         self.fuse_head = bool(last.bn and not last.pool and not (last.drop and last.drop[1] > 0) and last.y == plan.head['src']
                               and cg_ <= 64 and (cg_ & (cg_ - 1)) == 0 and os.environ.get('RVIP_FUSE_HEAD', '1') != '0')
         last_apply = None
+        # MSE head: the logit gradient and the sums of the head's / the stage's BN backward leave the forward pass
+        # (rvip_bn_apply_head_mse + rvip_head_mse_coef replace rvip_head_grad, rvip_bn_bwd_reduce_head and their finalisers)
+        self.head_alg = bool(self.fuse_head and self.loss_kind == N.LOSS_MSE and plan.head['k'] <= 2 and not last.act_post
+                             and N.ACT[last.act_conv] == N.ACT['relu'] and os.environ.get('RVIP_BNBWD_ALGEBRAIC', '1') != '0'
+                             and os.environ.get('RVIP_HEAD_ALGEBRAIC', '1') != '0')
         # who reads what: tensor name -> producing stage, stage -> [(consumer stage, 0 = as src0 / 1 = as the skip half)]
         producer = {}
         for st in plan.stages:
@@ -468,15 +473,21 @@ class Engine:
         hrows = C.c_longlong(n * hd['h'] * hd['w'])
         hx = self.act[hd['src']]
         hw_, hb_ = P.p(hd['conv'], 'kernel'), P.p(hd['conv'], 'bias')
+        head_eval = None
         if self.fuse_head:
-            fwd_t.append((L.rvip_bn_apply_head, (C.byref(last_apply), hw_, hb_, hd['k'], _ptr(self.pred), _ptr(self.y_true),
-                                                 _ptr(self.sums), ws, wsb)))
+            head_eval = (L.rvip_bn_apply_head, (C.byref(last_apply), hw_, hb_, hd['k'], _ptr(self.pred), _ptr(self.y_true),
+                                                _ptr(self.sums), ws, wsb), 'head')
+        if self.head_alg:
+            pass                                        # the launch is appended once the loss scale is known (below)
+        elif self.fuse_head:
+            fwd_t.append(head_eval[:2])
         else:
             fwd_t.append((L.rvip_head_fwd, (_ptr(hx), hw_, hb_, _ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), hrows,
                                             hd['cin'], hd['k'], dt, ws, wsb)))
         fwd_i.append((L.rvip_head_fwd, (_ptr(hx), hw_, hb_, _ptr(self.pred), None, None, hrows, hd['cin'], hd['k'], dt,
                                         None, C.c_size_t(0))))
-        self.fwd_eval = list(fwd_i[:-1]) + [fwd_t[-1]]          # inference-mode network + loss sums (validation)
+        # inference-mode network + loss sums (validation)
+        self.fwd_eval = list(fwd_i[:-1]) + [head_eval if head_eval is not None else fwd_t[-1]]
 
         # ---------------- backward ----------------
         per_rank = float(n * hd['h'] * hd['w'] * hd['k'])
@@ -498,11 +509,19 @@ class Engine:
         else:
             self.loss_scale = 1.0
         P.grad_unscale = 1.0 / self.loss_scale
-        bwd.append((L.rvip_head_grad, (_ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), _ptr(self.dlogit), _ptr(self.loss),
-                                       hrows, hd['k'], self.loss_kind, C.c_float(self._inv_count), C.c_float(1.0 / self.world),
-                                       C.c_float(self.w_bce), C.c_float(self.w_dice))))
-        if self.loss_scale * self.grad_factor != 1.0:
-            bwd.append((L.rvip_scale_f32, (_ptr(self.dlogit), C.c_longlong(self.dlogit.numel()), C.c_float(self.loss_scale * self.grad_factor))))
+        if self.head_alg:
+            nr = L.rvip_bn_apply_head_mse_rows(hrows, last.cout, dt, hd['k'])
+            self.head_rows = torch.empty(nr * 3 * last.cout, dtype=torch.float32, device=self.ws.device)
+            fwd_t.append((L.rvip_bn_apply_head_mse, (C.byref(last_apply), hw_, hb_, hd['k'], _ptr(self.pred), _ptr(self.y_true),
+                                                     _ptr(self.sums), _ptr(self.dlogit), C.c_float(self._inv_count),
+                                                     C.c_float(self.loss_scale * self.grad_factor), _ptr(self.head_rows),
+                                                     C.c_size_t(self.head_rows.numel() * 4), ws, wsb)))
+        else:
+            bwd.append((L.rvip_head_grad, (_ptr(self.pred), _ptr(self.y_true), _ptr(self.sums), _ptr(self.dlogit), _ptr(self.loss),
+                                           hrows, hd['k'], self.loss_kind, C.c_float(self._inv_count), C.c_float(1.0 / self.world),
+                                           C.c_float(self.w_bce), C.c_float(self.w_dice))))
+            if self.loss_scale * self.grad_factor != 1.0:
+                bwd.append((L.rvip_scale_f32, (_ptr(self.dlogit), C.c_longlong(self.dlogit.numel()), C.c_float(self.loss_scale * self.grad_factor))))
         if not self.fuse_head:
             bwd.append((L.rvip_head_bwd, (_ptr(hx), hw_, _ptr(self.dlogit), _ptr(self.grd[hd['src']]), P.g(hd['conv'], 'kernel'),
                                           P.g(hd['conv'], 'bias'), hrows, hd['cin'], hd['k'], dt, ws, wsb)))
@@ -690,8 +709,22 @@ class Engine:
             self._keep.append(b)
             if st is last and self.fuse_head:
                 b.dy = None
-                bwd.append((L.rvip_bn_bwd_reduce_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'], P.g(hd['conv'], 'kernel'),
-                                                        P.g(hd['conv'], 'bias'))))
+                if self.head_alg:
+                    hc = N.HeadCoefDesc()
+                    hc.bn, hc.beta = C.pointer(b), P.p(st.bn, 'beta').value
+                    hc.head_w, hc.dlogit, hc.k = hw_.value, self.dlogit.data_ptr(), hd['k']
+                    hc.mse_rows, hc.nrows = self.head_rows.data_ptr(), self.head_rows.numel() // (3 * st.cout)
+                    hc.head_dw, hc.head_db = P.g(hd['conv'], 'kernel').value, P.g(hd['conv'], 'bias').value
+                    hc.sums, hc.loss_out, hc.inv_count = self.sums.data_ptr(), self.loss.data_ptr(), self._inv_count
+                    flags = torch.zeros(-(-st.cout // 32), dtype=torch.int32, device=self.ws.device)
+                    self._fold_bufs.append(flags)
+                    self.bn_flags[st.conv] = flags
+                    hc.flags, hc.min_gamma, hc.max_beta_ratio = flags.data_ptr(), min_gamma, max_beta_ratio
+                    self._keep.append(hc)
+                    bwd.append((L.rvip_head_mse_coef, (C.byref(hc),)))
+                else:
+                    bwd.append((L.rvip_bn_bwd_reduce_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'], P.g(hd['conv'], 'kernel'),
+                                                            P.g(hd['conv'], 'bias'))))
                 bwd.append((L.rvip_bn_bwd_apply_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'])))
             elif st.conv in self.upact:              # dz was written, ReLU backward applied, by the reader's data gradient; bias gradient = its column sums
                 c = self.upact[st.conv]

@@ -872,3 +872,136 @@ def test_last_stage_fused_with_head_matches_the_separate_kernels(dtype, act_afte
         sc_ = float(np.abs(down(t0)).max())
         np.testing.assert_allclose(down(t1), down(t0), atol=(2e-3 if dtype != 'f32' else 1e-5) * sc_ + 1e-9, err_msg=nm)
     close(down(out1[0]), down(out0[0]).astype(np.float64), dtype, 'dz fused vs separate')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(3, 12, 20, 16, 2, 1.0), (2, 64, 96, 32, 2, 4096.0), (2, 40, 24, 8, 1, 1.0), (1, 64, 64, 64, 2, 1.0)])
+def test_mse_head_gradients_from_the_forward_pass(dtype, shape):
+    """rvip_bn_apply_head_mse + rvip_head_mse_coef (ABI 6) against rvip_bn_apply_head + rvip_head_grad (+ rvip_scale_f32) +
+    rvip_bn_bwd_reduce_head: same pred / loss sums / dlogit bit for bit, the head's and the stage's BN gradients up to the
+    summation order -- and up to the storage rounding of the rebuilt gradient, which the algebraic sums do not carry; the
+    in-kernel exact route (every block declared ill-conditioned) carries it and is held to the tight bound."""
+    n, h, w, c, k, dscale = shape
+    rows = n * h * w
+    rng = np.random.default_rng(17 + c)
+    z = rnd(np.maximum(rng.standard_normal((n, h, w, c)) * 1.5 + 0.2, 0), dtype)
+    gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    hw = (rng.standard_normal((c, k)) * 0.3).astype(np.float32)
+    hb = (rng.standard_normal(k) * 0.1).astype(np.float32)
+    _, yt = O.synthetic_batch(n, (h, w), k, seed=3)
+    L = N.lib()
+    wsb = L.rvip_reduce_workspace(rows, 16 * c)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    zd, gd, bd, hwd, hbd, ytd = up(z, dtype), f32(gamma), f32(beta), f32(hw), f32(hb), f32(yt)
+    mm, mv = f32(np.zeros(c)), f32(np.ones(c))
+    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(4))
+    N.call('rvip_bn_train_stats', P(zd), C.c_longlong(rows), c, ndt(dtype), P(gd), P(bd), P(mm), P(mv), 0.99, 1e-3, 1,
+           P(mean), P(invstd), P(scale), P(shift), P(ws), C.c_size_t(wsb), stream())
+    state = torch.zeros(8, dtype=torch.int32, device=dev())
+    a = N.ApplyDesc()
+    a.z, a.y, a.pooled = zd.data_ptr(), None, None
+    a.scale, a.shift, a.act = scale.data_ptr(), shift.data_ptr(), 0
+    a.drop_rate, a.mask, a.state, a.layer_id = 0.0, None, state.data_ptr(), 0
+    a.n, a.h, a.w, a.c, a.dtype = n, h, w, c, ndt(dtype)
+    inv_count = 1.0 / (rows * k)
+
+    def outputs():
+        o = {'dz': torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())}
+        for nm in ('dgamma', 'dbeta', 'dbias'):
+            o[nm] = torch.full((c,), 7.0, dtype=torch.float32, device=dev())
+        o['coef'] = torch.full((3 * c,), 7.0, dtype=torch.float32, device=dev())
+        o['hdw'] = torch.full((c, k), 7.0, dtype=torch.float32, device=dev())
+        o['hdb'] = torch.full((k,), 7.0, dtype=torch.float32, device=dev())
+        o['pred'] = torch.empty((n, h, w, k), dtype=torch.float32, device=dev())
+        o['sums'] = torch.zeros(16, dtype=torch.float32, device=dev())
+        o['dlogit'] = torch.full((n, h, w, k), 7.0, dtype=torch.float32, device=dev())
+        o['loss'] = torch.full((1,), 7.0, dtype=torch.float32, device=dev())
+        return o
+
+    def bwd_desc(o):
+        b = N.BnBwdDesc()
+        b.dy, b.z, b.dz = None, zd.data_ptr(), o['dz'].data_ptr()
+        b.gamma, b.mean, b.invstd = gd.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+        b.scale, b.shift = scale.data_ptr(), shift.data_ptr()
+        b.dgamma, b.dbeta, b.dbias, b.coef = o['dgamma'].data_ptr(), o['dbeta'].data_ptr(), o['dbias'].data_ptr(), o['coef'].data_ptr()
+        b.act, b.act_after_bn = N.ACT['relu'], 0
+        b.drop_rate, b.mask, b.state, b.layer_id = 0.0, None, state.data_ptr(), 0
+        b.rows, b.c, b.dtype = rows, c, ndt(dtype)
+        b.workspace, b.workspace_bytes = ws.data_ptr(), wsb
+        return b
+    # classic
+    o0 = outputs()
+    N.call('rvip_bn_apply_head', C.byref(a), P(hwd), P(hbd), k, P(o0['pred']), P(ytd), P(o0['sums']), P(ws), C.c_size_t(wsb), stream())
+    N.call('rvip_head_grad', P(o0['pred']), P(ytd), P(o0['sums']), P(o0['dlogit']), P(o0['loss']), C.c_longlong(rows), k, N.LOSS_MSE,
+           C.c_float(inv_count), C.c_float(1.0), C.c_float(0.5), C.c_float(1.0), stream())
+    if dscale != 1.0:
+        N.call('rvip_scale_f32', P(o0['dlogit']), C.c_longlong(rows * k), C.c_float(dscale), stream())
+    b0 = bwd_desc(o0)
+    N.call('rvip_bn_bwd_reduce_head', C.byref(b0), P(hwd), P(o0['dlogit']), k, P(o0['hdw']), P(o0['hdb']), stream())
+    # forward-side
+    nr = L.rvip_bn_apply_head_mse_rows(C.c_longlong(rows), c, ndt(dtype), k)
+    chunk = -(-rows // min(1024, -(-rows // 1024)))
+    assert nr == -(-rows // chunk)
+
+    def forward_side(min_gamma):
+        o = outputs()
+        mrows = torch.full((nr * 3 * c,), 7.0, dtype=torch.float32, device=dev())
+        N.call('rvip_bn_apply_head_mse', C.byref(a), P(hwd), P(hbd), k, P(o['pred']), P(ytd), P(o['sums']), P(o['dlogit']),
+               C.c_float(inv_count), C.c_float(dscale), P(mrows), C.c_size_t(mrows.numel() * 4), P(ws), C.c_size_t(wsb), stream())
+        b = bwd_desc(o)
+        hc = N.HeadCoefDesc()
+        hc.bn, hc.beta = C.pointer(b), bd.data_ptr()
+        hc.head_w, hc.dlogit, hc.k, hc.nrows = hwd.data_ptr(), o['dlogit'].data_ptr(), k, nr
+        hc.mse_rows, hc.head_dw, hc.head_db = mrows.data_ptr(), o['hdw'].data_ptr(), o['hdb'].data_ptr()
+        hc.sums, hc.loss_out, hc.inv_count = o['sums'].data_ptr(), o['loss'].data_ptr(), inv_count
+        o['flags'] = torch.full((-(-c // 32),), 7, dtype=torch.int32, device=dev())
+        hc.flags, hc.min_gamma, hc.max_beta_ratio = o['flags'].data_ptr(), min_gamma, 64.0
+        N.call('rvip_head_mse_coef', C.byref(hc), stream())
+        torch.cuda.synchronize()
+        return o, (a, b, hc, mrows)
+    # The BN terms of the algebraic route are held to the float64 straight-through values (g = sum_k d w unrounded, xhat from z):
+    # it sums g * y with y as the head read it (rounded to the storage type), the classic route sums round(g) * xhat -- two
+    # different zero-mean roundings per pixel, whose share of a sum shrinks with sqrt(rows).  The exact route of an ill-conditioned
+    # block repeats the classic arithmetic and is held to the classic launch.
+    dl64, z64 = down(o0['dlogit']).astype(np.float64).reshape(rows, k), down(zd).astype(np.float64).reshape(rows, c)
+    g64 = dl64 @ hw.astype(np.float64).T
+    xh = (z64 - down(mean).astype(np.float64)) * down(invstd).astype(np.float64)
+    want_db, want_dg = g64.sum(0), (g64 * xh).sum(0)
+    gm_, is_, mu_ = gamma.astype(np.float64), down(invstd).astype(np.float64), down(mean).astype(np.float64)
+    c2 = -gm_ * is_ * is_ * want_dg / rows
+    exact = {'dbeta': want_db, 'dgamma': want_dg, 'coef': np.concatenate([gm_ * is_, c2, -gm_ * is_ * want_db / rows - c2 * mu_])}
+    classic = {nm: down(o0[nm]).astype(np.float64) for nm in exact}
+    loose = {'f32': 2e-5, 'bf16': 8e-3, 'f16': 1.2e-3}[dtype] * max(1.0, (12288.0 / rows) ** 0.5)
+    for min_gamma, want, tol in ((1.0 / 64, exact, loose), (1e9, classic, 2e-5)):
+        o1, keep = forward_side(min_gamma)
+        assert torch.equal(o1['pred'], o0['pred']) and torch.equal(o1['sums'], o0['sums'])
+        assert torch.equal(o1['dlogit'], o0['dlogit'])
+        assert torch.equal(o1['loss'], o0['loss'])
+        assert bool(down(o1['flags']).all()) == (min_gamma > 1) and bool(down(o1['flags']).any()) == (min_gamma > 1)
+        for nm in ('hdw', 'hdb'):
+            sc_ = float(np.abs(down(o0[nm])).max())
+            np.testing.assert_allclose(down(o1[nm]), down(o0[nm]), atol=2e-5 * sc_ + 1e-12, err_msg=nm)
+        for nm in ('dgamma', 'dbeta', 'coef'):
+            got, ref = down(o1[nm]).reshape(-1, c).astype(np.float64), want[nm].reshape(-1, c)
+            for i in range(got.shape[0]):
+                assert np.abs(got[i] - ref[i]).max() <= tol * np.abs(ref[i]).max() + 1e-12, (nm, i, min_gamma, np.abs(got[i] - ref[i]).max(), np.abs(ref[i]).max())
+    for nm in exact:                           # (and the classic launch sits within the same distance of the float64 values)
+        got, ref = classic[nm].reshape(-1, c), exact[nm].reshape(-1, c)
+        for i in range(got.shape[0]):
+            assert np.abs(got[i] - ref[i]).max() <= loose * np.abs(ref[i]).max() + 1e-12, (nm, i, 'classic')
+    # what the entry points refuse
+    a2, b2, hc2, mrows2 = keep
+    args = lambda kk, nbytes: (C.byref(a2), P(hwd), P(hbd), kk, P(o1['pred']), P(ytd), P(o1['sums']), P(o1['dlogit']), C.c_float(inv_count),  # noqa: E731
+                               C.c_float(1.0), P(mrows2), C.c_size_t(nbytes), P(ws), C.c_size_t(wsb), stream())
+    assert L.rvip_bn_apply_head_mse(*args(3, mrows2.numel() * 4)) == -2
+    assert L.rvip_bn_apply_head_mse(*args(k, mrows2.numel() * 4 - 4)) == -3
+    a2.act = N.ACT['relu']
+    assert L.rvip_bn_apply_head_mse(*args(k, mrows2.numel() * 4)) == -2
+    a2.act = 0
+    b2.act_after_bn = 1
+    assert L.rvip_head_mse_coef(C.byref(hc2), stream()) == -2
+    b2.act_after_bn = 0
+    hc2.min_gamma = 0.0
+    assert L.rvip_head_mse_coef(C.byref(hc2), stream()) == -1
+    assert L.rvip_bn_apply_head_mse_rows(C.c_longlong(rows), c, ndt(dtype), 3) == 0
