@@ -69,6 +69,15 @@ __device__ __forceinline__ void block_fold(const float (&part)[K][VE], bool acti
     }
 }
 
+// Buffer loads for the folds that request many rows at once: one 32-bit offset register per thread and a scalar offset per row
+// instead of a 64-bit address pair per load in flight; offsets past the end (and NULL sources: 0 records) read as zero.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 // stage 2: totals[k] for channel ch = sum over workspace rows, then Post::run(ch, totals).
 // 512 threads = 32 channels x 16 row groups; every thread keeps 4 loads in flight (the loop is latency-bound).
 // GROUPS row groups of 32 channels: 32 (1024 threads) halves the chain of load round trips of the 1024-row folds; a Post whose
@@ -1667,31 +1676,31 @@ __global__ __launch_bounds__(1024) void head_mse_coef_kernel(HeadCoefArgs a) {
     double s[KK + 1];
 #pragma unroll
     for (int q = 0; q <= KK; ++q) s[q] = 0.0;
-    if (ch < a.c) {
-        const float* base = a.rows + ch;
-        int b = g;
-        for (; b + 96 < a.nrows; b += 128) {
-            float v[4][KK];
+    {
+        // one latency chain on one CU: 16 rows (S of both classes, and Q for the threads that fold it) are requested together
+        const bool mine = ch < a.c, qmine = c < KK;           // every workgroup folds the Q row itself (T1 of each channel needs all of it)
+        const __amdgpu_buffer_rsrc_t rr = rows_rsrc(a.rows, (size_t)a.nrows * rs * 4);
+        constexpr unsigned NONE = 0x80000000u;
+        const unsigned vs = mine ? (unsigned)((size_t)g * rs + ch) * 4u : NONE, vq = qmine ? (unsigned)((size_t)g * rs + (size_t)KK * a.c + c) * 4u : NONE;
+        constexpr int D = 16;
+        for (int b = 0; b < a.nrows; b += 32 * D) {
+            float v[D][KK], qv[D];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < D; ++u) {
+                // (a scalar offset past the end would make the range check's `records - soffset` wrap: such rows get offset 0 + NONE)
+                const bool any = b + 32 * u < a.nrows;                             // wave-uniform
+                const unsigned so = any ? (unsigned)((size_t)(b + 32 * u) * rs) * 4u : 0u;
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk) v[u][kk] = base[(size_t)(b + 32 * u) * rs + (size_t)kk * a.c];
+                for (int kk = 0; kk < KK; ++kk) v[u][kk] = buf_f32(rr, any ? vs : NONE, any ? so + (unsigned)(kk * a.c) * 4u : 0u);
+                qv[u] = buf_f32(rr, any ? vq : NONE, so);
+            }
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) s[kk] += ((double)v[0][kk] + (double)v[1][kk]) + ((double)v[2][kk] + (double)v[3][kk]);
+            for (int u = 0; u < D; u += 4) {
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) s[kk] += ((double)v[u][kk] + (double)v[u + 1][kk]) + ((double)v[u + 2][kk] + (double)v[u + 3][kk]);
+                s[KK] += ((double)qv[u] + (double)qv[u + 1]) + ((double)qv[u + 2] + (double)qv[u + 3]);
+            }
         }
-        for (; b < a.nrows; b += 32) {
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk) s[kk] += (double)base[(size_t)b * rs + (size_t)kk * a.c];
-        }
-    }
-    if (c < KK) {                                   // every workgroup folds the Q row itself (T1 of each channel needs all of it)
-        const float* qb = a.rows + (size_t)KK * a.c + c;
-        int b = g;
-        for (; b + 96 < a.nrows; b += 128) {
-            const float v0 = qb[(size_t)b * rs], v1 = qb[(size_t)(b + 32) * rs], v2 = qb[(size_t)(b + 64) * rs], v3 = qb[(size_t)(b + 96) * rs];
-            s[KK] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
-        }
-        for (; b < a.nrows; b += 32) s[KK] += (double)qb[(size_t)b * rs];
     }
 #pragma unroll
     for (int q = 0; q <= KK; ++q) sh[q][g][c] = s[q];
