@@ -195,6 +195,7 @@ struct WgArgs2 {
     int depth, dshift;                        // Conv3D depth tap: X is read from image n + dshift of the same volume (zeros outside)
     int dbg;                                  // ablation only (RVIP_DBG): 1 = no DMA after the first tile, 2 = no MFMA, 4 = DMAs fetch nothing
     int nt_slab;                              // slabs leave with the non-temporal hint (deferred fold: their reader runs milliseconds later)
+    int sp;                                   // sub-pixel form of the up-sampled layer (wgrad3x3_ws<..., TAPS = 4>): h, w = the low-resolution grid, nsplit = 4 phases x pixel splits
 };
 
 template <typename T, int TW, int CIB, int COB>
@@ -399,8 +400,18 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
 // joins them.  In v2 every wave issues ~19 DMA instructions (~150 issue cycles each) in front of its 144 MFMAs per tile.
 // NST = LDS stages: 3 where they fit (the 32 x 32 block variant, 38 KiB per stage - the full-resolution layers, which are bound
 // by the latency of the input stream: a second tile in flight per CU), else 2.
-template <typename T, int TW, int CIB, int COB, int NST = 2>
+// TAPS = 4: the weight gradient of UpSampling2D(2) -> conv in its sub-pixel form (16-bit types).  Output pixel (2i+pa, 2j+pb) of the
+// up-sampled convolution only sees the low-resolution pixels (i+pa-1..i+pa) x (j+pb-1..j+pb), each through a SUM of the 3x3 taps
+// that land on it (rvip_pack_subpixel_weights has the table), so per output phase (pa, pb) the gradient of those four summed taps is
+// a 2x2-tap contraction of the low-resolution X with the phase image dY[2i+pa][2j+pb]: 16 instead of 36 multiply-adds per
+// low-resolution pixel.  blockIdx.x = 4 * pixel split + phase; X tiles are read from the low-resolution tensor as they lie (a.h, a.w
+// = ITS grid), dY tiles with stride 2.  d/dW[kh][kw] = the sum over the phases of the summed-tap gradient that contains (kh, kw) --
+// exactly one per phase -- so every workgroup writes a full nine-tap slab (its four blocks repeated where they belong) and the slab
+// fold stays what it is.
+template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
+    static_assert(TAPS == 9 || (TAPS == 4 && sizeof(T) == 2), "taps");
+    constexpr bool SP = TAPS == 4;
     constexpr int TH = 256 / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
     constexpr int NHROWS = (NHALO + 15) / 16 * 16;
     constexpr int ESZ = (int)sizeof(T), VE = Vec<T>::VE;
@@ -421,7 +432,16 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wv8 >= 4;
     const int wv = wv8 & 3;                                           // compute wave id / loader wave id
-    const int split = blockIdx.x, ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
+    // Sub-pixel form: the four phases of a pixel split read the same X tiles and the four interleaved quarters of the same dY lines
+    // (a pixel of a 32-channel dY is half a 128-byte line).  Workgroups go to the 8 XCDs round-robin, so with a grid of whole
+    // groups of 32 the phases of split s are the workgroups 8 apart -- same XCD, same L2, running side by side; otherwise every line
+    // of dY comes from memory twice (64 -> 32 at 256^2: 85 us against 74 for the nine-tap form it replaces).
+    const bool xcd_map = SP && gridDim.x % 32 == 0;
+    const int ph = !SP ? 0 : xcd_map ? (int)((blockIdx.x >> 3) & 3) : (int)(blockIdx.x & 3);
+    const int split = !SP ? (int)blockIdx.x : xcd_map ? (int)((blockIdx.x & 7) | ((blockIdx.x >> 5) << 3)) : (int)(blockIdx.x >> 2);
+    const int ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
+    const int pa = ph >> 1, pb = ph & 1;                                                                // output phase (wave-uniform)
+    const int nsplit = SP ? a.nsplit >> 2 : a.nsplit;                                                   // pixel splits
     const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
     const int pair = wv % PAIRS, part = wv / PAIRS;
     const int ci_t = pair % NCI, co_t = pair / NCI;
@@ -458,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
         const int c = co0 + p * VE;
         gpy[i] = (c < a.cout) ? P / TW : -100000;
         gpx[i] = P % TW;
-        grel[i] = (((P / TW) * a.w + (P % TW)) * a.cout + c) * ESZ;
+        grel[i] = SP ? ((2 * (P / TW) * 2 * a.w + 2 * (P % TW)) * a.cout + c) * ESZ : (((P / TW) * a.w + (P % TW)) * a.cout + c) * ESZ;
     }
     auto issue = [&](int tile, int stage) __attribute__((always_inline)) {
         int bx = tile;
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
         const int ty0 = ty_i * TH, tx0 = tx_i * TW;
         const bool dok = (unsigned)(n % a.depth + a.dshift) < (unsigned)a.depth;
         const int xbase = (((n + a.dshift) * hs + (ty0 >> shf)) * wsrc + (tx0 >> shf)) * csrc * ESZ;
-        const int gbase = ((n * a.h + ty0) * a.w + tx0) * a.cout * ESZ;
+        const int gbase = SP ? ((n * 2 * a.h + 2 * ty0 + pa) * 2 * a.w + 2 * tx0 + pb) * a.cout * ESZ : ((n * a.h + ty0) * a.w + tx0) * a.cout * ESZ;
 #pragma unroll
         for (int i = 0; i < QX; ++i) {
             const int q = wv + 4 * i;
@@ -494,25 +514,25 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
 
     if (loader) {
         if (split < a.ntiles) issue(split, 0);
-        if constexpr (NST == 3) { if (split + a.nsplit < a.ntiles) issue(split + a.nsplit, 1); }
+        if constexpr (NST == 3) { if (split + nsplit < a.ntiles) issue(split + nsplit, 1); }
         // DMA instructions this wave issues per tile (the pieces are dealt round-robin to the four loader waves)
         const int mine = ((NQX - wv + 3) >> 2) + ((NQG - wv + 3) >> 2);
         int it = 0;
-        for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
+        for (int tile = split; tile < a.ntiles; tile += nsplit, ++it) {
             // my pieces of this tile have landed; after the barrier everybody's have, and the compute waves are done
             // with the previous tile, whose stage the next one may overwrite
             if constexpr (NST == 3) {
                 // the tile after this one may stay in flight: wait until at most its `mine` instructions are outstanding
-                if (tile + a.nsplit < a.ntiles && !(a.dbg & 1)) {
+                if (tile + nsplit < a.ntiles && !(a.dbg & 1)) {
                     if (mine == QX + QG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG) : "memory");
                     else if (mine == QX + QG - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG - 1) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG >= 2 ? QX + QG - 2 : 0) : "memory");
                 } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
-                if (tile + 2 * a.nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + 2 * a.nsplit, (it + 2) % 3);
+                if (tile + 2 * nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + 2 * nsplit, (it + 2) % 3);
             } else {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                if (tile + a.nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + a.nsplit, (it + 1) & 1);
+                if (tile + nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + nsplit, (it + 1) & 1);
             }
         }
         asm volatile("s_barrier" ::: "memory");                       // matches the compute waves' barrier before the fold
@@ -520,14 +540,14 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
         return;
     }
 
-    f32x16 acc[9];
+    f32x16 acc[TAPS];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     int it = 0;
-    for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
+    for (int tile = split; tile < a.ntiles; tile += nsplit, ++it) {
         asm volatile("s_barrier" ::: "memory");                       // the tile is in LDS (the loaders waited for their DMAs)
         if (a.dbg & 2) continue;
         const unsigned char* lx = smem + (NST == 3 ? it % 3 : (it & 1)) * ST_BYTES;
@@ -554,6 +574,17 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
                 }
                 gp[u] = lg + (wave_px + pxl) * RBG + ((RBG == 128) ? ((co_t ^ ((pxl >> 1) & 1)) << 6) : 0) + cb;
             }
+            // sub-pixel form: tap (tr, tc) of phase (pa, pb) reads halo row + pa + tr, halo column + pb + tc
+            const unsigned char* xq[SP ? 2 : 1][2];
+            if constexpr (SP) {
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int hx = kk + 4 * u + tc + pb;
+                        xq[tc][u] = lx + ((wave_px / TW + pa) * HWD + hx) * RBX + ((RBX == 128) ? ((ci_t ^ ((hx >> 1) & 1)) << 6) : 0) + cb;
+                    }
+            }
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 constexpr int dummy = 0; (void)dummy;
@@ -562,10 +593,10 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
                 const s16x4 g1 = tr_read(gp[1] + s * 16 * RBG);
                 const uint4 fb = __builtin_bit_cast(uint4, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int off = ((srow + t / 3) * HWD + scol) * RBX;
-                    const s16x4 x0 = tr_read(xp[t % 3][0] + off);
-                    const s16x4 x1 = tr_read(xp[t % 3][1] + off);
+                for (int t = 0; t < TAPS; ++t) {
+                    const int off = ((srow + (SP ? t >> 1 : t / 3)) * HWD + scol) * RBX;
+                    const s16x4 x0 = tr_read((SP ? xq[t & 1][0] : xp[t % 3][0]) + off);
+                    const s16x4 x1 = tr_read((SP ? xq[t & 1][1] : xp[t % 3][1]) + off);
                     const uint4 fa = __builtin_bit_cast(uint4, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
                     acc[t] = mfma16<T>(fa, fb, acc[t]);
                 }
@@ -580,7 +611,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
                 const int py = P / TW, px = P % TW;
                 const float g = *reinterpret_cast<const float*>(lg + P * RBG + ((chalf ^ ((px >> 1) & 1)) << 6) + choff);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
+                for (int t = 0; t < (SP ? 0 : 9); ++t) {
                     const int hx = px + t % 3;
                     const int rr = (py + t / 3) * HWD + hx;
                     const float x = *reinterpret_cast<const float*>(lx + rr * RBX + ((chalf ^ ((hx >> 1) & 1)) << 6) + choff);
@@ -592,38 +623,46 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
 
     // results: one 9 x 32 x 32 fp32 block per (ci_t, co_t) pair; waves that split the pixels fold through LDS
     asm volatile("s_barrier" ::: "memory");                           // every stage has been consumed by every compute wave
-    float* out = a.slab + (size_t)split * 9 * a.cin * a.cout;
+    float* out = a.slab + (size_t)blockIdx.x * 9 * a.cin * a.cout;
+    // sub-pixel form: which of the phase's two summed taps per axis holds 3x3 tap row kh / column kw
+    auto tap_of = [](int phase, int k3) { return phase ? (k3 == 2 ? 1 : 0) : (k3 != 0 ? 1 : 0); };
     if constexpr (PSPLIT == 1) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) {
+            if (SP ? (2 * tap_of(pa, t9 / 3) + tap_of(pb, t9 % 3) != t) : (t != t9)) continue;           // wave-uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + ci_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf, co = co0 + co_t * 32 + j;
                 // the slab is read back by the batched fold at the end of the gradient bucket, milliseconds later: non-temporal
                 // stores keep its 37.7 MB per layer from displacing the activations (measured: -0.07 ms per step)
                 if (ci < a.cin && co < a.cout) {
-                    if (a.nt_slab) __builtin_nontemporal_store(acc[t][r], &out[((size_t)t * a.cin + ci) * a.cout + co]);
-                    else out[((size_t)t * a.cin + ci) * a.cout + co] = acc[t][r];      // folded by the next launch: keep it cached
+                    if (a.nt_slab) __builtin_nontemporal_store(acc[t][r], &out[((size_t)t9 * a.cin + ci) * a.cout + co]);
+                    else out[((size_t)t9 * a.cin + ci) * a.cout + co] = acc[t][r];      // folded by the next launch: keep it cached
                 }
             }
+          }
     } else {
         // every compute wave parks its block in LDS (the stages are free), one barrier, then 256 threads add the PSPLIT copies in
         // a fixed order and write 16 bytes each (the first form took turns: PSPLIT read-modify-write rounds behind barriers and
         // 4-byte stores -- 10-20 us at the end of the 32-channel launches, with nothing to overlap them)
-        constexpr int BLK = 9 * 32 * 32, N4 = PAIRS * BLK / 4;
+        constexpr int BLK = TAPS * 32 * 32, N4 = PAIRS * BLK / 4, BLK9 = 9 * 32 * 32;
         float* red = reinterpret_cast<float*>(smem) + (part * PAIRS + pair) * BLK;   // [PSPLIT][PAIRS][9][32][32]
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < TAPS; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j] = acc[t][r];
         __syncthreads();
         const f32x4* r4 = reinterpret_cast<const f32x4*>(smem);
-        for (int e4 = tid; e4 < N4; e4 += 256) {
+        for (int o4 = tid; o4 < PAIRS * BLK9 / 4; o4 += 256) {
+            const int e = 4 * o4, pr = e / BLK9, rem = e % BLK9;
+            const int t = rem >> 10;                                             // 3x3 tap of the slab element
+            const int e4 = SP ? (pr * BLK + (2 * tap_of(pa, t / 3) + tap_of(pb, t % 3)) * 1024 + (rem & 1023)) / 4 : o4;
             f32x4 sum = r4[e4];
 #pragma unroll
             for (int p = 1; p < PSPLIT; ++p) sum += r4[p * N4 + e4];
-            const int e = 4 * e4, pr = e / BLK, rem = e % BLK;
-            const int t = rem >> 10, ci = ci0 + (pr % NCI) * 32 + ((rem >> 5) & 31), co = co0 + (pr / NCI) * 32 + (rem & 31);
+            const int ci = ci0 + (pr % NCI) * 32 + ((rem >> 5) & 31), co = co0 + (pr / NCI) * 32 + (rem & 31);
             if (ci < a.cin && co + 3 < a.cout) {
                 if (a.nt_slab) __builtin_nontemporal_store(sum, reinterpret_cast<f32x4*>(&out[((size_t)t * a.cin + ci) * a.cout + co]));
                 else *reinterpret_cast<f32x4*>(&out[((size_t)t * a.cin + ci) * a.cout + co]) = sum;
@@ -809,7 +848,7 @@ static Wg2Geom wgrad2_geometry(int n, int h, int w, int c0, int c1, int cout, in
     return g;
 }
 
-template <typename T, int TW, int CIB, int COB, bool WS>
+template <typename T, int TW, int CIB, int COB, bool WS, int TAPS = 9>
 static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
     constexpr int TH = 256 / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
@@ -817,19 +856,19 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
     constexpr int ST = NHROWS * CIB * ESZ + 256 * COB * ESZ;
     constexpr int NST = (WS && 3 * ST <= 160 * 1024) ? 3 : 2;
     // the wave-specialised kernel folds the pixel-split copies of a block through LDS: 4 x [9][32][32] floats
-    constexpr int FOLD = (WS && (ESZ == 4 || (CIB / 32) * (COB / 32) < 4)) ? 4 * 9 * 32 * 32 * 4 : 0;
+    constexpr int FOLD = (WS && (ESZ == 4 || (CIB / 32) * (COB / 32) < 4)) ? 4 * TAPS * 32 * 32 * 4 : 0;
     constexpr int lds = NST * ST > FOLD ? NST * ST : FOLD;
     static_assert(lds <= 160 * 1024, "LDS");
     static std::atomic<bool> attr_done{false};      // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!attr_done) {
         hipError_t e;
-        if constexpr (WS) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if constexpr (WS) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB, NST, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma<T, TW, CIB, COB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
         attr_done = true;
     }
     dim3 grid((unsigned)a.nsplit, (unsigned)cdiv(a.cin, CIB), (unsigned)cdiv(a.cout, COB));
-    if constexpr (WS) hipLaunchKernelGGL((wgrad3x3_ws<T, TW, CIB, COB, NST>), grid, dim3(512), lds, s, a);
+    if constexpr (WS) hipLaunchKernelGGL((wgrad3x3_ws<T, TW, CIB, COB, NST, TAPS>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((wgrad3x3_dma<T, TW, CIB, COB>), grid, dim3(256), lds, s, a);
     return check_launch();
 }
@@ -837,7 +876,28 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
 // the wave-specialised kernel for the 16-bit types, the four-wave LDS-DMA kernel for f32
 template <typename T, int TW, int CIB, int COB>
 static int launch_wgrad2(const WgArgs2& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) { if (a.sp) return launch_wgrad2x<T, TW, CIB, COB, true, 4>(a, s); }
     return launch_wgrad2x<T, TW, CIB, COB, sizeof(T) == 2>(a, s);
+}
+
+// UpSampling2D -> conv, 16-bit types, 2-D: geometry of the sub-pixel form (tiles of the LOW-resolution grid, 4 phases x pixel splits)
+static bool wgrad_subpixel_geometry(const rvip_wgrad3x3_desc* d, Wg2Geom& g) {
+    const char* e = getenv("RVIP_SUBPIX_WGRAD");                  // read per call (host side of a launch; tests flip it): 0 never, 2 wherever eligible
+    const bool on = !(e && e[0] == '0'), force = e && e[0] == '2';
+    const int kd = d->kd > 0 ? d->kd : 1;
+    if (!on || d->up0 != 1 || d->c1 != 0 || d->dtype == RVIP_F32 || kd != 1 || ((d->h | d->w) & 1)) return false;
+    g = wgrad2_geometry(d->n, d->h / 2, d->w / 2, d->c0, 0, d->cout, d->dtype);
+    if (!g.ok) return false;
+    // The form saves matrix work (16 / 36), not staging: every phase stages the X tile again.  It pays where the nine-tap kernel is
+    // bound by its MFMA / LDS-read side -- the 64 x 64 blocks (512 -> 256 .. 128 -> 64: 64 -> 45 us) -- and not on the 32-wide
+    // blocks of the full-resolution layer, whose tiles carry half the matrix work per staged byte (64 -> 32 at 256^2: 74 -> 77 us).
+    if (!force && !(g.cib == 64 && g.cob == 64)) return false;
+    const long long blocks = cdiv(d->c0, g.cib) * cdiv(d->cout, g.cob);
+    long long sp = 64 / blocks;                                   // 4 phases x sp pixel splits x blocks ~ one workgroup per CU
+    if (sp < 1) sp = 1;
+    if (sp > g.ntiles) sp = g.ntiles;
+    g.nsplit = (int)(4 * sp);
+    return true;
 }
 
 
@@ -867,7 +927,7 @@ extern "C" int rvip_conv3x3_wgrad_dot_rows(const rvip_wgrad3x3_desc* d);
 extern "C" size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout) {
     int tw, tx, ty, nt, ns;
     wgrad_geometry(n, h, w, cin, cout, tw, tx, ty, nt, ns);
-    int ns2 = nt < 256 ? nt : 256;                              // upper bound of the LDS-DMA kernel's split count
+    int ns2 = 4 * nt < 256 ? 4 * nt : 256;                      // upper bound of the LDS-DMA kernels' split count (sub-pixel form: 4 phases x <= nt pixel splits)
     if (ns2 > ns) ns = ns2;
     return (size_t)ns * 9 * cin * cout * sizeof(float);
 }
@@ -898,12 +958,16 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     const long long esz = RVIP_ESZ(d->dtype);
     const long long x0b = (long long)a.n * (a.h >> a.up0) * (a.w >> a.up0) * a.c0 * esz, x1b = (long long)a.n * a.h * a.w * a.c1 * esz;
     const long long dyb = (long long)a.n * a.h * a.w * a.cout * esz;
-    const Wg2Geom g2 = wgrad2_geometry(a.n, a.h, a.w, a.c0, a.c1, a.cout, d->dtype);
+    Wg2Geom g2;
+    const bool sp = wgrad_subpixel_geometry(d, g2);
+    if (!sp) g2 = wgrad2_geometry(a.n, a.h, a.w, a.c0, a.c1, a.cout, d->dtype);
     if (g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) {
         WgArgs2 b;
         b.x0 = a.x0; b.x1 = a.x1; b.dy = a.dy; b.slab = a.slab;
         b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.dy_bytes = (unsigned)dyb;
         b.c0 = a.c0; b.c1 = a.c1; b.up0 = a.up0; b.zs = a.zs; b.n = a.n; b.h = a.h; b.w = a.w; b.cin = a.cin; b.cout = a.cout;
+        b.sp = sp ? 1 : 0;
+        if (sp) { b.up0 = 0; b.h = a.h / 2; b.w = a.w / 2; }     // X is read as it lies; tiles, borders and splits are those of its grid
         b.tiles_x = g2.tiles_x; b.tiles_y = g2.tiles_y; b.ntiles = g2.ntiles; b.nsplit = g2.nsplit;
         { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
         b.nt_slab = d->defer_fold ? 1 : 0;        // (measured equal either way for the fold that follows at once: 6 452 vs 6 451 slices/s)
@@ -967,7 +1031,8 @@ extern "C" int rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d) {
     const long long esz = RVIP_ESZ(d->dtype);
     const long long x0b = (long long)d->n * (d->h >> up) * (d->w >> up) * d->c0 * esz, x1b = (long long)d->n * d->h * d->w * d->c1 * esz;
     const long long dyb = (long long)d->n * d->h * d->w * d->cout * esz;
-    const Wg2Geom g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype);
+    Wg2Geom g2;
+    if (!wgrad_subpixel_geometry(d, g2)) g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype);
     if (g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) return g2.nsplit;
     int tw, tx, ty, nt, ns;
     wgrad_geometry(d->n, d->h, d->w, d->c0 + d->c1, d->cout, tw, tx, ty, nt, ns);

@@ -3,6 +3,7 @@
 to the result scale (fp32 MFMA = exact fp32 products, different summation order); bf16 path: inputs are
 rounded to bf16 first, so only accumulation order and the output rounding differ (2^-8 relative)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -365,6 +366,66 @@ def test_upsample_conv_subpixel_form(shape, dtype):
     scale = float(np.abs(ref).max())
     tol = (2.0 ** -6 if dtype != 'f32' else 2e-5) * scale      # bf16: + one rounding of the summed taps
     assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max() / scale
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(2, 16, 32, 32, 32), (3, 24, 40, 64, 32), (1, 32, 32, 128, 64), (2, 64, 64, 64, 32), (1, 64, 128, 72, 40),
+                                   (5, 8, 8, 8, 8), (2, 32, 64, 256, 128)])
+def test_upsample_conv_wgrad_subpixel_form(shape, dtype):
+    """Weight gradient of UpSampling2D(2) -> Conv2D(3x3, same) in its sub-pixel form (16-bit types: wgrad3x3_ws<..., TAPS = 4>, four
+    2x2-tap phase contractions of the low-resolution X with the stride-2 phase images of dY, each workgroup writing its four blocks into
+    the nine-tap slab positions they belong to) against the same entry point with RVIP_SUBPIX_WGRAD=0 (the nine-tap contraction over
+    the virtually up-sampled X) -- fp32 summation order only -- and against the float64 oracle.  f32 does not take the form."""
+    n, h, w, ci, co = shape                     # h, w = up-sampled size = size of dy
+    rng = np.random.default_rng(sum(shape) + 5)
+    lo = rnd(rng.standard_normal((n, h // 2, w // 2, ci)), dtype)
+    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
+    wt = (rng.standard_normal((3, 3, ci, co)) * 0.2).astype(np.float32)
+    lod, dyd, wm = up(lo, dtype), up(dy, dtype), f32(wt)
+    L = N.lib()
+    wsb = L.rvip_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    wsd = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+
+    def run(flag, dot):
+        old = os.environ.get('RVIP_SUBPIX_WGRAD')
+        os.environ['RVIP_SUBPIX_WGRAD'] = flag
+        try:
+            wsd.fill_(float('nan'))
+            dw = torch.full((3, 3, ci, co), 7.0, dtype=torch.float32, device=dev())
+            g = N.Wgrad3x3Desc()
+            g.x0, g.c0, g.up0, g.x1, g.c1 = lod.data_ptr(), ci, 1, None, 0
+            g.dy, g.dw = dyd.data_ptr(), dw.data_ptr()
+            g.n, g.h, g.w, g.cout, g.dtype = n, h, w, co, ndt(dtype)
+            g.workspace, g.workspace_bytes = wsd.data_ptr(), wsb
+            rows = None
+            if dot:
+                nr = L.rvip_conv3x3_wgrad_dot_rows(C.byref(g))
+                rows = torch.full((nr, ci), 7.0, dtype=torch.float64, device=dev())
+                g.w_master, g.dot_rows, g.dot_rows_bytes = wm.data_ptr(), rows.data_ptr(), rows.numel() * 8
+            ns = L.rvip_conv3x3_wgrad_splits(C.byref(g))
+            N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+            torch.cuda.synchronize()
+            return down(dw).astype(np.float64), (rows.cpu().numpy().sum(0) if dot else None), ns
+        finally:
+            if old is None:
+                del os.environ['RVIP_SUBPIX_WGRAD']
+            else:
+                os.environ['RVIP_SUBPIX_WGRAD'] = old
+    dw9, rows9, ns9 = run('0', True)
+    dw4, rows4, ns4 = run('2', True)              # 2: the form wherever it is eligible (the default takes it for 64 x 64 blocks only)
+    dw4b, _, _ = run('2', False)
+    np.testing.assert_array_equal(dw4, dw4b)                 # plain fold and dot-row fold of the same slabs
+    assert 0 < ns4 * 9 * ci * co * 4 <= wsb and 0 < ns9 * 9 * ci * co * 4 <= wsb
+    if dtype == 'f32':
+        np.testing.assert_array_equal(dw4, dw9)
+        assert ns4 == ns9
+    else:
+        assert ns4 % 4 == 0
+        scale = np.abs(dw9).max()
+        assert np.abs(dw4 - dw9).max() <= 2e-5 * scale, np.abs(dw4 - dw9).max() / scale
+        assert np.abs(rows4 - rows9).max() <= 2e-5 * np.abs(rows9).max() + 1e-9
+    _, rdw, _ = O.conv2d_same_bwd(O.upsample_nearest_fwd(lo).astype(np.float64), wt.astype(np.float64), dy.astype(np.float64))
+    close(dw4, rdw, 'f32', 'sub-pixel wgrad vs oracle')        # operands are exact in the storage type: fp32 accumulation is the only error
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
