@@ -118,6 +118,7 @@ SIGNATURES = {
     'rvip_bn_stats_finalize': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp, vp]),
     'rvip_pack_conv3x3_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_pack_subpixel_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'rvip_pack_subpixel_dgrad_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'rvip_pack_all_conv3x3_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'rvip_pack_all_conv3x3_weights_tick': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     'rvip_conv3x3_wgrad_workspace': (C.c_size_t, [C.c_int] * 5),

@@ -856,6 +856,11 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.y * BN;
     const int ph = (TAPS == 4) ? (int)blockIdx.z : 0, pa = ph >> 1, pb = ph & 1;      // output phase of the sub-pixel form
+    // subpix == 2 (TAPS = 4, gridDim.z = 1): the DATA GRADIENT of the sub-pixel form.  x0 is the full-resolution gradient [N, 2h, 2w, c0],
+    // the result the low-resolution [N, h, w, cout]; the K loop runs over kd = 4 source phases (al, be) x the channel chunks: chunk
+    // (al, be, c) reads x0[2y + al][2x + be] (an addressing mode of the loaders) through the 2x2 window at halo origin (1 - al, 1 - be)
+    // with the summed taps of rvip_pack_subpixel_dgrad_weights -- 16 instead of 36 multiply-adds per low-resolution pixel, no 2x2-sum epilogue.
+    const bool s2d = TAPS == 4 && a.subpix == 2;
     const int nch = (a.cin + KCE - 1) / KCE;         // chunks per depth tap
     const int nchunks = nch * a.kd;
     const bool resident = a.wres > 0;
@@ -895,7 +900,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             ich[i] = (dslot ^ slot_swz(hx)) * VE;
             ihy[i] = (row < NHALO) ? hy - 1 : -100000;
             ihx[i] = hx - 1;
-            irel0[i] = ((((hy - 1) >> a.up0) * w0 + ((hx - 1) >> a.up0)) * a.c0 + ich[i]) * (int)sizeof(T);
+            irel0[i] = s2d ? ((2 * (hy - 1) * 2 * a.w + 2 * (hx - 1)) * a.c0 + ich[i]) * (int)sizeof(T)
+                           : ((((hy - 1) >> a.up0) * w0 + ((hx - 1) >> a.up0)) * a.c0 + ich[i]) * (int)sizeof(T);
             irel1[i] = (((hy - 1) * a.w + (hx - 1)) * a.c1 + ich[i]) * (int)sizeof(T);
         }
         unsigned t0[QI], t1[QI];                         // prepared tile: per-piece offsets (border test folded in)
@@ -916,7 +922,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             const int n_out = (int)(bx / (unsigned)a.tiles_y);
             const int ty0 = (int)ty_i * TH, tx0 = (int)tx_i * TW;
             p_nmod = a.depth > 1 ? n_out % a.depth : 0;
-            p_tb0 = ((n_out * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 * (int)sizeof(T);
+            p_tb0 = s2d ? ((n_out * 2 * a.h + 2 * ty0) * 2 * a.w + 2 * tx0) * a.c0 * (int)sizeof(T)
+                        : ((n_out * h0 + (ty0 >> a.up0)) * w0 + (tx0 >> a.up0)) * a.c0 * (int)sizeof(T);
             p_tb1 = ((n_out * a.h + ty0) * a.w + tx0) * a.c1 * (int)sizeof(T);
             if constexpr (STATS == 3) {
                 const bool ok = mb_mine && ty0 + mb_row < a.h && tx0 + mb_x < a.w;
@@ -954,14 +961,15 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
         // stages chunk kc of the PREPARED tile
         auto issue_input = [&](int kc, int stage) __attribute__((always_inline)) {
             const int kdi = a.kd > 1 ? kc / nch : 0;
-            const int dsh = kdi - (a.kd >> 1);               // depth tap: the image dsh slices away, zeros outside the volume
+            const int dsh = s2d ? 0 : kdi - (a.kd >> 1);     // depth tap: the image dsh slices away, zeros outside the volume
             const bool dok = (unsigned)(p_nmod + dsh) < (unsigned)a.depth;
+            const int phoff = s2d ? ((kdi >> 1) * 2 * a.w + (kdi & 1)) * a.c0 * (int)sizeof(T) : 0;      // source phase (al, be) = (kdi >> 1, kdi & 1)
             const int cbase = (kc - kdi * nch) * KCE;
             const bool from0 = cbase < a.c0;                 // chunks never straddle the two sources (host checks)
             const int cb = from0 ? cbase : cbase - a.c0;
             const int crem = dok ? (from0 ? a.c0 : a.c1) - cb : 0;
             const unsigned li0 = lds_base + stage * IN_BYTES + lwv * 1024;                      // + i * 4096 per piece
-            const unsigned base = (unsigned)((from0 ? p_tb0 + dsh * img0_bytes : p_tb1 + dsh * img1_bytes) + cb * (int)sizeof(T));
+            const unsigned base = (unsigned)((from0 ? p_tb0 + dsh * img0_bytes : p_tb1 + dsh * img1_bytes) + cb * (int)sizeof(T) + phoff);
             if constexpr (STATS == 3) {
                 if (kc == 0) {                               // first chunk of a tile: its mask words ride along (wave-uniform)
                     if (lwv < NCT * NPM) dma16(rsm, p_mb, lds_base + a.lds_mb_off + mb_par * MB_TILE + lwv * 1024);
@@ -1033,6 +1041,13 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     const int row0 = (wv * (NPT * 32)) / TW;                              // first tile row of this wave
     // one address register per tap column / for the weights: a second pixel block of a tile row is 16 halo columns (1 KiB) further,
     // a further channel block 16 rows (1 KiB) further, and neither moves bit 2 of the swizzle key -- compile-time offsets
+    int in_base3[3];                                                      // halo column i16 + 0 / 1 / 2
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+        const int hx = i16 + tx;
+        in_base3[tx] = (row0 * HWD + hx) * 64 + ((kq ^ slot_swz(hx)) << 4);
+    }
+    // TAPS = 4: the window's first column is halo column pb (forward phase, per workgroup) / 1 - be (data gradient, per chunk)
     int in_base[TXN];
 #pragma unroll
     for (int tx = 0; tx < TXN; ++tx) {
@@ -1075,6 +1090,15 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             asm volatile("s_barrier" ::: "memory");              // item `it` is in LDS (the loaders waited for their DMAs)
             if (a.dbg & 2) continue;
             const unsigned char* sin = lin + (it & 1) * IN_BYTES + (TAPS == 4 ? pa * HWD * 64 : 0);
+            if constexpr (TAPS == 4) {
+                if (s2d) {                                           // source phase of this chunk -> window origin (wave-uniform)
+                    const int kdi = kc / nch;
+                    sin = lin + (it & 1) * IN_BYTES + (1 - (kdi >> 1)) * HWD * 64;
+                    const bool c1st = (kdi & 1) != 0;                // be = 1: window starts at halo column 0
+                    in_base[0] = c1st ? in_base3[0] : in_base3[1];
+                    in_base[1] = c1st ? in_base3[1] : in_base3[2];
+                }
+            }
             const unsigned char* sw = lw + (resident ? kc : (it & 1)) * W_BYTES;
             // one tap = one K = 32 step, issued as two half steps (all channel blocks x half of the pixel blocks); the weight
             // fragments of the next tap and the pixel fragments of the next half step are read above the MFMAs of this one
@@ -1151,8 +1175,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                         int gy, gx;
                         block_pixel(blk, gy, gx);
                         ok[s2] = gy < a.h && gx < a.w;
-                        const unsigned pix = TAPS == 4 ? (unsigned)((n * 2 * a.h + 2 * gy + pa) * 2 * a.w + 2 * gx + pb)
-                                                       : (unsigned)((n * a.h + gy) * a.w + gx);
+                        const unsigned pix = (TAPS == 4 && !s2d) ? (unsigned)((n * 2 * a.h + 2 * gy + pa) * 2 * a.w + 2 * gx + pb)
+                                                                 : (unsigned)((n * a.h + gy) * a.w + gx);
                         unsigned mword = 0, sword = 0;
                         if constexpr (STATS == 3) {
                             if (gated) mword = *reinterpret_cast<const unsigned*>(smem + a.lds_mb_off + mb_par * MB_TILE + cp * MB_PLANE +
@@ -1315,15 +1339,18 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     constexpr int LDS_MAX = 160 * 1024;
     used = false;
     const int nchunks = (int)cdiv(a0.cin, KCE) * a0.kd;
-    const long long x0b = (long long)a0.n * (a0.h >> a0.up0) * (a0.w >> a0.up0) * a0.c0 * (long long)sizeof(T);
+    const long long x0b = (a0.subpix == 2 ? 4LL : 1LL) * a0.n * (a0.h >> a0.up0) * (a0.w >> a0.up0) * a0.c0 * (long long)sizeof(T);
     const long long x1b = (long long)a0.n * a0.h * a0.w * a0.c1 * (long long)sizeof(T);
     const long long wpb = (TAPS == 4 ? 16LL : 9LL * a0.kd) * a0.cin * a0.cout * (long long)sizeof(T);
     if ((TAPS == 4) != (a0.subpix != 0)) return RVIP_OK;
+    constexpr bool WS16 = V5 && sizeof(T) == 2 && NPIX / (32 * NCW) <= 2;      // (igemm_ws_kernel's choice)
+    if (a0.subpix == 2 && !WS16) return RVIP_OK;           // the data-gradient form of the sub-pixel up-conv lives in the 16-bit kernel only
+    const bool sp_fwd = TAPS == 4 && a0.subpix == 1;        // forward form: four output phases = blockIdx.z, result at twice the grid
     if (x0b >= (1LL << 31) || x1b >= (1LL << 31) || wpb >= (1LL << 31)) return RVIP_OK;
     if (a0.c1 > 0 && a0.c0 % KCE) return RVIP_OK;
     if (a0.y1 && a0.csplit % 32) return RVIP_OK;
     const long long npx = (long long)a0.n * a0.h * a0.w;
-    const long long yb = (a0.down2 ? npx / 4 : (TAPS == 4 ? npx * 4 : npx)) * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
+    const long long yb = (a0.down2 ? npx / 4 : (sp_fwd ? npx * 4 : npx)) * (a0.y1 ? a0.csplit : a0.cout) * (long long)sizeof(T), y1b = a0.y1 ? npx * (a0.cout - a0.csplit) * (long long)sizeof(T) : 0;
     if (yb >= (1LL << 31) || y1b >= (1LL << 31)) return RVIP_OK;
     if (sizeof(T) == 2 && a0.cout % 8) return RVIP_OK;
     ConvArgs2 b;
@@ -1336,7 +1363,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     b.mbits = gated ? a0.mbits : nullptr; b.mbits_c = gated ? a0.mbits_c : 0; b.mscale = a0.mscale;
     b.mbits_bytes = gated ? (unsigned)((long long)cdiv(a0.mbits_c, 32) * npx * 4) : 0u;
     b.sbits = (!stats && a0.sbits) ? a0.sbits : nullptr;
-    b.sbits_bytes = b.sbits ? (unsigned)((long long)cdiv(a0.cout, 32) * (TAPS == 4 ? npx * 4 : npx) * 4) : 0u;
+    b.sbits_bytes = b.sbits ? (unsigned)((long long)cdiv(a0.cout, 32) * (sp_fwd ? npx * 4 : npx) * 4) : 0u;
     if ((gated || b.sbits) && (a0.cout % 8 || a0.down2 || (gated && a0.mbits_c % 32 && a0.mbits_c != a0.cout))) return RVIP_OK;      // (not served: the caller sees used == false)
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
@@ -1351,6 +1378,10 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (!dry && lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, 0, TAPS, NCW>()),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        if constexpr (TAPS == 4 && WS16) {
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, 2, TAPS, NCW>()),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        }
         if constexpr (TAPS == 9) {
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, 1, TAPS, NCW>()),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
@@ -1364,19 +1395,24 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     }
     const int cot = (int)cdiv(a0.cout, NCT * 32);
     if (cot > 1) b.nt_in = 0;       // several workgroup columns re-read the same input tile: keep it cached (measured)
-    constexpr int NZ = TAPS == 4 ? 4 : 1;
+    const int NZ = sp_fwd ? 4 : 1;
     int gx = 256 / (cot * NZ);                     // one workgroup per CU (LDS-limited), persistent over the pixel tiles
     if (gx < 1) gx = 1;
     if (gx > b.ntiles) gx = b.ntiles;
     b.stats = stats;
     { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
     if (rows_out) *rows_out = gx;
+    if (stats && TAPS == 4 && (!WS16 || a0.subpix != 2 || smode != 2 || gated)) return dry ? RVIP_OK : RVIP_EUNSUPPORTED;
     if (dry) { used = true; return RVIP_OK; }
     if (stats) {
         if constexpr (TAPS == 9) {
             if (smode == 2 && gated) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 3, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
             else if (smode == 2) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 2, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
             else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 1, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
+        } else if constexpr (WS16) {
+            // TAPS = 4: only the data-gradient form carries partial rows, and only plain column sums
+            if (a0.subpix != 2 || smode != 2 || gated) return RVIP_EUNSUPPORTED;
+            hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 2, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
         } else return RVIP_EUNSUPPORTED;
     } else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 0, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
     used = true;
@@ -1676,9 +1712,32 @@ __device__ __forceinline__ void pack_subpixel_range(const float* __restrict__ w,
     }
 }
 
+// The data gradient of the same layer (rvip_conv3x3_desc.subpix = 2): w_dphase[2 al + be][2 u + v][ci][co] (ci = the layer's INPUT
+// channel = the result's channel, co = its output channel = the contraction) = sum of W[kh][kw][ci][co] over the taps through which
+// source phase (al, be) of the gradient -- row 2y' + al -- at window position u (low-resolution row y - al + u) reaches the
+// low-resolution pixel y:  al = 0: u = 0 <- kh {1, 2}, u = 1 <- {0};  al = 1: u = 0 <- {2}, u = 1 <- {0, 1}  (columns alike).
 template <typename T>
-__global__ __launch_bounds__(256) void pack_subpixel_kernel(const float* __restrict__ w, int cin, int cout, T* __restrict__ wp) {
-    pack_subpixel_range<T>(w, cin, cout, wp);
+__device__ __forceinline__ void pack_subpixel_dgrad_range(const float* __restrict__ w, int cin, int cout, T* __restrict__ wp) {
+    const long long total = 16LL * cin * cout;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i % cout);
+        const int ci = (int)((i / cout) % cin);
+        const int tap = (int)((i / ((long long)cin * cout)) & 3), ph = (int)(i / (4LL * cin * cout));
+        const int al = ph >> 1, be = ph & 1, u = tap >> 1, v = tap & 1;
+        const int kh0 = al == 0 ? (u == 0 ? 1 : 0) : (u == 0 ? 2 : 0), kh1 = al == 0 ? (u == 0 ? 2 : 0) : (u == 0 ? 2 : 1);
+        const int kw0 = be == 0 ? (v == 0 ? 1 : 0) : (v == 0 ? 2 : 0), kw1 = be == 0 ? (v == 0 ? 2 : 0) : (v == 0 ? 2 : 1);
+        float acc = 0.f;
+        for (int kh = kh0; kh <= kh1; ++kh)
+            for (int kw = kw0; kw <= kw1; ++kw) acc += w[((size_t)(kh * 3 + kw) * cin + ci) * cout + co];
+        if constexpr (sizeof(T) == 4) wp[i] = acc;
+        else wp[i].bits = Vec<T>::enc(acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_subpixel_kernel(const float* __restrict__ w, int cin, int cout, T* __restrict__ wp, int dgrad) {
+    if (dgrad) pack_subpixel_dgrad_range<T>(w, cin, cout, wp);
+    else pack_subpixel_range<T>(w, cin, cout, wp);
 }
 
 // all 3x3 kernels of the model in ONE launch: table-driven re-layout (see pack_w_kernel)
@@ -1698,8 +1757,9 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     const float* w = theta + en.w_off;
     T* wf = wf_base + en.f_off;
     T* wd = wd_base + en.d_off;
-    if (en.reserved == 1) {              // mode 1: the phase kernels of the sub-pixel up-conv form, [4][4][Cout][Cin] at f_off
-        pack_subpixel_range<T>(w, en.cin, en.cout, wf);
+    if (en.reserved == 1) {              // mode 1: the phase kernels of the sub-pixel up-conv form, [4][4][Cout][Cin] at f_off,
+        pack_subpixel_range<T>(w, en.cin, en.cout, wf);               // and of its data gradient, [4][4][Cin][Cout] at d_off
+        pack_subpixel_dgrad_range<T>(w, en.cin, en.cout, wd);
         return;
     }
     const int nbi = (en.cin + TI - 1) / TI, nbo = (en.cout + TO - 1) / TO;
@@ -1792,12 +1852,15 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     a.down2 = d->down2 ? 1 : 0;
     if (a.down2 && (d->y1 || d->bias || d->act != RVIP_ACT_NONE || ((d->h | d->w) & 1))) return RVIP_EINVAL;
     a.nt_in = d->stream_in ? 1 : 0;
-    a.subpix = d->subpix ? 1 : 0;
+    a.subpix = d->subpix == 2 ? 2 : (d->subpix ? 1 : 0);
     a.mbits = nullptr; a.mbits_c = 0; a.mscale = 1.f; a.sbits = nullptr;
     a.sums_from = (d->sums_from > 0 && d->sums_from % 32 == 0) ? d->sums_from : 0;
-    if (a.subpix) {                      // UpSampling2D -> conv as four phase convolutions on the low-resolution grid
+    if (a.subpix == 1) {                 // UpSampling2D -> conv as four phase convolutions on the low-resolution grid
         if (d->up0 != 1 || d->c1 || d->y1 || a.kd != 1 || a.down2) return RVIP_EINVAL;
         a.up0 = 0; a.h = d->h / 2; a.w = d->w / 2;
+    } else if (a.subpix == 2) {          // its data gradient: x0 at the up-sampled size h x w, result on the h/2 x w/2 grid, K loop over four source phases
+        if (d->up0 || d->c1 || d->y1 || a.kd != 1 || a.down2 || d->bias || d->act != RVIP_ACT_NONE || ((d->h | d->w) & 1) || d->dtype == RVIP_F32) return RVIP_EINVAL;
+        a.h = d->h / 2; a.w = d->w / 2; a.kd = 4;
     }
     return RVIP_OK;
 }
@@ -1862,7 +1925,7 @@ extern "C" int rvip_conv3x3_fwd_stats(const rvip_conv3x3_desc* d, float* stats_w
 // Data-gradient launches: the per-channel sums of the STORED result as partial rows sums_ws[rows][cout] (include/rvip_hip.h)
 extern "C" int rvip_conv3x3_fwd_sums_rows(const rvip_conv3x3_desc* d) {
     ConvArgs a;
-    if (conv_args_from_desc(d, a) != RVIP_OK || d->subpix) return 0;
+    if (conv_args_from_desc(d, a) != RVIP_OK || d->subpix == 1 || (d->subpix == 2 && d->mask_bits)) return 0;
     if (d->mask_bits) { a.mbits = d->mask_bits; a.mbits_c = d->mask_channels; a.mscale = d->mask_scale; }
     bool used = false; int rows = 0;
     static float dummy;                                   // dry run: only tells the dispatcher that partial rows are wanted
@@ -2005,9 +2068,22 @@ extern "C" int rvip_pack_subpixel_weights(const float* w, int cin, int cout, int
     const long long total = 16LL * cin * cout;
     const int blocks = (int)(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == RVIP_BF16) hipLaunchKernelGGL(pack_subpixel_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (bf16_t*)w_phase);
-    else if (dtype == RVIP_F16) hipLaunchKernelGGL(pack_subpixel_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (f16_t*)w_phase);
-    else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_subpixel_kernel<float>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (float*)w_phase);
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(pack_subpixel_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (bf16_t*)w_phase, 0);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(pack_subpixel_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (f16_t*)w_phase, 0);
+    else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_subpixel_kernel<float>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (float*)w_phase, 0);
+    else return RVIP_EINVAL;
+    return check_launch();
+}
+
+extern "C" int rvip_pack_subpixel_dgrad_weights(const float* w, int cin, int cout, int dtype, void* w_phase, void* stream) {
+    (void)hipGetLastError();
+    if (!w || !w_phase || cin <= 0 || cout <= 0) return RVIP_EINVAL;
+    const long long total = 16LL * cin * cout;
+    const int blocks = (int)(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RVIP_BF16) hipLaunchKernelGGL(pack_subpixel_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (bf16_t*)w_phase, 1);
+    else if (dtype == RVIP_F16) hipLaunchKernelGGL(pack_subpixel_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (f16_t*)w_phase, 1);
+    else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_subpixel_kernel<float>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (float*)w_phase, 1);
     else return RVIP_EINVAL;
     return check_launch();
 }

@@ -97,13 +97,14 @@ class ParamStore:
         self.wd_all = torch.empty(max(off, ALIGN), dtype=self.tdtype, device=device)
         tab = (N.PackEntry * max(len(entries), 1))()
         self.pack_max = 1
-        self.subpix = {}
+        self.subpix, self.subpix_d = {}, {}
         for i, (name, w_off, p_off, cin, cout, mode) in enumerate(entries):
             tab[i].w_off, tab[i].f_off, tab[i].d_off, tab[i].cin, tab[i].cout = w_off, p_off, p_off, cin, cout
             tab[i].taps, tab[i].mode = self.taps, mode
             k = (16 if mode else self.taps) * cin * cout
             if mode:
                 self.subpix[name] = self.wf_all[p_off:p_off + k]
+                self.subpix_d[name] = self.wd_all[p_off:p_off + k]      # the phase kernels of the layer's data gradient (subpix = 2)
             else:
                 self.packed[name] = (self.wf_all[p_off:p_off + k], self.wd_all[p_off:p_off + k])
             self.pack_max = max(self.pack_max, k)
@@ -579,6 +580,13 @@ class Engine:
                 dg.y, dg.y1, dg.csplit = self.grd[st.src0].data_ptr(), self.gskip[st.src1].data_ptr(), st.c0
             elif st.up0 == 1 and fuse_down_on:      # UpSampling2D: the 2x2 block sums leave the data-gradient epilogue directly
                 dg.y, dg.down2 = self.grd[st.src0].data_ptr(), 1
+                if st.conv in P.subpix_d and dt != N.F32 and self.kd == 1 and os.environ.get('RVIP_SUBPIX_DGRAD', '1') != '0':
+                    # ... or, 16-bit types, the gradient arrives on the low-resolution grid at once: the sub-pixel form of the same launch
+                    # (four source phases x 2x2 summed taps, 16 instead of 36 multiply-adds per low-resolution pixel)
+                    sp = N.Conv3x3Desc.from_buffer_copy(dg)
+                    sp.down2, sp.subpix, sp.w_packed = 0, 2, P.subpix_d[st.conv].data_ptr()
+                    if L.rvip_conv3x3_fwd_sums_rows(C.byref(sp)) > 0:
+                        dg = sp
             elif st.up0:
                 dg.y = self.up_tmp[st.conv].data_ptr()
             else:

@@ -96,7 +96,14 @@ typedef struct rvip_conv3x3_desc {
     int32_t      down2;
     /* subpix != 0 (with up0 = 1, no x1 / y1): the UpSampling2D -> conv pair in its sub-pixel form - four 2x2-tap phase
      * convolutions on the low-resolution x0, 16 instead of 36 multiply-adds per low-resolution pixel; same result up to
-     * the summation order of the taps.  w_packed is then the [4][4][Cout][C0] block of rvip_pack_subpixel_weights. */
+     * the summation order of the taps.  w_packed is then the [4][4][Cout][C0] block of rvip_pack_subpixel_weights.
+     * subpix = 2 (ABI 6; 16-bit types, rvip_conv3x3_fwd / rvip_conv3x3_fwd_sums without mask_bits; up0 = 0, no x1 / y1 / bias /
+     * activation / down2): the DATA GRADIENT of that pair in the same form.  x0 is the gradient at the up-sampled size [N, h, w, C0],
+     * y the gradient of the low-resolution tensor [N, h/2, w/2, Cout]; the contraction runs over the four source phases
+     * x0[2y + al][2x + be] (an addressing mode, nothing is re-laid out) x 2x2 summed taps x C0 -- 16 instead of 36 multiply-adds per
+     * low-resolution pixel and no 2x2-sum epilogue (down2 is the nine-tap form of the same launch).  w_packed is the
+     * [4][4][Cout][C0] block of rvip_pack_subpixel_dgrad_weights (summed taps rounded once, like the forward form's).
+     * RVIP_EUNSUPPORTED for shapes the LDS-DMA kernel does not serve: fall back to down2. */
     int32_t      subpix;
     /* stream_in != 0: hint that this launch is the last reader of x0 for a while (e.g. the data gradient reading dz):
      * its input is fetched with the non-temporal cache policy. */
@@ -144,14 +151,17 @@ int rvip_conv3x3_fwd_sums(const rvip_conv3x3_desc* d, float* sums_ws, size_t sum
 int rvip_pack_conv3x3_weights(const float* w_hwio, int cin, int cout, int dtype,
                               void* w_fwd, void* w_dgrad, void* stream);
 
-/* Phase kernels of the sub-pixel form of UpSampling2D -> conv (rvip_conv3x3_desc.subpix): w_phase[2a+b][2u+v][Cout][Cin]. */
+/* Phase kernels of the sub-pixel form of UpSampling2D -> conv (rvip_conv3x3_desc.subpix): w_phase[2a+b][2u+v][Cout][Cin];
+ * rvip_pack_subpixel_dgrad_weights: those of its data gradient (subpix = 2), w_dphase[2al+be][2u+v][Cin][Cout] (Cin of the LAYER
+ * = the channels of that launch's result). */
 int rvip_pack_subpixel_weights(const float* w_hwio, int cin, int cout, int dtype, void* w_phase, void* stream);
+int rvip_pack_subpixel_dgrad_weights(const float* w_hwio, int cin, int cout, int dtype, void* w_dphase, void* stream);
 
 /* The same re-layout for ALL 3x3 kernels of a model in one launch.  `theta` is the flat fp32 parameter block;
  * `table` is a DEVICE array of `entries` records {int64 w_off (floats into theta), int64 f_off, int64 d_off
  * (elements into wf_base / wd_base), int32 cin, int32 cout, int32 taps (9, or 27 for a 3x3x3 kernel; 0 = 9),
  * int32 mode (0: the two operands above; 1: the [4][4][Cout][Cin] phase kernels of rvip_pack_subpixel_weights at
- * f_off, d_off unused)}; max_elems = max over entries of taps*cin*cout. */
+ * f_off and the [4][4][Cin][Cout] ones of rvip_pack_subpixel_dgrad_weights at d_off)}; max_elems = max over entries of taps*cin*cout. */
 typedef struct rvip_pack_entry { long long w_off, f_off, d_off; int32_t cin, cout; int32_t taps, mode; } rvip_pack_entry;
 int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
                                   void* wf_base, void* wd_base, void* stream);

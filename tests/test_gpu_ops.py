@@ -343,6 +343,73 @@ def test_conv3x3_dgrad_with_fused_2x2_sum(shape, dtype):
     close(down(glo), O.upsample_nearest_bwd(rdx), dtype, 'down2 dgrad')
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(2, 48, 80, 32, 64), (1, 32, 32, 16, 40), (2, 16, 144, 8, 8), (1, 64, 64, 64, 32), (3, 32, 32, 128, 64),
+                                   (1, 64, 128, 40, 72), (2, 8, 8, 256, 128)])
+def test_upsample_conv_dgrad_subpixel_form(shape, dtype):
+    """subpix = 2: the data gradient of UpSampling2D -> Conv2D in its sub-pixel form (K loop over the four source phases of the
+    full-resolution gradient x 2x2 summed taps; result on the low-resolution grid, no 2x2-sum epilogue) against the float64 oracle
+    (conv with the rotated kernel, then the 2x2 sum), with and without the column sums of rvip_conv3x3_fwd_sums -- and the nine-tap
+    down2 launch next to it.  bf16 / f16: the summed taps are rounded once (as in the forward form)."""
+    n, h, w, ci, co = shape                     # forward conv ci -> co at the up-sampled size h x w; the gradient dy is [n, h, w, co]
+    rng = np.random.default_rng(sum(shape) + 1)
+    wt = (rng.standard_normal((3, 3, ci, co)) * 0.2).astype(np.float32)
+    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
+    wm, dyd = f32(wt), up(dy, dtype)
+    wph = torch.empty(16 * ci * co, dtype=tdt(dtype), device=dev())
+    N.call('rvip_pack_subpixel_dgrad_weights', P(wm), ci, co, ndt(dtype), P(wph), stream())
+    L = N.lib()
+
+    def desc(out):
+        d = conv_desc(dyd, co, 0, None, 0, wph, None, out, None, 0, n, h, w, ci, 0, dtype)
+        d.subpix = 2
+        return d
+    g0 = torch.full((n, h // 2, w // 2, ci), 5.0, dtype=tdt(dtype), device=dev())
+    N.call('rvip_conv3x3_fwd', C.byref(desc(g0)), stream())
+    g1 = torch.full_like(g0, 6.0)
+    d1 = desc(g1)
+    nr = L.rvip_conv3x3_fwd_sums_rows(C.byref(d1))
+    assert nr > 0
+    rows = torch.full((nr, ci), 7.0, dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_fwd_sums', C.byref(d1), P(rows), C.c_size_t(rows.numel() * 4), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g1)
+    # oracle: with the kernel as the launch sees it (summed taps rounded to the storage type) the result is exact up to accumulation order
+    ref = O.upsample_nearest_bwd(O.conv2d_same_bwd(np.zeros((n, h, w, ci)), wt.astype(np.float64), dy.astype(np.float64))[0])
+    scale = float(np.abs(ref).max())
+    got = down(g0).astype(np.float64)
+    assert np.abs(got - ref).max() <= 2.0 ** -6 * scale, np.abs(got - ref).max() / scale
+    # the nine-tap form of the same launch (taps rounded one by one) agrees within the same bound
+    wr = rnd(wt, dtype)
+    _, wd9 = pack(wr, dtype)
+    g9 = torch.full_like(g0, 4.0)
+    d9 = conv_desc(dyd, co, 0, None, 0, wd9, None, g9, None, 0, n, h, w, ci, 0, dtype)
+    d9.down2 = 1
+    N.call('rvip_conv3x3_fwd', C.byref(d9), stream())
+    assert np.abs(got - down(g9).astype(np.float64)).max() <= 2.0 ** -6 * scale
+    # column sums: of the fp32 values in front of the storage rounding
+    sums = down(rows).astype(np.float64).sum(0)
+    want = got.sum((0, 1, 2))
+    tol = {'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}[dtype] * np.abs(got).sum((0, 1, 2)).max() + 1e-6
+    assert np.abs(sums - want).max() <= tol, (np.abs(sums - want).max(), tol)
+    # exact check of the packed phase kernels: what the launch multiplies with
+    wph_h = down(wph).reshape(4, 4, ci, co).astype(np.float64)
+    sets = {(0, 0): (1, 2), (0, 1): (0,), (1, 0): (2,), (1, 1): (0, 1)}
+    for al in range(2):
+        for be in range(2):
+            for u in range(2):
+                for v in range(2):
+                    acc = sum(wt[kh, kw].astype(np.float32) for kh in sets[(al, u)] for kw in sets[(be, v)])
+                    np.testing.assert_array_equal(wph_h[2 * al + be, 2 * u + v], rnd(acc, dtype).astype(np.float64))
+    # refused: f32, an up-sampling read, a bias
+    d = desc(g0)
+    d.up0 = 1
+    assert L.rvip_conv3x3_fwd(C.byref(d), stream()) == -1
+    d = desc(g0)
+    d.dtype = N.F32
+    assert L.rvip_conv3x3_fwd(C.byref(d), stream()) == -1
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(2, 48, 80, 32, 32), (1, 32, 32, 16, 40), (2, 16, 72, 8, 8), (1, 64, 64, 72, 64)])
 def test_upsample_conv_subpixel_form(shape, dtype):
