@@ -293,6 +293,57 @@ def test_real_shape_upconv_subpixel_form(idx, dtype):
     assert np.abs(got - k['fwd']).max() <= tol, (name, np.abs(got - k['fwd']).max() / scale)
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('idx', UPS, ids=[ALL[i][0].replace(' ', '_') for i in UPS])
+def test_real_shape_upconv_subpixel_backward(idx, dtype):
+    """The up-convs' backward as the engine launches it for the 16-bit types: the data gradient in its sub-pixel form (subpix = 2,
+    rvip_pack_subpixel_dgrad_weights) WITH the column sums of its result, and the weight gradient whose 64 x 64-block layers take the
+    sub-pixel form inside rvip_conv3x3_wgrad (the split count says which form ran) with the sum W*dW rows -- against the float64 oracle
+    of UpSampling2D -> Conv2D (KerasLayers.py:756-758 autodiff)."""
+    name, n, h, c0, up0, c1, co, bn = ALL[idx]
+    k = _case(idx)
+    L = N.lib()
+    wm, dyd, lod = f32(k['wt']), up(k['dy'], dtype), up(k['x0'], dtype)
+    # ---- data gradient
+    wph = torch.empty(16 * c0 * co, dtype=tdt(dtype), device=dev())
+    N.call('rvip_pack_subpixel_dgrad_weights', P(wm), c0, co, ndt(dtype), P(wph), stream())
+    glo = torch.full((n, h // 2, h // 2, c0), 9.0, dtype=tdt(dtype), device=dev())
+    d = conv_desc(dyd, co, 0, None, 0, wph, None, glo, None, 0, n, h, h, c0, 0, dtype)
+    d.subpix = 2
+    nr = L.rvip_conv3x3_fwd_sums_rows(C.byref(d))
+    assert nr > 0, 'the real up-conv shapes must take the sub-pixel data gradient'
+    rows = torch.full((nr, c0), 7.0, dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_fwd_sums', C.byref(d), P(rows), C.c_size_t(rows.numel() * 4), stream())
+    ref = O.upsample_nearest_bwd(k['dx'])
+    got = down(glo).astype(np.float64)
+    scale = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 2.0 ** -6 * scale, (name, np.abs(got - ref).max() / scale)      # + one rounding of the summed taps
+    sums, want = down(rows).astype(np.float64).sum(0), got.sum((0, 1, 2))
+    tol = {'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}[dtype] * np.abs(got).sum((0, 1, 2)).max() + 1e-6
+    assert np.abs(sums - want).max() <= tol, (name, np.abs(sums - want).max(), tol)
+    # ---- weight gradient (+ dot rows)
+    wsb = L.rvip_conv3x3_wgrad_workspace(n, h, h, c0, co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.full((3, 3, c0, co), 7.0, dtype=torch.float32, device=dev())
+    g = N.Wgrad3x3Desc()
+    g.x0, g.c0, g.up0, g.x1, g.c1 = lod.data_ptr(), c0, 1, None, 0
+    g.dy, g.dw = dyd.data_ptr(), dw.data_ptr()
+    g.n, g.h, g.w, g.cout, g.dtype = n, h, h, co, ndt(dtype)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
+    nd = L.rvip_conv3x3_wgrad_dot_rows(C.byref(g))
+    drows = torch.full((nd, c0), 7.0, dtype=torch.float64, device=dev())
+    g.w_master, g.dot_rows, g.dot_rows_bytes = wm.data_ptr(), drows.data_ptr(), drows.numel() * 8
+    ns = L.rvip_conv3x3_wgrad_splits(C.byref(g))
+    assert (ns % 4 == 0 and ns >= 4) if (c0 >= 64 and co >= 64) else ns >= 1          # four phases x pixel splits where the form is taken
+    N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+    gotw = down(dw).astype(np.float64)
+    sw = float(np.abs(k['dw']).max())
+    assert np.abs(gotw - k['dw']).max() <= 2e-5 * sw * max(1.0, np.sqrt(n * h * h / 4096.0)), (name, np.abs(gotw - k['dw']).max() / sw)
+    wr = k['wt'].astype(np.float64)                                               # on the grid: exact in every storage type
+    t2 = (wr * gotw).sum((0, 1, 3))
+    assert np.abs(drows.cpu().numpy().sum(0) - t2).max() <= 2e-6 * (np.abs(wr) * np.abs(gotw)).sum((0, 1, 3)).max()
+
+
 @functools.lru_cache(maxsize=1)
 def _tcase(idx):
     """Conv2DTranspose(3, strides=2, 'same') at an up-conv's shape (USE_UPSAMPLE=False, KerasLayers.py:761-765)"""
