@@ -293,8 +293,11 @@ def test_real_shape_upconv_subpixel_form(idx, dtype):
     assert np.abs(got - k['fwd']).max() <= tol, (name, np.abs(got - k['fwd']).max() / scale)
 
 
+UPS_ALL = [i for i, s in enumerate(ALL) if s[4] == 1]          # + config 4's 2048 -> 1024 at 32^2: 128 K chunks, 32 channel columns
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'f16'])
-@pytest.mark.parametrize('idx', UPS, ids=[ALL[i][0].replace(' ', '_') for i in UPS])
+@pytest.mark.parametrize('idx', UPS_ALL, ids=[ALL[i][0].replace(' ', '_') for i in UPS_ALL])
 def test_real_shape_upconv_subpixel_backward(idx, dtype):
     """The up-convs' backward as the engine launches it for the 16-bit types: the data gradient in its sub-pixel form (subpix = 2,
     rvip_pack_subpixel_dgrad_weights) WITH the column sums of its result, and the weight gradient whose 64 x 64-block layers take the
