@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
         for (int u = 0; u < U; ++u) {
             const long long r = rb + (long long)u * rpi;
             tv[u] = (yt && r < r1 && cgi < k) ? yt[(size_t)r * k + cgi] : 0.f;      // lane cgi finishes class cgi (+ cg, ... below)
-            if (r < r1) Vec<T>::load(a.z + ((size_t)r * a.c + cgi * VE) * sizeof(T), v[u]);
+            if (r < r1) Vec<T>::load_nt(a.z + ((size_t)r * a.c + cgi * VE) * sizeof(T), v[u]);      // z is not read again before the backward pass
             else {
 #pragma unroll
                 for (int e = 0; e < VE; ++e) v[u][e] = 0.f;
@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(BnBwdArgs a, Hea
                 const long long rr = r + u * gm.rpi;
                 ok[u] = rr < r1;
                 e0[u] = (size_t)rr * a.c + cgi * VE;
-                if (ok[u]) { Vec<T>::load(a.z + e0[u] * sizeof(T), z[u]); head_grad_vec<T, VE, KK>(hd, rr, wr, d, g[u]); }
+                if (ok[u]) { Vec<T>::load_nt(a.z + e0[u] * sizeof(T), z[u]); head_grad_vec<T, VE, KK>(hd, rr, wr, d, g[u]); }      // last use of z
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {

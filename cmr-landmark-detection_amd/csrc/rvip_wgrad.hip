@@ -184,6 +184,12 @@ __device__ __forceinline__ void dma16w(i32x4w rsrc, unsigned voff, unsigned lds_
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
 }
 
+__device__ __forceinline__ void dma16w_nt(i32x4w rsrc, unsigned voff, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
+}
+
 struct WgArgs2 {
     const unsigned char* x0; const unsigned char* x1; const unsigned char* dy;
     float* slab;
@@ -195,6 +201,9 @@ struct WgArgs2 {
     int depth, dshift;                        // Conv3D depth tap: X is read from image n + dshift of the same volume (zeros outside)
     int dbg;                                  // ablation only (RVIP_DBG): 1 = no DMA after the first tile, 2 = no MFMA, 4 = DMAs fetch nothing
     int nt_slab;                              // slabs leave with the non-temporal hint (deferred fold: their reader runs milliseconds later)
+    int nt_x;                                 // X tiles are fetched with the non-temporal hint: the activations of the forward pass are read here for the last time,
+                                              // and the gradient tensor the data gradient reads next stays cached (same box: 4.836 -> 4.815, 4.947 -> 4.894 ms per step;
+                                              // the same hint on dY, or on X of only the one-block / only the many-block layers, measured slower)
     int sp;                                   // sub-pixel form of the up-sampled layer (wgrad3x3_ws<..., TAPS = 4>): h, w = the low-resolution grid, nsplit = 4 phases x pixel splits
 };
 
@@ -497,7 +506,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
                 bool ok = dok && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
                 if (zsx) ok = ok && ((gy & gx) & 1);
                 const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(xbase + xrel[i]) : OOB;
-                dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
+                if (a.nt_x) dma16w_nt(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
+                else dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
             }
         }
 #pragma unroll
@@ -970,6 +980,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
         if (sp) { b.up0 = 0; b.h = a.h / 2; b.w = a.w / 2; }     // X is read as it lies; tiles, borders and splits are those of its grid
         b.tiles_x = g2.tiles_x; b.tiles_y = g2.tiles_y; b.ntiles = g2.ntiles; b.nsplit = g2.nsplit;
         { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
+        { static const bool ntx = [] { const char* e = getenv("RVIP_NT_WGRAD"); return !(e && e[0] == '0'); }(); b.nt_x = ntx ? 1 : 0; }
         b.nt_slab = d->defer_fold ? 1 : 0;        // (measured equal either way for the fold that follows at once: 6 452 vs 6 451 slices/s)
         if (d->workspace_bytes < (size_t)b.nsplit * 9 * a.cin * a.cout * sizeof(float)) return RVIP_EWORKSPACE;
         // Conv3D: one pass per depth tap (X shifted by kdi - 1 images inside the volume) into dw[kdi][9][Cin][Cout]
