@@ -121,7 +121,7 @@ def test_struct_layouts_match_header(tmp_path):
     structs = {'rvip_conv3x3_desc': N.Conv3x3Desc, 'rvip_wgrad3x3_desc': N.Wgrad3x3Desc,
                'rvip_apply_desc': N.ApplyDesc, 'rvip_bnbwd_desc': N.BnBwdDesc,
                'rvip_pack_entry': N.PackEntry, 'rvip_fold_entry': N.FoldEntry,
-               'rvip_bncoef_src': N.BnCoefSrc, 'rvip_bncoef_desc': N.BnCoefDesc}
+               'rvip_bncoef_src': N.BnCoefSrc, 'rvip_bncoef_desc': N.BnCoefDesc, 'rvip_headcoef_desc': N.HeadCoefDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rvip_hip.h"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
