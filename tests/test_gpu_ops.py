@@ -848,6 +848,37 @@ def test_pack_all_with_step_tick_is_pack_all_plus_state_tick():
     assert N.lib().rvip_pack_all_conv3x3_weights_tick(P(wm), P(tabd), 1, 9 * 16 * 24, N.BF16, P(wf), P(wd), None, stream()) == -1
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(16, 24), (64, 32), (72, 40), (256, 128), (8, 8)])
+def test_pack_all_mode_1_writes_both_phase_kernel_sets(shape, dtype):
+    """A mode-1 entry of the pack table (an UpSampling2D -> conv layer): the forward phase kernels at f_off and the data-gradient phase
+    kernels at d_off, bit for bit what rvip_pack_subpixel_weights / rvip_pack_subpixel_dgrad_weights write; a mode-0 entry beside it is
+    untouched by it."""
+    ci, co = shape
+    rng = np.random.default_rng(ci + co)
+    w = rng.standard_normal((3, 3, ci, co)).astype(np.float32)
+    w2 = rng.standard_normal((3, 3, 8, 16)).astype(np.float32)
+    theta = f32(np.concatenate([w.reshape(-1), w2.reshape(-1)]))
+    k1, k0 = 16 * ci * co, 9 * 8 * 16
+    wf = torch.full((k1 + k0 + 64,), 3.0, dtype=tdt(dtype), device=dev())
+    wd = torch.full((k1 + k0 + 64,), 5.0, dtype=tdt(dtype), device=dev())
+    tab = (N.PackEntry * 2)()
+    tab[0].w_off, tab[0].f_off, tab[0].d_off, tab[0].cin, tab[0].cout, tab[0].taps, tab[0].mode = 0, 32, 32, ci, co, 9, 1
+    tab[1].w_off, tab[1].f_off, tab[1].d_off, tab[1].cin, tab[1].cout, tab[1].taps, tab[1].mode = 9 * ci * co, 32 + k1, 32 + k1, 8, 16, 9, 0
+    tabd = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev())
+    N.call('rvip_pack_all_conv3x3_weights', P(theta), P(tabd), 2, max(k1, k0), ndt(dtype), P(wf), P(wd), stream())
+    rf = torch.empty(k1, dtype=tdt(dtype), device=dev())
+    rd = torch.empty(k1, dtype=tdt(dtype), device=dev())
+    wm = f32(w)
+    N.call('rvip_pack_subpixel_weights', P(wm), ci, co, ndt(dtype), P(rf), stream())
+    N.call('rvip_pack_subpixel_dgrad_weights', P(wm), ci, co, ndt(dtype), P(rd), stream())
+    f0, d0 = pack(w2, dtype)
+    torch.cuda.synchronize()
+    assert torch.equal(wf[32:32 + k1], rf) and torch.equal(wd[32:32 + k1], rd)
+    assert torch.equal(wf[32 + k1:32 + k1 + k0], f0) and torch.equal(wd[32 + k1:32 + k1 + k0], d0)
+    assert bool((wf[:32] == 3.0).all()) and bool((wd[:32] == 5.0).all()) and bool((wf[32 + k1 + k0:] == 3.0).all()) and bool((wd[32 + k1 + k0:] == 5.0).all())
+
+
 def test_adam_state_and_convert():
     rng = np.random.default_rng(7)
     cnt = 10007
