@@ -152,7 +152,7 @@ SIGNATURES = {
     'rvip_head_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'rvip_bn_apply_head': (C.c_int, [C.POINTER(ApplyDesc), vp, vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp]),
     'rvip_bn_apply_head_mse_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_int]),
-    'rvip_bn_apply_head_mse': (C.c_int, [C.POINTER(ApplyDesc), vp, vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float,
+    'rvip_bn_apply_head_mse': (C.c_int, [C.POINTER(ApplyDesc), vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float,
                                          vp, C.c_size_t, vp, C.c_size_t, vp]),
     'rvip_head_mse_coef': (C.c_int, [C.POINTER(HeadCoefDesc), vp]),
     'rvip_bn_bwd_reduce_head': (C.c_int, [C.POINTER(BnBwdDesc), vp, vp, C.c_int, vp, vp, vp]),

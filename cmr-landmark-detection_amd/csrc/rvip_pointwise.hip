@@ -943,8 +943,11 @@ struct HeadFuse { const float* w; const float* b; const float* dlogit; int k; };
 // KK = class capacity of the instantiation (2 for the reference's two heat-maps): half the shuffles and logit registers of the
 // MAXK-sized form; the target values of the round are loaded with its z rows, not after the arithmetic that depends on them.
 // MSE = 1 (include/rvip_hip.h: rvip_bn_apply_head_mse): the MSE logit gradient d = 2 (p - t) inv_count p (1 - p) [* dscale] is
-// written here, and S_kk[c] = sum y[c] * d[kk], Q_kk = sum d[kk] are accumulated while y is in registers -> mse.rows[block][KK + 1][C].
-struct HeadMse { float* dlogit; float* rows; float inv_count, dscale; };
+// written here, and S_kk[c] = sum (y[c] - beta[c]) * d[kk], Q_kk = sum d[kk] are accumulated while y is in registers ->
+// mse.rows[block][KK + 1][C].  y - beta = gamma * xhat: the rows are sums of g * xhat up to gamma, so the stage's dgamma needs no
+// `sum g*y - beta * sum g` difference (which loses what the float partial sums cannot hold when the gradient is mostly common-mode);
+// the head's weight gradient adds beta * Q back, where nothing cancels.
+struct HeadMse { float* dlogit; float* rows; const float* beta; float inv_count, dscale; };
 template <typename T, int KK, int SPEC = 0, int MSE = 0>
 __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFuse hd, float* __restrict__ pred, const float* __restrict__ yt,
                                                             long long rows, long long chunk, int reduce, float* __restrict__ ws, HeadMse mse) {
@@ -966,7 +969,11 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
 #pragma unroll
     for (int i = 0; i < 11; ++i) s[i] = 0.f;
     static_assert(!MSE || KK <= VE, "the Q row holds one column per class");
-    float hp[MSE ? KK + 1 : 1][VE];
+    float hp[MSE ? KK + 1 : 1][VE], bt[MSE ? VE : 1];
+    if constexpr (MSE) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) bt[e] = mse.beta ? mse.beta[cgi * VE + e] : 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < (MSE ? KK + 1 : 1); ++q)
 #pragma unroll
@@ -986,13 +993,12 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long r = rb + (long long)u * rpi;
-            float lg[KK], yv[MSE ? VE : 1], dl[MSE ? KK : 1];
+            float lg[KK], dl[MSE ? KK : 1];
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) lg[kk] = 0.f;
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
                 const float y = Vec<T>::round(act_fwd(fmaf(v[u][e], sc[e], sh[e]), SPEC ? RVIP_ACT_NONE : a.act));   // what rvip_bn_apply would have stored
-                if constexpr (MSE) yv[e] = y;
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) lg[kk] = fmaf(y, wr[e][kk], lg[kk]);
             }
@@ -1048,9 +1054,13 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
                     } else {
                         for (int o = cg >> 1; o > 0; o >>= 1) dl[kk] += __shfl_xor(dl[kk], o);
                     }
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) hp[kk][e] = fmaf(yv[e], dl[kk], hp[kk][e]);
                     if (cgi == 0) hp[KK][kk] += dl[kk];
+                }
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {                          // y again from z (its registers are still live; keeping y cost eight more)
+                    const float yb = Vec<T>::round(act_fwd(fmaf(v[u][e], sc[e], sh[e]), SPEC ? RVIP_ACT_NONE : a.act)) - bt[e];
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) hp[kk][e] = fmaf(yb, dl[kk], hp[kk][e]);
                 }
             }
         }
@@ -1717,15 +1727,15 @@ __global__ __launch_bounds__(1024) void head_mse_coef_kernel(HeadCoefArgs a) {
         }
         int isbad = 0;
         if (ch < a.c) {
+            gm = a.gamma[ch]; bt = a.beta ? a.beta[ch] : 0.f;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                if (kk < a.k) {
+                if (kk < a.k) {                                          // S = sum (y - beta) d:  t2 = gamma * sum g*xhat
                     const double w = (double)a.w[ch * a.k + kk];
                     t1 += w * Q[kk]; t2 += w * S[kk];
-                    a.head_dw[ch * a.k + kk] = (float)S[kk];
+                    a.head_dw[ch * a.k + kk] = (float)(S[kk] + (double)bt * Q[kk]);
                 }
             }
-            gm = a.gamma[ch]; bt = a.beta ? a.beta[ch] : 0.f;
             isbad = !(fabsf(gm) >= a.min_gamma && fabsf(bt) <= a.max_beta_ratio * fabsf(gm));
         }
         if (blockIdx.x == 0 && c == 0) {
@@ -1745,7 +1755,7 @@ __global__ __launch_bounds__(1024) void head_mse_coef_kernel(HeadCoefArgs a) {
     }
     __syncthreads();
     if (!sbad) {
-        if (g == 0 && ch < a.c) coef_store(a, ch, t1, (t2 - (double)bt * t1) / (double)gm);
+        if (g == 0 && ch < a.c) coef_store(a, ch, t1, t2 / (double)gm);
         return;
     }
     // ---------------- exact route for this block: sum g and sum g*xhat over every pixel, as rvip_bn_bwd_reduce_head computes them ----------------
@@ -2066,7 +2076,7 @@ extern "C" int rvip_bn_apply_head_mse_rows(long long rows, int c, int dtype, int
     return (int)head_fwd_blocks(rows, nullptr);
 }
 
-extern "C" int rvip_bn_apply_head_mse(const rvip_apply_desc* d, const float* head_w, const float* head_b, int k, float* pred,
+extern "C" int rvip_bn_apply_head_mse(const rvip_apply_desc* d, const float* head_w, const float* head_b, const float* beta, int k, float* pred,
                                       const float* y_true, float* sums, float* dlogit, float inv_count, float dscale,
                                       float* mse_rows, size_t mse_rows_bytes, void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
@@ -2087,7 +2097,7 @@ extern "C" int rvip_bn_apply_head_mse(const rvip_apply_desc* d, const float* hea
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
     HeadFuse hd{head_w, head_b, nullptr, k};
-    HeadMse mse{dlogit, mse_rows, inv_count, dscale};
+    HeadMse mse{dlogit, mse_rows, beta, inv_count, dscale};
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
         hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, 1, ws, mse);

@@ -513,7 +513,7 @@ class Engine:
         if self.head_alg:
             nr = L.rvip_bn_apply_head_mse_rows(hrows, last.cout, dt, hd['k'])
             self.head_rows = torch.empty(nr * 3 * last.cout, dtype=torch.float32, device=self.ws.device)
-            fwd_t.append((L.rvip_bn_apply_head_mse, (C.byref(last_apply), hw_, hb_, hd['k'], _ptr(self.pred), _ptr(self.y_true),
+            fwd_t.append((L.rvip_bn_apply_head_mse, (C.byref(last_apply), hw_, hb_, P.p(last.bn, 'beta'), hd['k'], _ptr(self.pred), _ptr(self.y_true),
                                                      _ptr(self.sums), _ptr(self.dlogit), C.c_float(self._inv_count),
                                                      C.c_float(self.loss_scale * self.grad_factor), _ptr(self.head_rows),
                                                      C.c_size_t(self.head_rows.numel() * 4), ws, wsb)))

@@ -405,21 +405,22 @@ int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* head_w, const 
  *   dlogit[p][k] = 2 (pred - y_true) * inv_count * pred (1 - pred) [* dscale]
  * depends on nothing outside the pixel, so the FORWARD pass writes it (the same values, bit for bit, as rvip_head_grad followed
  * by rvip_scale_f32) and accumulates, while y is in registers, rvip_bn_apply_head_mse_rows() partial rows [rows][k_cap + 1][C]
- * (k_cap = 2):   row kk < k_cap: S_kk[c] = sum_p y[p][c] * dlogit[p][kk];   row k_cap, column kk: Q_kk = sum_p dlogit[p][kk].
- * Their column sums are the head's gradients (dW_h[c][kk] = S_kk[c], db_h[kk] = Q_kk) and, the head being linear,
- *   T1[c] = sum_p g[p][c] = sum_kk W_h[c][kk] Q_kk,      T2[c] = sum_p g[p][c] y[p][c] = sum_kk W_h[c][kk] S_kk[c]
+ * (k_cap = 2):   row kk < k_cap: S_kk[c] = sum_p (y[p][c] - beta[c]) * dlogit[p][kk];   row k_cap, column kk: Q_kk = sum_p dlogit[p][kk]
+ * (`beta` = the stage's BatchNormalization beta: y - beta = gamma * xhat, so no `sum g*y - beta * sum g` difference is ever formed).
+ * Their column sums give the head's gradients (dW_h[c][kk] = S_kk[c] + beta[c] Q_kk, db_h[kk] = Q_kk) and, the head being linear,
+ *   sum_p g[p][c] = sum_kk W_h[c][kk] Q_kk,      gamma[c] * sum_p g[p][c] xhat[p][c] = sum_kk W_h[c][kk] S_kk[c]
  * of the stage's BatchNormalization backward -- rvip_head_mse_coef folds the rows and writes dW_h, db_h, the loss value
  * (sums[0] * inv_count), dgamma, dbeta and coef[3][C] as rvip_bn_bwd_coef does, with the same ill-conditioned-block exact route
  * (over z and dlogit, as rvip_bn_bwd_reduce_head computes them): rvip_head_grad, rvip_bn_bwd_reduce_head and their finalisers
  * drop out of the step, and with them two passes over z.  Needs k <= 2, d->act == NONE (activation in front of the BN, ReLU),
  * y_true; RVIP_EUNSUPPORTED otherwise (use the entry points above). */
 int rvip_bn_apply_head_mse_rows(long long rows, int c, int dtype, int k);
-int rvip_bn_apply_head_mse(const rvip_apply_desc* d, const float* head_w, const float* head_b, int k, float* pred,
+int rvip_bn_apply_head_mse(const rvip_apply_desc* d, const float* head_w, const float* head_b, const float* beta, int k, float* pred,
                            const float* y_true, float* sums, float* dlogit, float inv_count, float dscale,
                            float* mse_rows, size_t mse_rows_bytes, void* workspace, size_t workspace_bytes, void* stream);
 typedef struct rvip_headcoef_desc {
     const struct rvip_bnbwd_desc* bn;     /* the stage's rvip_bn_bwd_apply_head descriptor (z, mean, invstd, gamma, dgamma, dbeta, coef; act RELU in front of the BN) */
-    const float* beta;
+    const float* beta;                    /* the same beta the forward launch was given */
     const float* head_w; const float* dlogit; int32_t k; int32_t nrows;
     const float* mse_rows;                /* [nrows][3][C] from rvip_bn_apply_head_mse */
     float*       head_dw; float* head_db;

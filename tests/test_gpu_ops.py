@@ -1106,7 +1106,7 @@ def test_mse_head_gradients_from_the_forward_pass(dtype, shape):
     def forward_side(min_gamma):
         o = outputs()
         mrows = torch.full((nr * 3 * c,), 7.0, dtype=torch.float32, device=dev())
-        N.call('rvip_bn_apply_head_mse', C.byref(a), P(hwd), P(hbd), k, P(o['pred']), P(ytd), P(o['sums']), P(o['dlogit']),
+        N.call('rvip_bn_apply_head_mse', C.byref(a), P(hwd), P(hbd), P(bd), k, P(o['pred']), P(ytd), P(o['sums']), P(o['dlogit']),
                C.c_float(inv_count), C.c_float(dscale), P(mrows), C.c_size_t(mrows.numel() * 4), P(ws), C.c_size_t(wsb), stream())
         b = bwd_desc(o)
         hc = N.HeadCoefDesc()
@@ -1151,7 +1151,7 @@ def test_mse_head_gradients_from_the_forward_pass(dtype, shape):
             assert np.abs(got[i] - ref[i]).max() <= loose * np.abs(ref[i]).max() + 1e-12, (nm, i, 'classic')
     # what the entry points refuse
     a2, b2, hc2, mrows2 = keep
-    args = lambda kk, nbytes: (C.byref(a2), P(hwd), P(hbd), kk, P(o1['pred']), P(ytd), P(o1['sums']), P(o1['dlogit']), C.c_float(inv_count),  # noqa: E731
+    args = lambda kk, nbytes: (C.byref(a2), P(hwd), P(hbd), P(bd), kk, P(o1['pred']), P(ytd), P(o1['sums']), P(o1['dlogit']), C.c_float(inv_count),  # noqa: E731
                                C.c_float(1.0), P(mrows2), C.c_size_t(nbytes), P(ws), C.c_size_t(wsb), stream())
     assert L.rvip_bn_apply_head_mse(*args(3, mrows2.numel() * 4)) == -2
     assert L.rvip_bn_apply_head_mse(*args(k, mrows2.numel() * 4 - 4)) == -3
