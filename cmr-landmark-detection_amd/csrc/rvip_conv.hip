@@ -1616,25 +1616,47 @@ __global__ __launch_bounds__(256) void conv3d_c1_tiled(const T* __restrict__ x, 
             xs[k][r] = ok ? ld1<T>(x + ((long long)(img + k - 1) * h + gy) * wd + gx) : 0.f;
         }
         __syncthreads();
-        for (int p = ps; p < 256; p += pps) {
-            const int py = p >> 5, px = p & 31;
-            const int gy = ty0 + py, gx = tx0 + px;
-            if (gy >= h || gx >= wd) continue;
-            float v[VE];
+        // A thread owns one channel vector of FOUR vertically adjacent pixels: a tap's weights are read from LDS once for the four (the
+        // one-pixel form read 9 LDS words per 8 multiply-adds and was LDS-bound: 502 us at config 5 against 54 us of stores), the six
+        // input rows of a column are read once per tap column, and a wave still stores 1 KiB of contiguous NHWC output per instruction.
+        // Per output the 27 multiply-adds run in the same order as before (bias, then k, kh, kw): same bits.
+        for (int q = ps; q < 64; q += pps) {
+            const int px = q & 31, py0 = (q >> 5) * 4;
+            const int gx = tx0 + px;
+            float v[4][VE];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) v[e] = br[e];
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+                for (int e = 0; e < VE; ++e) v[j][e] = br[e];
+            // rolled over the nine (slice, tap row) pairs on purpose: unrolled, the compiler hoists all 27 x VE tap weights out of the
+            // pixel loop into registers -- 256 VGPRs + AGPR copies, ONE wave per SIMD and nothing to hide latency behind (502 us)
+#pragma unroll 1
+            for (int kr = 0; kr < 9; ++kr) {
+                const int k = kr / 3, dy = kr - 3 * k;
+                float xw[4][3];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float xv = xs[k][(py + t / 3) * 34 + px + t % 3];
-                    const float* wt = ws + (k * 9 + t) * cout + cv * VE;
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int e = 0; e < VE; ++e) v[e] = fmaf(xv, wt[e], v[e]);
+                    for (int dx = 0; dx < 3; ++dx) xw[j][dx] = xs[k][(py0 + j + dy) * 34 + px + dx];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    float wt[VE];
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) wt[e] = ws[(kr * 3 + dx) * cout + cv * VE + e];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) v[j][e] = fmaf(xw[j][dx], wt[e], v[j][e]);
                 }
+            }
 #pragma unroll
-            for (int e = 0; e < VE; ++e) v[e] = act_fwd(v[e], act);
-            Vec<T>::store(y + ((((size_t)img * h + gy) * wd + gx) * cout + cv * VE) * sizeof(T), v);
+            for (int j = 0; j < 4; ++j) {
+                const int gy = ty0 + py0 + j;
+                if (gy >= h || gx >= wd) continue;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) v[j][e] = act_fwd(v[j][e], act);
+                Vec<T>::store(y + ((((size_t)img * h + gy) * wd + gx) * cout + cv * VE) * sizeof(T), v[j]);
+            }
         }
     }
 }
