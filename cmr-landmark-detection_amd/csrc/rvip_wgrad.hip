@@ -417,16 +417,22 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
 // = ITS grid), dY tiles with stride 2.  d/dW[kh][kw] = the sum over the phases of the summed-tap gradient that contains (kh, kw) --
 // exactly one per phase -- so every workgroup writes a full nine-tap slab (its four blocks repeated where they belong) and the slab
 // fold stays what it is.
-template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9>
+// PB = 1 (with TAPS = 4): a workgroup contracts BOTH column phases pb = 0, 1 of its row phase pa against one staged X tile -- two dY
+// phase tiles per stage, two accumulator sets, their blocks added before the slab leaves.  A tile's DMA pieces need ~2.2 us to issue
+// and land whatever the MFMA count (one tile in flight), so the form pays where the stage still fits two buffers: 64 x 32 blocks
+// (X 45 KB + 2 x 16 KB), i.e. the full-resolution layer 64 -> 32 at 256^2, which the four-phase form could not speed up.
+template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9, int PB = 0>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     static_assert(TAPS == 9 || (TAPS == 4 && sizeof(T) == 2), "taps");
+    static_assert(PB == 0 || TAPS == 4, "phase pairs belong to the sub-pixel form");
     constexpr bool SP = TAPS == 4;
+    constexpr int NG = PB ? 2 : 1;                                    // dY phase tiles per stage
     constexpr int TH = 256 / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
     constexpr int NHROWS = (NHALO + 15) / 16 * 16;
     constexpr int ESZ = (int)sizeof(T), VE = Vec<T>::VE;
     constexpr int RBX = CIB * ESZ, RBG = COB * ESZ;                 // row bytes: 64 or 128
     static_assert((RBX == 64 || RBX == 128) && (RBG == 64 || RBG == 128), "row bytes");
-    constexpr int X_BYTES = NHROWS * RBX, G_BYTES = 256 * RBG, ST_BYTES = X_BYTES + G_BYTES;
+    constexpr int X_BYTES = NHROWS * RBX, G_BYTES = 256 * RBG, ST_BYTES = X_BYTES + NG * G_BYTES;
     constexpr int NQX = X_BYTES / 1024, NQG = G_BYTES / 1024;
     constexpr int QX = (NQX + 3) / 4, QG = (NQG + 3) / 4;
     constexpr int NPAIR = (CIB / 32) * (COB / 32) > 4 ? 4 : (CIB * ESZ / 64) * 0 + ((CIB / 32) * (COB / 32));
@@ -445,12 +451,13 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     // (a pixel of a 32-channel dY is half a 128-byte line).  Workgroups go to the 8 XCDs round-robin, so with a grid of whole
     // groups of 32 the phases of split s are the workgroups 8 apart -- same XCD, same L2, running side by side; otherwise every line
     // of dY comes from memory twice (64 -> 32 at 256^2: 85 us against 74 for the nine-tap form it replaces).
-    const bool xcd_map = SP && gridDim.x % 32 == 0;
-    const int ph = !SP ? 0 : xcd_map ? (int)((blockIdx.x >> 3) & 3) : (int)(blockIdx.x & 3);
-    const int split = !SP ? (int)blockIdx.x : xcd_map ? (int)((blockIdx.x & 7) | ((blockIdx.x >> 5) << 3)) : (int)(blockIdx.x >> 2);
+    constexpr int NPHB = PB ? 1 : 2;                                  // log2 of the phases that are separate workgroups (PB: only pa)
+    const bool xcd_map = SP && gridDim.x % (8 << NPHB) == 0;
+    const int ph = !SP ? 0 : xcd_map ? (int)((blockIdx.x >> 3) & ((1 << NPHB) - 1)) : (int)(blockIdx.x & ((1 << NPHB) - 1));
+    const int split = !SP ? (int)blockIdx.x : xcd_map ? (int)((blockIdx.x & 7) | ((blockIdx.x >> (3 + NPHB)) << 3)) : (int)(blockIdx.x >> NPHB);
     const int ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
-    const int pa = ph >> 1, pb = ph & 1;                                                                // output phase (wave-uniform)
-    const int nsplit = SP ? a.nsplit >> 2 : a.nsplit;                                                   // pixel splits
+    const int pa = PB ? ph : ph >> 1, pb = PB ? 0 : ph & 1;                                             // output phase (wave-uniform); PB: pb = 0 and 1
+    const int nsplit = SP ? a.nsplit >> NPHB : a.nsplit;                                                // pixel splits
     const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
     const int pair = wv % PAIRS, part = wv / PAIRS;
     const int ci_t = pair % NCI, co_t = pair / NCI;
@@ -498,6 +505,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
         const bool dok = (unsigned)(n % a.depth + a.dshift) < (unsigned)a.depth;
         const int xbase = (((n + a.dshift) * hs + (ty0 >> shf)) * wsrc + (tx0 >> shf)) * csrc * ESZ;
         const int gbase = SP ? ((n * 2 * a.h + 2 * ty0 + pa) * 2 * a.w + 2 * tx0 + pb) * a.cout * ESZ : ((n * a.h + ty0) * a.w + tx0) * a.cout * ESZ;
+        const int gstep = a.cout * ESZ;                                  // PB: the pb = 1 phase image is one full-resolution pixel to the right
 #pragma unroll
         for (int i = 0; i < QX; ++i) {
             const int q = wv + 4 * i;
@@ -511,13 +519,15 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
             }
         }
 #pragma unroll
+        for (int gph = 0; gph < NG; ++gph)
+#pragma unroll
         for (int i = 0; i < QG; ++i) {
             const int q = wv + 4 * i;
             if (q < NQG) {
                 const int gy = ty0 + gpy[i], gx = tx0 + gpx[i];
                 const bool ok = (unsigned)gy < (unsigned)a.h && gx < a.w;
-                const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(gbase + grel[i]) : OOB;
-                dma16w(rsg, off, lds_base + stage * ST_BYTES + X_BYTES + q * 1024);
+                const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(gbase + gph * gstep + grel[i]) : OOB;
+                dma16w(rsg, off, lds_base + stage * ST_BYTES + X_BYTES + gph * G_BYTES + q * 1024);
             }
         }
     };
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
         if (split < a.ntiles) issue(split, 0);
         if constexpr (NST == 3) { if (split + nsplit < a.ntiles) issue(split + nsplit, 1); }
         // DMA instructions this wave issues per tile (the pieces are dealt round-robin to the four loader waves)
-        const int mine = ((NQX - wv + 3) >> 2) + ((NQG - wv + 3) >> 2);
+        const int mine = ((NQX - wv + 3) >> 2) + NG * ((NQG - wv + 3) >> 2);
         int it = 0;
         for (int tile = split; tile < a.ntiles; tile += nsplit, ++it) {
             // my pieces of this tile have landed; after the barrier everybody's have, and the compute waves are done
@@ -534,6 +544,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
             if constexpr (NST == 3) {
                 // the tile after this one may stay in flight: wait until at most its `mine` instructions are outstanding
                 if (tile + nsplit < a.ntiles && !(a.dbg & 1)) {
+                    static_assert(NG == 1 || NST == 2, "the counted wait below knows one dY tile per stage");
                     if (mine == QX + QG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG) : "memory");
                     else if (mine == QX + QG - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG - 1) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG >= 2 ? QX + QG - 2 : 0) : "memory");
@@ -550,9 +561,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
         return;
     }
 
-    f32x16 acc[TAPS];
+    f32x16 acc[NG * TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < NG * TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -585,30 +596,34 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
                 gp[u] = lg + (wave_px + pxl) * RBG + ((RBG == 128) ? ((co_t ^ ((pxl >> 1) & 1)) << 6) : 0) + cb;
             }
             // sub-pixel form: tap (tr, tc) of phase (pa, pb) reads halo row + pa + tr, halo column + pb + tc
-            const unsigned char* xq[SP ? 2 : 1][2];
+            const unsigned char* xq[SP ? NG : 1][SP ? 2 : 1][2];
             if constexpr (SP) {
+#pragma unroll
+                for (int gph = 0; gph < NG; ++gph)
 #pragma unroll
                 for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const int hx = kk + 4 * u + tc + pb;
-                        xq[tc][u] = lx + ((wave_px / TW + pa) * HWD + hx) * RBX + ((RBX == 128) ? ((ci_t ^ ((hx >> 1) & 1)) << 6) : 0) + cb;
+                        const int hx = kk + 4 * u + tc + (PB ? gph : pb);
+                        xq[gph][tc][u] = lx + ((wave_px / TW + pa) * HWD + hx) * RBX + ((RBX == 128) ? ((ci_t ^ ((hx >> 1) & 1)) << 6) : 0) + cb;
                     }
             }
+#pragma unroll
+            for (int gph = 0; gph < NG; ++gph)
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 constexpr int dummy = 0; (void)dummy;
                 const int srow = (s * 16) / TW, scol = (s * 16) % TW;     // compile-time after unrolling
-                const s16x4 g0 = tr_read(gp[0] + s * 16 * RBG);
-                const s16x4 g1 = tr_read(gp[1] + s * 16 * RBG);
+                const s16x4 g0 = tr_read(gp[0] + gph * G_BYTES + s * 16 * RBG);
+                const s16x4 g1 = tr_read(gp[1] + gph * G_BYTES + s * 16 * RBG);
                 const uint4 fb = __builtin_bit_cast(uint4, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
                     const int off = ((srow + (SP ? t >> 1 : t / 3)) * HWD + scol) * RBX;
-                    const s16x4 x0 = tr_read((SP ? xq[t & 1][0] : xp[t % 3][0]) + off);
-                    const s16x4 x1 = tr_read((SP ? xq[t & 1][1] : xp[t % 3][1]) + off);
+                    const s16x4 x0 = tr_read((SP ? xq[SP ? gph : 0][t & 1][0] : xp[t % 3][0]) + off);
+                    const s16x4 x1 = tr_read((SP ? xq[SP ? gph : 0][t & 1][1] : xp[t % 3][1]) + off);
                     const uint4 fa = __builtin_bit_cast(uint4, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    acc[t] = mfma16<T>(fa, fb, acc[t]);
+                    acc[gph * TAPS + t] = mfma16<T>(fa, fb, acc[gph * TAPS + t]);
                 }
             }
         } else {
@@ -637,6 +652,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     // sub-pixel form: which of the phase's two summed taps per axis holds 3x3 tap row kh / column kw
     auto tap_of = [](int phase, int k3) { return phase ? (k3 == 2 ? 1 : 0) : (k3 != 0 ? 1 : 0); };
     if constexpr (PSPLIT == 1) {
+        static_assert(PB == 0, "phase pairs are folded through LDS (PSPLIT > 1 blocks)");
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
@@ -657,10 +673,10 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
         // every compute wave parks its block in LDS (the stages are free), one barrier, then 256 threads add the PSPLIT copies in
         // a fixed order and write 16 bytes each (the first form took turns: PSPLIT read-modify-write rounds behind barriers and
         // 4-byte stores -- 10-20 us at the end of the 32-channel launches, with nothing to overlap them)
-        constexpr int BLK = TAPS * 32 * 32, N4 = PAIRS * BLK / 4, BLK9 = 9 * 32 * 32;
+        constexpr int BLK = NG * TAPS * 32 * 32, N4 = PAIRS * BLK / 4, BLK9 = 9 * 32 * 32;
         float* red = reinterpret_cast<float*>(smem) + (part * PAIRS + pair) * BLK;   // [PSPLIT][PAIRS][9][32][32]
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
+        for (int t = 0; t < NG * TAPS; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j] = acc[t][r];
         __syncthreads();
@@ -672,6 +688,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
             f32x4 sum = r4[e4];
 #pragma unroll
             for (int p = 1; p < PSPLIT; ++p) sum += r4[p * N4 + e4];
+            if constexpr (PB) {                                           // + the pb = 1 phase's block that holds this tap
+                const int e41 = (pr * BLK + (TAPS + 2 * tap_of(pa, t / 3) + tap_of(1, t % 3)) * 1024 + (rem & 1023)) / 4;
+#pragma unroll
+                for (int p = 0; p < PSPLIT; ++p) sum += r4[p * N4 + e41];
+            }
             const int ci = ci0 + (pr % NCI) * 32 + ((rem >> 5) & 31), co = co0 + (pr / NCI) * 32 + (rem & 31);
             if (ci < a.cin && co + 3 < a.cout) {
                 if (a.nt_slab) __builtin_nontemporal_store(sum, reinterpret_cast<f32x4*>(&out[((size_t)t * a.cin + ci) * a.cout + co]));
@@ -832,7 +853,7 @@ static void wgrad_geometry(int n, int h, int w, int cin, int cout, int& tw, int&
     nsplit = (int)s;
 }
 
-struct Wg2Geom { int tw, cib, cob, tiles_x, tiles_y, ntiles, nsplit; bool ok; };
+struct Wg2Geom { int tw, cib, cob, tiles_x, tiles_y, ntiles, nsplit; bool ok; bool pair = false; };     // pair: sub-pixel form with both column phases per workgroup
 
 static Wg2Geom wgrad2_geometry(int n, int h, int w, int c0, int c1, int cout, int dtype) {
     Wg2Geom g;
@@ -858,27 +879,27 @@ static Wg2Geom wgrad2_geometry(int n, int h, int w, int c0, int c1, int cout, in
     return g;
 }
 
-template <typename T, int TW, int CIB, int COB, bool WS, int TAPS = 9>
+template <typename T, int TW, int CIB, int COB, bool WS, int TAPS = 9, int PB = 0>
 static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
     constexpr int TH = 256 / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int ESZ = (int)sizeof(T);
-    constexpr int ST = NHROWS * CIB * ESZ + 256 * COB * ESZ;
+    constexpr int ST = NHROWS * CIB * ESZ + (PB ? 2 : 1) * 256 * COB * ESZ;
     constexpr int NST = (WS && 3 * ST <= 160 * 1024) ? 3 : 2;
     // the wave-specialised kernel folds the pixel-split copies of a block through LDS: 4 x [9][32][32] floats
-    constexpr int FOLD = (WS && (ESZ == 4 || (CIB / 32) * (COB / 32) < 4)) ? 4 * TAPS * 32 * 32 * 4 : 0;
+    constexpr int FOLD = (WS && (ESZ == 4 || (CIB / 32) * (COB / 32) < 4)) ? 4 * (PB ? 2 : 1) * TAPS * 32 * 32 * 4 : 0;
     constexpr int lds = NST * ST > FOLD ? NST * ST : FOLD;
     static_assert(lds <= 160 * 1024, "LDS");
     static std::atomic<bool> attr_done{false};      // idempotent attribute call; atomic so concurrent host threads do not race on the flag
     if (!attr_done) {
         hipError_t e;
-        if constexpr (WS) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB, NST, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if constexpr (WS) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws<T, TW, CIB, COB, NST, TAPS, PB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma<T, TW, CIB, COB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
         attr_done = true;
     }
     dim3 grid((unsigned)a.nsplit, (unsigned)cdiv(a.cin, CIB), (unsigned)cdiv(a.cout, COB));
-    if constexpr (WS) hipLaunchKernelGGL((wgrad3x3_ws<T, TW, CIB, COB, NST, TAPS>), grid, dim3(512), lds, s, a);
+    if constexpr (WS) hipLaunchKernelGGL((wgrad3x3_ws<T, TW, CIB, COB, NST, TAPS, PB>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((wgrad3x3_dma<T, TW, CIB, COB>), grid, dim3(256), lds, s, a);
     return check_launch();
 }
@@ -886,7 +907,10 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
 // the wave-specialised kernel for the 16-bit types, the four-wave LDS-DMA kernel for f32
 template <typename T, int TW, int CIB, int COB>
 static int launch_wgrad2(const WgArgs2& a, hipStream_t s) {
-    if constexpr (sizeof(T) == 2) { if (a.sp) return launch_wgrad2x<T, TW, CIB, COB, true, 4>(a, s); }
+    if constexpr (sizeof(T) == 2) {
+        if constexpr (CIB == 64 && COB == 32) { if (a.sp == 2) return launch_wgrad2x<T, TW, CIB, COB, true, 4, 1>(a, s); }
+        if (a.sp) return launch_wgrad2x<T, TW, CIB, COB, true, 4>(a, s);
+    }
     return launch_wgrad2x<T, TW, CIB, COB, sizeof(T) == 2>(a, s);
 }
 
@@ -901,12 +925,15 @@ static bool wgrad_subpixel_geometry(const rvip_wgrad3x3_desc* d, Wg2Geom& g) {
     // The form saves matrix work (16 / 36), not staging: every phase stages the X tile again.  It pays where the nine-tap kernel is
     // bound by its MFMA / LDS-read side -- the 64 x 64 blocks (512 -> 256 .. 128 -> 64: 64 -> 45 us) -- and not on the 32-wide
     // blocks of the full-resolution layer, whose tiles carry half the matrix work per staged byte (64 -> 32 at 256^2: 74 -> 77 us).
-    if (!force && !(g.cib == 64 && g.cob == 64)) return false;
+    const bool pair = g.cib == 64 && g.cob == 32;                 // both column phases per workgroup (wgrad3x3_ws<..., PB = 1>): fits LDS there
+    if (!force && !(g.cib == 64 && g.cob == 64) && !pair) return false;
     const long long blocks = cdiv(d->c0, g.cib) * cdiv(d->cout, g.cob);
-    long long sp = 64 / blocks;                                   // 4 phases x sp pixel splits x blocks ~ one workgroup per CU
+    const int nph = pair ? 2 : 4;                                 // phases that are separate workgroups
+    long long sp = 256 / nph / blocks;                            // phases x sp pixel splits x blocks ~ one workgroup per CU
     if (sp < 1) sp = 1;
     if (sp > g.ntiles) sp = g.ntiles;
-    g.nsplit = (int)(4 * sp);
+    g.nsplit = (int)(nph * sp);
+    g.pair = pair;
     return true;
 }
 
@@ -976,7 +1003,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
         b.x0 = a.x0; b.x1 = a.x1; b.dy = a.dy; b.slab = a.slab;
         b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.dy_bytes = (unsigned)dyb;
         b.c0 = a.c0; b.c1 = a.c1; b.up0 = a.up0; b.zs = a.zs; b.n = a.n; b.h = a.h; b.w = a.w; b.cin = a.cin; b.cout = a.cout;
-        b.sp = sp ? 1 : 0;
+        b.sp = sp ? (g2.pair ? 2 : 1) : 0;                       // 2: both column phases per workgroup
         if (sp) { b.up0 = 0; b.h = a.h / 2; b.w = a.w / 2; }     // X is read as it lies; tiles, borders and splits are those of its grid
         b.tiles_x = g2.tiles_x; b.tiles_y = g2.tiles_y; b.ntiles = g2.ntiles; b.nsplit = g2.nsplit;
         { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
