@@ -15,6 +15,7 @@ row 4: CPU, I/O-bound, outside the hot path).
 from __future__ import annotations
 
 import sys
+import threading
 
 import numpy as np
 
@@ -63,6 +64,7 @@ class BaseGenerator:
         self.INDICES = list(range(n_samples))
         self._epochs_seen = 0
         self.samples_generated = 0          # samples this process has produced (data-parallel tests: B / world per step and rank)
+        self._count_lock = threading.Lock() # __getitem__ may run on several pool threads (fit(workers=))
         self.on_epoch_end()
 
     def __len__(self):
@@ -100,7 +102,8 @@ class BaseGenerator:
         y = np.empty((len(idxs), *self.DIM, self.N_CLASSES), dtype=np.float32)
         for i, ID in enumerate(idxs):
             x[i], y[i] = self.__preprocess_one_image__(i, int(ID))
-        self.samples_generated += len(idxs)
+        with self._count_lock:
+            self.samples_generated += len(idxs)
         return x, y
 
     def __preprocess_one_image__(self, i, ID):
@@ -156,7 +159,8 @@ class ArrayGenerator(BaseGenerator):
 
     def __data_generation__(self, idxs):
         idxs = np.asarray(idxs)
-        self.samples_generated += len(idxs)
+        with self._count_lock:
+            self.samples_generated += len(idxs)
         return self._x[idxs], (None if self._y is None else self._y[idxs])
 
 
@@ -185,7 +189,6 @@ class DataGenerator(BaseGenerator):
         self.AUGMENT = config.get('AUGMENT', False)
         self.AUGMENT_PROB = config.get('AUGMENT_PROB', 0.8)
         self.IN_MEMORY = in_memory
-        self._rng = np.random.default_rng(config.get('SEED', 42))
         super().__init__(len(self.IMAGES), config)
         if not self.MASKS:
             self.N_CLASSES = 1                                   # the image is yielded twice (Generators.py:393-395)
@@ -219,7 +222,12 @@ class DataGenerator(BaseGenerator):
         from . import Preprocess as pp
         img, msk = self._processed[ID] if ID in self._processed else self.__fix_preprocessing__(ID)
         if self.AUGMENT:
-            img, msk = pp.augment(img, msk, self.config, self._rng, self.AUGMENT_PROB)
+            # The reference draws from albumentations' process-global stream, one sample after the other in its single process.  Here
+            # the draws of a sample come from (SEED, reshuffles so far, sample ID): the same sample gets the same augmentation whichever
+            # rank, pool thread or batch slice produces it (a shared sequential stream would hand every data-parallel rank the SAME
+            # parameter sequence for DIFFERENT samples, and is not safe under fit(workers > 1)).
+            rng = np.random.default_rng([int(self.SEED), int(self._epochs_seen), int(ID)])
+            img, msk = pp.augment(img, msk, self.config, rng, self.AUGMENT_PROB)
         img = normalise_image(pp.pad_and_crop(img, self.DIM), self.SCALER)
         msk = pp.pad_and_crop(msk, self.DIM)
         if self.MASKS:

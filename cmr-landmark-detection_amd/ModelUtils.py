@@ -7,21 +7,32 @@ lr) lives on the device next to the flat parameter block and is advanced by ``rv
 """
 from __future__ import annotations
 
+import weakref
+
 
 class _LR:
     """``model.optimizer.lr`` -- readable / assignable like the Keras variable (KerasCallbacks.py:173)."""
 
     def __init__(self, value):
         self._value = float(value)
-        self._listeners = []
+        self._listeners = []                      # weak references to bound methods: the variable must not keep a model alive
 
     def numpy(self):
         return self._value
 
+    def add_listener(self, method):
+        """`method(value)` is called on every assignment for as long as its object lives.  Held weakly: model -> optimizer -> lr ->
+        listener -> model would be a reference cycle, and a model in a cycle dies in the cyclic collector -- at an arbitrary moment,
+        on an arbitrary thread -- together with the hipGraphs its engines own (see Engine.capture)."""
+        ref = weakref.WeakMethod(method)
+        self._listeners = [r for r in self._listeners if r() is not None and r() != method] + [ref]
+
     def assign(self, v):
         self._value = float(v)
-        for cb in self._listeners:
-            cb(self._value)
+        for ref in list(self._listeners):
+            cb = ref()
+            if cb is not None:
+                cb(self._value)
 
     def __float__(self):
         return self._value

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RVIP_LIB') or os.path.join(_HERE, 'librvip_hip.so')     # RVIP_LIB: A/B another build of the same ABI
 
-EXPECTED_ABI = 6          # RVIP_ABI_VERSION of include/rvip_hip.h (tests/test_host_cpu.py holds the two together)
+EXPECTED_ABI = 7          # RVIP_ABI_VERSION of include/rvip_hip.h (tests/test_host_cpu.py holds the two together)
 F32, BF16, F16 = 0, 1, 2
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'elu': 2, 'sigmoid': 3}
 LOSS_MSE, LOSS_BCE_DICE = 0, 1
@@ -109,6 +109,7 @@ SIGNATURES = {
     'rvip_abi_version': (C.c_int, []),
     'rvip_build_info': (C.c_char_p, []),
     'rvip_last_hip_error': (C.c_int, []),
+    'rvip_device_check': (C.c_int, []),
     'rvip_conv3x3_fwd': (C.c_int, [C.POINTER(Conv3x3Desc), vp]),
     'rvip_conv3x3_sign_bits_ok': (C.c_int, [C.POINTER(Conv3x3Desc)]),
     'rvip_conv3x3_fwd_stats_rows': (C.c_int, [C.POINTER(Conv3x3Desc)]),
@@ -120,11 +121,13 @@ SIGNATURES = {
     'rvip_pack_subpixel_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'rvip_pack_subpixel_dgrad_weights': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'rvip_pack_all_conv3x3_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    'rvip_pack_table_check': (C.c_int, [vp, C.c_int, C.c_int]),
     'rvip_pack_all_conv3x3_weights_tick': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     'rvip_conv3x3_wgrad_workspace': (C.c_size_t, [C.c_int] * 5),
     'rvip_conv3x3_wgrad': (C.c_int, [C.POINTER(Wgrad3x3Desc), vp]),
     'rvip_conv3x3_wgrad_splits': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
     'rvip_conv3x3_wgrad_dot_rows': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
+    'rvip_conv3x3_wgrad_form': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
     'rvip_fold_rows_batch': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'rvip_bn_bwd_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'rvip_bn_bwd_apply_head_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_int]),

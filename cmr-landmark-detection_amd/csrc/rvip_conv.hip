@@ -1767,6 +1767,36 @@ struct PackEntry { long long w_off; long long f_off; long long d_off; int cin, c
 // A workgroup moves tiles of one tap: 32 input channels x 64 output channels, read as 256-byte rows of the HWIO master,
 // written as 128-byte rows of w_dgrad (same orientation, taps reversed) and, transposed through LDS, as 64-byte rows of
 // w_fwd.  (The element-per-thread form scattered 2-byte stores Cin apart: 1.5 ms for the 138 M parameters of cfg 4.)
+// four consecutive output channels of one HWIO row; `ragged` (Cout % 4 != 0: rows are not 16-byte aligned and the last group is
+// partial) takes the element path, bounded by the `nv` channels the row still has
+__device__ __forceinline__ float4 pack_load4(const float* src, bool ragged, int nv) {
+    if (!ragged) return *reinterpret_cast<const float4*>(src);
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (nv > 0) v.x = src[0];
+    if (nv > 1) v.y = src[1];
+    if (nv > 2) v.z = src[2];
+    if (nv > 3) v.w = src[3];
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ void pack_store4(T* dst, const float4& v, bool ragged, int nv) {
+    if (!ragged) {
+        if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = v;
+        else {
+            uint2 pk;
+            pk.x = Vec<T>::pack2(v.x, v.y);
+            pk.y = Vec<T>::pack2(v.z, v.w);
+            *reinterpret_cast<uint2*>(dst) = pk;
+        }
+        return;
+    }
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < 4 && i < nv; ++i) {
+        if constexpr (sizeof(T) == 4) dst[i] = e[i];
+        else dst[i].bits = Vec<T>::enc(e[i]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__ theta, const PackEntry* __restrict__ tab,
                                                        T* __restrict__ wf_base, T* __restrict__ wd_base, uint32_t* tick) {
@@ -1779,6 +1809,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     const float* w = theta + en.w_off;
     T* wf = wf_base + en.f_off;
     T* wd = wd_base + en.d_off;
+    const bool ragged = (en.cout & 3) != 0;
     if (en.reserved == 1) {
         // mode 1: the phase kernels of the sub-pixel up-conv form, [4][4][Cout][Cin] at f_off, and of its data gradient, [4][4][Cin][Cout]
         // at d_off (pack_subpixel_range / pack_subpixel_dgrad_range, same sums in the same order), tiled like mode 0: the element-per-
@@ -1802,24 +1833,18 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
                 float4 sf = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
                 if (ok) {
                     const float* src = w + (size_t)(ci0 + r) * en.cout + co0 + c4;
+                    const int nv = en.cout - (co0 + c4);      // valid output channels of this group (< 4 only when Cout % 4 != 0)
                     for (int kh = fh0; kh <= fh1; ++kh)
                         for (int kw = fw0; kw <= fw1; ++kw) {
-                            const float4 t4 = *reinterpret_cast<const float4*>(src + (size_t)(kh * 3 + kw) * en.cin * en.cout);
+                            const float4 t4 = pack_load4(src + (size_t)(kh * 3 + kw) * en.cin * en.cout, ragged, nv);
                             sf.x += t4.x; sf.y += t4.y; sf.z += t4.z; sf.w += t4.w;
                         }
                     for (int kh = dh0; kh <= dh1; ++kh)
                         for (int kw = dw0; kw <= dw1; ++kw) {
-                            const float4 t4 = *reinterpret_cast<const float4*>(src + (size_t)(kh * 3 + kw) * en.cin * en.cout);
+                            const float4 t4 = pack_load4(src + (size_t)(kh * 3 + kw) * en.cin * en.cout, ragged, nv);
                             sd.x += t4.x; sd.y += t4.y; sd.z += t4.z; sd.w += t4.w;
                         }
-                    T* dst = wd + ((size_t)pt * en.cin + ci0 + r) * en.cout + co0 + c4;
-                    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = sd;
-                    else {
-                        uint2 pk;
-                        pk.x = Vec<T>::pack2(sd.x, sd.y);
-                        pk.y = Vec<T>::pack2(sd.z, sd.w);
-                        *reinterpret_cast<uint2*>(dst) = pk;
-                    }
+                    pack_store4<T>(wd + ((size_t)pt * en.cin + ci0 + r) * en.cout + co0 + c4, sd, ragged, nv);
                 }
                 tile[r * LDW + c4] = sf.x; tile[r * LDW + c4 + 1] = sf.y; tile[r * LDW + c4 + 2] = sf.z; tile[r * LDW + c4 + 3] = sf.w;
             }
@@ -1863,19 +1888,12 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
         for (int q = 0; q < 2; ++q) {
             const int idx = tid + q * 256, r = idx >> 4, c4 = (idx & 15) * 4;
             float4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ci0 + r < en.cin && co0 + c4 < en.cout) v = *reinterpret_cast<const float4*>(w + ((size_t)t * en.cin + ci0 + r) * en.cout + co0 + c4);
+            const int nv = en.cout - (co0 + c4);
+            if (ci0 + r < en.cin && nv > 0) v = pack_load4(w + ((size_t)t * en.cin + ci0 + r) * en.cout + co0 + c4, ragged, nv);
             tile[r * LDW + c4] = v.x; tile[r * LDW + c4 + 1] = v.y; tile[r * LDW + c4 + 2] = v.z; tile[r * LDW + c4 + 3] = v.w;
             // w_dgrad[8 - t][ci][co]: same row, 4 consecutive output channels
-            if (ci0 + r < en.cin && co0 + c4 < en.cout) {
-                T* dst = wd + ((size_t)(taps - 1 - t) * en.cin + ci0 + r) * en.cout + co0 + c4;
-                if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = v;
-                else {
-                    uint2 pk;
-                    pk.x = Vec<T>::pack2(v.x, v.y);
-                    pk.y = Vec<T>::pack2(v.z, v.w);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                }
-            }
+            if (ci0 + r < en.cin && nv > 0)
+                pack_store4<T>(wd + ((size_t)(taps - 1 - t) * en.cin + ci0 + r) * en.cout + co0 + c4, v, ragged, nv);
         }
         __syncthreads();
         // w_fwd[t][co][ci]: thread = (output channel, 8 input channels)
@@ -1916,6 +1934,13 @@ using namespace rvip;
 extern "C" int rvip_abi_version(void) { return RVIP_ABI_VERSION; }     // 3: round-2 prune; 4: window argmax of the pooled stages (apply / BN-backward descriptors), IMG_CHANNELS 2..4 entry points
 extern "C" const char* rvip_build_info(void) { return "rvip_hip gfx950 wave64 mfma"; }
 extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
+extern "C" int rvip_device_check(void) {
+    const hipError_t a = hipDeviceSynchronize();
+    const hipError_t b = hipGetLastError();
+    const hipError_t e = a != hipSuccess ? a : b;
+    if (e != hipSuccess) g_last_hip_error = (int)e;
+    return (int)e;
+}
 
 static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     if (!d || !d->x0 || !d->w_packed || !d->y) return RVIP_EINVAL;
@@ -2174,6 +2199,24 @@ extern "C" int rvip_pack_subpixel_dgrad_weights(const float* w, int cin, int cou
     else if (dtype == RVIP_F32) hipLaunchKernelGGL(pack_subpixel_kernel<float>, dim3(blocks), dim3(256), 0, s, w, cin, cout, (float*)w_phase, 1);
     else return RVIP_EINVAL;
     return check_launch();
+}
+
+// Host-side check of a pack table BEFORE it is uploaded (the launch below only sees the device copy): every entry must describe
+// a kernel the table-driven re-layout and the conv kernels behind it take.
+extern "C" int rvip_pack_table_check(const rvip_pack_entry* host_table, int entries, int dtype) {
+    static_assert(sizeof(PackEntry) == sizeof(rvip_pack_entry), "the kernel's view of a table entry is the ABI's");
+    if (!host_table || entries <= 0 || !RVIP_DT_OK(dtype)) return RVIP_EINVAL;
+    const PackEntry* t = (const PackEntry*)host_table;
+    for (int i = 0; i < entries; ++i) {
+        const PackEntry& e = t[i];
+        if (e.cin <= 0 || e.cout <= 0 || e.w_off < 0 || e.f_off < 0 || e.d_off < 0) return RVIP_EINVAL;
+        if (e.reserved != 0 && e.reserved != 1) return RVIP_EINVAL;
+        if (e.reserved == 0 && e.taps != 9 && e.taps != 27 && e.taps != 0) return RVIP_EINVAL;
+        if (e.reserved == 1 && e.taps != 9 && e.taps != 0) return RVIP_EINVAL;          // phase kernels exist for 3x3 kernels only
+        if ((e.w_off | e.f_off | e.d_off) & 3) return RVIP_EINVAL;                       // 16-byte rows start 16-byte aligned
+        if (e.cout & 3) return RVIP_EINVAL;                                              // no conv kernel of this library takes such a layer
+    }
+    return RVIP_OK;
 }
 
 static int pack_all_launch(const float* theta, const void* table, int entries, int max_elems, int dtype,

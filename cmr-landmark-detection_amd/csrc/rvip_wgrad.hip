@@ -1062,6 +1062,21 @@ extern "C" int rvip_conv3x3_wgrad_dot_rows(const rvip_wgrad3x3_desc* d) {
     return kd * 9 * dot_geometry(9, d->c0 + d->c1, d->cout).nchunk;
 }
 
+// which kernel form rvip_conv3x3_wgrad launches for this shape: 0 nine-tap LDS-DMA kernel, 1 sub-pixel form (four phase workgroups),
+// 2 sub-pixel form with both column phases per workgroup (PB = 1), 3 register-staged fallback, -1 invalid descriptor
+extern "C" int rvip_conv3x3_wgrad_form(const rvip_wgrad3x3_desc* d) {
+    if (!d || !RVIP_DT_OK(d->dtype) || d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c0 <= 0 || d->cout <= 0) return -1;
+    const int up = d->up0 ? 1 : 0;
+    const long long esz = RVIP_ESZ(d->dtype);
+    const long long x0b = (long long)d->n * (d->h >> up) * (d->w >> up) * d->c0 * esz, x1b = (long long)d->n * d->h * d->w * d->c1 * esz;
+    const long long dyb = (long long)d->n * d->h * d->w * d->cout * esz;
+    Wg2Geom g2;
+    const bool sp = wgrad_subpixel_geometry(d, g2);
+    if (!sp) g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype);
+    if (g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) return sp ? (g2.pair ? 2 : 1) : 0;
+    return 3;
+}
+
 // number of split-K slabs rvip_conv3x3_wgrad writes for this shape (rows of the deferred fold; 0 = invalid descriptor)
 extern "C" int rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d) {
     if (!d || !RVIP_DT_OK(d->dtype) || d->n <= 0 || d->h <= 0 || d->w <= 0) return 0;

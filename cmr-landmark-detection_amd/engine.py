@@ -18,8 +18,10 @@ Data layout in HBM (per rank)
 from __future__ import annotations
 
 import ctypes as C
+import gc
 import os
-from collections import OrderedDict
+import threading
+from collections import OrderedDict, deque
 
 import numpy as np
 
@@ -27,6 +29,9 @@ from . import _native as N
 
 BN_MOMENTUM, BN_EPS = 0.99, 1e-3          # Keras BatchNormalization defaults (KerasLayers.py:684 passes none)
 ALIGN = 64                                 # floats: every parameter tensor starts 256-byte aligned
+
+
+_CAPTURE_LOCK = threading.RLock()            # one stream capture at a time per process; graph release never overlaps one
 
 
 def _torch():
@@ -109,6 +114,8 @@ class ParamStore:
                 self.packed[name] = (self.wf_all[p_off:p_off + k], self.wd_all[p_off:p_off + k])
             self.pack_max = max(self.pack_max, k)
         self.pack_entries = len(entries)
+        if entries:                                # the launch only sees the device copy: refuse a bad table here
+            N.check(N.lib().rvip_pack_table_check(C.cast(tab, C.c_void_p), len(entries), self.dt), 'rvip_pack_table_check')
         self.pack_table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(device)
         self.upload(host_weights)
 
@@ -196,7 +203,107 @@ class ParamStore:
             N.check(fn(*args, C.c_void_p(stream)), 'rvip_pack_all_conv3x3_weights')
 
 
-class Engine:
+class InputRing:
+    """Host -> device input pipeline of fit(): a ring of pinned slots + a copy stream, so that the H2D of batch k+1 runs under step k.
+
+    Threading contract (keras_model._Stager): the generator thread only waits on host-side flags and writes pinned memory through
+    NumPy views (next_slot, stage_host_batch); every HIP call (allocation, copies, event record / query / synchronise: the _ring_*
+    hooks, feed, reset_input_ring) belongs to the training thread.  Slot protocol: item i uses slot i % slots; feeding item k hands
+    back every slot up to item k - 2 (their uploads were queued two steps ago) and newer ones whose upload happens to be complete.
+    With a queue of `depth` items between the threads the generator thread can be at most depth + 2 items ahead of the last feed, so
+    slots >= depth + 4 never deadlocks (tests/test_host_cpu.py drives exactly that worst case)."""
+
+    pin_x = None
+
+    # -- hooks (HIP side; overridden by the host-only twin in the tests) ---------------------------------------------
+    def _ring_alloc(self, slots):
+        torch = _torch()
+        self.pin_x = [torch.empty(self.x_stage.shape, dtype=torch.float32).pin_memory() for _ in range(slots)]
+        self.pin_y = [torch.empty(self.y_true.shape, dtype=torch.float32).pin_memory() for _ in range(slots)]
+        self.pin_x_np = [t.numpy() for t in self.pin_x]    # host views, created here so that the generator thread never enters torch
+        self.pin_y_np = [t.numpy() for t in self.pin_y]
+        self.dev_in = [(torch.empty_like(self.x_stage), torch.empty_like(self.y_true)) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=self.P.device)
+        self.ev_free = [None, None]                        # device staging pair -> event after which it may be refilled
+
+    def _ring_upload(self, slot, d):
+        """pinned slot -> device staging pair d on the copy stream, then device-to-device into the buffers the captured step reads, on
+        the compute stream (only that last copy is ordered with the step).  Returns the event recorded after the H2D copy."""
+        torch = _torch()
+        cs, main = self.copy_stream, torch.cuda.current_stream()
+        if self.ev_free[d] is not None:
+            cs.wait_event(self.ev_free[d])
+        with torch.cuda.stream(cs):
+            self.dev_in[d][0].copy_(self.pin_x[slot], non_blocking=True)
+            self.dev_in[d][1].copy_(self.pin_y[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        main.wait_event(ev)
+        self.x_stage.copy_(self.dev_in[d][0], non_blocking=True)
+        self.y_true.copy_(self.dev_in[d][1], non_blocking=True)
+        evf = torch.cuda.Event()
+        evf.record(main)
+        self.ev_free[d] = evf
+        return ev
+
+    # -- protocol ----------------------------------------------------------------------------------------------------
+    def alloc_input_ring(self, slots):
+        if self.pin_x is not None and len(self.pin_x) >= slots:
+            return
+        self._ring_alloc(slots)
+        self.slot_free = [threading.Event() for _ in range(slots)]     # set: the generator thread may overwrite the pinned slot
+        self._uploads = deque()
+        self.reset_input_ring()
+
+    def reset_input_ring(self):
+        """(training thread, no generator thread running) waits for the uploads in flight and marks every slot free."""
+        if self.pin_x is None:
+            return
+        for _, ev in self._uploads:
+            ev.synchronize()
+        self._uploads = deque()                            # (slot, event recorded after its H2D copy), in feed order
+        for f in self.slot_free:
+            f.set()
+        self._fed = 0
+        self._staged = 0
+
+    def ring_slots(self):
+        return len(self.pin_x) if self.pin_x is not None else 0
+
+    def next_slot(self):
+        """(generator thread) pinned slots are used round-robin"""
+        slot = self._staged % len(self.pin_x)
+        self._staged += 1
+        return slot
+
+    def stage_host_batch(self, slot, x, y, cancel=None):
+        """(generator thread; host memory only) pageable NumPy batch -> pinned slot, once the training thread has handed the slot
+        back (its previous upload has completed).  Returns False if `cancel` was set while waiting."""
+        flag = self.slot_free[slot]
+        while not flag.wait(0.1):
+            if cancel is not None and cancel.is_set():
+                return False
+        flag.clear()
+        np.copyto(self.pin_x_np[slot], np.asarray(x, np.float32).reshape(self.pin_x_np[slot].shape))
+        np.copyto(self.pin_y_np[slot], np.asarray(y, np.float32).reshape(self.pin_y_np[slot].shape))
+        return True
+
+    def _release_slots(self, keep):
+        up = self._uploads
+        while up and (len(up) > keep or up[0][1].query()):
+            slot, ev = up.popleft()
+            ev.synchronize()
+            self.slot_free[slot].set()
+
+    def feed(self, slot):
+        """(training thread) queue the upload of a staged slot; hand older slots back to the generator thread."""
+        d = self._fed & 1
+        self._fed += 1
+        self._uploads.append((slot, self._ring_upload(slot, d)))
+        self._release_slots(keep=2)
+
+
+class Engine(InputRing):
     """Activation/gradient buffers and pre-built launch lists for ONE (batch size, loss) configuration."""
 
     def __init__(self, params, batch, loss_kind='mse', w_bce=0.5, w_dice=1.0, world=1, masks=None, sum_reduction=False):
@@ -312,7 +419,6 @@ class Engine:
         self.ws_wg = torch.empty(need_wg // 4 + 64, **f32)
         self.ws_wg_bytes = need_wg
         self._graphs, self._eager_steps, self.launch_mode = None, 0, 'eager'
-        self.pin_x = None
         self._build_lists()
 
     # -- helpers --------------------------------------------------------------------------------------
@@ -892,25 +998,51 @@ class Engine:
     def capture(self):
         """hipGraph capture of the step (one graph on one GPU; around the RCCL collectives when data-parallel).  Needs one
         eager step before it (lazy module / kernel loading is not capturable).  Returns False -- and the engine stays on eager
-        launches, in-process -- if the runtime refuses the capture."""
+        launches, in-process -- if the runtime refuses the capture.
+
+        Nothing may DESTROY a hipGraph while a stream is capturing: ``at::cuda::CUDAGraph::~CUDAGraph`` calls hipDeviceSynchronize
+        and throws from the destructor on its error (hipErrorStreamCaptureUnsupported while any stream captures) -> std::terminate
+        -> SIGABRT of the process.  A graph dies with its engine, an engine with its model, and a model that sits in a reference
+        cycle dies in Python's cyclic collector -- on any thread, at any allocation (torch >= 2.9 no longer collects before a
+        capture).  That was round 3's box-dependent abort of the GPU suite.  So: collect BEFORE the capture, on
+        this thread, and keep the automatic collector off (it is process-global: all threads) until the capture has ended."""
         torch = _torch()
         parts, _ = self._step_parts()
         graphs = []
-        try:
-            for fn in parts:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):           # a generator thread may be pinning memory meanwhile
-                    fn()
-                graphs.append(g)
-        except Exception as e:                                                            # pragma: no cover (needs a failing runtime)
-            import sys
-            sys.stderr.write('rvip: hipGraph capture failed (%s: %s); the step runs on eager launches\n' % (type(e).__name__, e))
+        with _CAPTURE_LOCK:
             torch.cuda.synchronize()
-            self._graphs, self.launch_mode = None, 'eager (capture failed)'
-            return False
+            gc.collect()                                       # dead engines release their graphs here, legally
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                for fn in parts:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):       # other threads' (host-only) work is not our capture's business
+                        fn()
+                    graphs.append(g)
+            except Exception as e:                                                        # pragma: no cover (needs a failing runtime)
+                import sys
+                sys.stderr.write('rvip: hipGraph capture failed (%s: %s); the step runs on eager launches\n' % (type(e).__name__, e))
+                torch.cuda.synchronize()
+                del graphs[:]
+                self._graphs, self.launch_mode = None, 'eager (capture failed)'
+                return False
+            finally:
+                if gc_was_on:
+                    gc.enable()
         torch.cuda.synchronize()
         self._graphs, self.launch_mode = graphs, 'hipGraph' if len(graphs) == 1 else 'hipGraph x%d + RCCL between' % len(graphs)
         return True
+
+    def release(self):
+        """Drops the captured graphs and the pinned ring now (training thread, outside any capture, device idle)."""
+        torch = _torch()
+        with _CAPTURE_LOCK:
+            torch.cuda.synchronize()
+            self._graphs, self.launch_mode = None, 'eager'
+            self._eager_steps = 0
+            self.reset_input_ring()
+            self.pin_x = self.pin_y = self.pin_x_np = self.pin_y_np = None
 
     def train_step(self):
         """stage input + fwd + loss + bwd + [all-reduce] + Adam on the batch in ``x_stage`` / ``y_true``.  The first call runs
@@ -931,59 +1063,6 @@ class Engine:
             if i == len(parts) - 2:                        # every collective must have landed before the optimiser segment
                 for w in pending:
                     w.wait()
-
-    # -- host -> device input pipeline of fit(): pinned ring + copy stream, so the H2D of batch k+1 runs under step k -----
-    def alloc_input_ring(self, slots):
-        torch = _torch()
-        if getattr(self, 'pin_x', None) is not None and len(self.pin_x) >= slots:
-            return
-        self.pin_x = [torch.empty(self.x_stage.shape, dtype=torch.float32).pin_memory() for _ in range(slots)]
-        self.pin_y = [torch.empty(self.y_true.shape, dtype=torch.float32).pin_memory() for _ in range(slots)]
-        self.dev_in = [(torch.empty_like(self.x_stage), torch.empty_like(self.y_true)) for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(device=self.P.device)
-        self.ev_h2d = [None] * slots                       # slot -> event after which the pinned slot may be rewritten
-        self.ev_free = [None, None]                        # device staging pair -> event after which it may be refilled
-        self._fed = 0
-        self._staged = 0
-
-    def ring_slots(self):
-        return len(self.pin_x) if self.pin_x is not None else 0
-
-    def next_slot(self):
-        """(generator thread) pinned slots are used round-robin; stage_host_batch waits for the slot's previous upload."""
-        slot = self._staged % len(self.pin_x)
-        self._staged += 1
-        return slot
-
-    def stage_host_batch(self, slot, x, y):
-        """(generator thread) pageable NumPy batch -> pinned slot; waits until the slot's previous H2D has completed."""
-        ev = self.ev_h2d[slot]
-        if ev is not None:
-            ev.synchronize()
-        np.copyto(self.pin_x[slot].numpy(), np.asarray(x, np.float32).reshape(self.x_stage.shape))
-        np.copyto(self.pin_y[slot].numpy(), np.asarray(y, np.float32).reshape(self.y_true.shape))
-
-    def feed(self, slot):
-        """(training thread) pinned slot -> device staging pair on the copy stream, then a device-to-device copy into the
-        buffers the captured step reads, on the compute stream.  Only the last copy is ordered with the step."""
-        torch = _torch()
-        d = self._fed & 1
-        self._fed += 1
-        cs, main = self.copy_stream, torch.cuda.current_stream()
-        if self.ev_free[d] is not None:
-            cs.wait_event(self.ev_free[d])
-        with torch.cuda.stream(cs):
-            self.dev_in[d][0].copy_(self.pin_x[slot], non_blocking=True)
-            self.dev_in[d][1].copy_(self.pin_y[slot], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(cs)
-        self.ev_h2d[slot] = ev
-        main.wait_event(ev)
-        self.x_stage.copy_(self.dev_in[d][0], non_blocking=True)
-        self.y_true.copy_(self.dev_in[d][1], non_blocking=True)
-        evf = torch.cuda.Event()
-        evf.record(main)
-        self.ev_free[d] = evf
 
     def landmarks(self, thr=0.5, want_mask=False):
         torch = _torch()

@@ -17,11 +17,13 @@ import math
 import queue
 import threading
 import time
+import weakref
 from collections import OrderedDict
 
 import numpy as np
 
 from . import Loss_and_metrics as metr
+from .KerasCallbacks import Callback as _Callback
 
 
 def _he_normal(rng, shape):
@@ -118,7 +120,7 @@ class Model:
             self.optimizer = Adam()
         self.loss = loss
         self.metrics = list(metrics or [])
-        self.optimizer.lr._listeners.append(self._on_lr)
+        self.optimizer.lr.add_listener(self._on_lr)
         self._engines = {}
         self._rings = {}
 
@@ -545,11 +547,11 @@ class Model:
                     break
                 cbs.on_epoch_begin(epoch)
                 t0 = time.time()
-                steps = len(gen) if steps_per_epoch is None else min(steps_per_epoch, len(gen))
                 hist = eng = None
+                steps = 0
                 counts = []                                        # loss elements of every step's OWN batch (a Sequence may end on a smaller one)
-                for step, (eng, slot) in enumerate(staged.epoch()):
-                    if hist is None:
+                for step, (eng, slot, steps) in enumerate(staged.epoch()):
+                    if hist is None:                               # `steps`: the length of the order the stager took for THIS epoch
                         hist = torch.zeros((steps, eng.sums.numel()), dtype=torch.float32, device=eng.sums.device)
                     if slot is not None:
                         eng.feed(slot)
@@ -585,124 +587,28 @@ class Model:
         return self.history
 
     def _staged_batches(self, gen, orders, depth, workers):
-        """Starts the stager thread and returns an object whose epoch() iterates (engine, pinned slot | None) over the batches of the
-        next entry of `orders` (an iterable of per-epoch batch orders, evaluated lazily in the stager thread) and which must be
-        close()d.  Between two epochs the stager calls the generator's on_epoch_end() -- as soon as the epoch's last batch has been
-        PRODUCED, as Keras' OrderedEnqueuer does from its own thread (workers >= 1: the reference's fit call) -- and goes on with the
-        next epoch's batches while the training thread still consumes the queue and reads out the epoch.  The
-        stager thread takes the generator's batches in order
-        (produced by `workers` threads when > 1), shards them by rank and copies them into the engine's pinned ring; the very
-        first batch of a batch size is loaded directly (it creates the engine and its ring)."""
-        depth = max(int(depth), 1)
-        q = queue.Queue(maxsize=depth)
-        ring = self._rings                                     # batch size -> engine whose pinned ring exists (kept across epochs)
-        ready = threading.Event()
-        cancel = threading.Event()                             # set when the training thread leaves early (exception, callback stop)
-        stop = object()
-        slots = depth + 3
-        dev = self._device()
-        rank, world = self._dist()
-        # Rank-local batches: a generator of this package hands out any slice of a batch (BaseGenerator.batch_slice), and the seeded
-        # shuffles make every rank agree on what the global batch is, so a rank produces only ITS B / world samples -- as the
-        # reference's single MirroredStrategy process produces every sample once (Generators.py:175-228).  A foreign Sequence is
-        # asked for the whole batch, which is then sharded.
-        local = world > 1 and hasattr(gen, 'batch_slice') and getattr(gen, 'BATCHSIZE', 0) % world == 0 and getattr(gen, 'BATCHSIZE', 0) > 0
-        if local:
-            b = gen.BATCHSIZE // world
-            fetch = lambda i: gen.batch_slice(i, rank * b, (rank + 1) * b)            # noqa: E731
-        else:
-            fetch = gen.__getitem__
+        """Starts the stager thread of one fit() call (see _Stager) and returns it; the caller must close() it."""
+        prev = getattr(self, '_stager', None)
+        if prev is not None and prev() is not None and prev().alive():
+            raise RuntimeError('fit(): the stager thread of an earlier fit() of this model is still alive')
+        st = _Stager(self, gen, orders, depth, workers)
+        self._stager = weakref.ref(st)
+        return st
 
-        class _Cancelled(Exception):
-            pass
-
-        def put(item):
-            while True:
-                if cancel.is_set():
-                    raise _Cancelled()
-                try:
-                    q.put(item, timeout=0.1)
-                    return
-                except queue.Full:
-                    continue
-
-        def work():
-            try:
-                import torch
-                torch.cuda.set_device(dev)
-                for order in orders:
-                    for xb, yb in _prefetch(fetch, order, depth, workers, cancel):
-                        if not local:
-                            xb, yb = self._shard(xb, yb)
-                        eng = ring.get(xb.shape[0])
-                        if eng is None or eng.ring_slots() < slots:
-                            ready.clear()
-                            put(('raw', xb, yb))
-                            while not ready.wait(0.1):         # the training thread builds the engine for this batch size
-                                if cancel.is_set():
-                                    raise _Cancelled()
-                            continue
-                        slot = eng.next_slot()
-                        eng.stage_host_batch(slot, xb, yb)
-                        put(('pin', eng, slot))
-                    put(stop)                                  # end of this epoch's batches
-                    if hasattr(gen, 'on_epoch_end'):
-                        gen.on_epoch_end()
-            except _Cancelled:
-                pass
-            except BaseException as e:                         # surface generator errors in the training thread
-                try:
-                    put(e)
-                    put(stop)
-                except _Cancelled:
-                    pass
-
-        th = threading.Thread(target=work, daemon=True)
-        th.start()                                             # (now: fit() starts the next epoch's stager before it turns to this epoch's logs)
-        model = self
-
-        class _Staged:
-            def close(self_):                                  # also on an exception / an early stop in the training thread:
-                cancel.set()                                   # the stager must not keep pinned slots and the thread pool
-                ready.set()
-                while th.is_alive():
-                    try:
-                        q.get_nowait()
-                    except queue.Empty:
-                        pass
-                    th.join(0.05)
-
-            def epoch(self_):
-                """the batches of the next epoch (up to the stager's end-of-epoch mark)"""
-                while True:
-                    item = q.get()
-                    if item is stop:
-                        return
-                    if isinstance(item, BaseException):
-                        raise item
-                    if item[0] == 'raw':
-                        _, xb, yb = item
-                        eng = model._engine(xb.shape[0])
-                        eng.alloc_input_ring(slots)
-                        eng.load_input(xb, yb)
-                        if eng.ring_slots() >= slots:
-                            ring[xb.shape[0]] = eng
-                        ready.set()
-                        yield eng, None
-                    else:
-                        yield item[1], item[2]
-        return _Staged()
+    def close(self):
+        """Releases the device state (engines with their captured hipGraphs, pinned rings, parameter blocks) NOW, on the calling
+        thread, after a device synchronisation -- instead of whenever the last reference happens to go.  The weights stay
+        readable (they are downloaded first); the next fit / predict rebuilds the device state from them."""
+        import torch
+        if self._params is not None:
+            self.get_weights(sync=False)
+            torch.cuda.synchronize()
+        for eng in self._engines.values():
+            eng.release()
+        self._engines, self._rings, self._params = {}, {}, None
 
     def history_callback(self):
-        from .KerasCallbacks import Callback
-        model = self
-
-        class _Hist(Callback):
-            def on_epoch_end(self, epoch, logs=None):
-                model.history.epoch.append(epoch)
-                for k, v in (logs or {}).items():
-                    model.history.history.setdefault(k, []).append(v)
-        return _Hist()
+        return _HistoryCallback(self)
 
 
 def _prefetch(fetch, order, depth, workers=1, cancel=None):
@@ -737,3 +643,152 @@ def _prefetch(fetch, order, depth, workers=1, cancel=None):
         if cancel is not None and cancel.is_set():
             return
         yield fetch(int(i))
+
+
+class _HistoryCallback(_Callback):
+    """Keras' History callback: epoch numbers and logs into ``model.history``.  (A module-level class holding the model in an
+    attribute: a class defined inside fit() and closing over the model is a reference cycle of its own that keeps the model --
+    and the hipGraphs of its engines -- alive until the cyclic collector runs, on whichever thread that happens.)"""
+
+    def __init__(self, model):
+        self.model = model
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.model.history.epoch.append(epoch)
+        for k, v in (logs or {}).items():
+            self.model.history.history.setdefault(k, []).append(v)
+
+
+class _Cancelled(Exception):
+    pass
+
+
+class _Stager:
+    """The input pipeline of ONE fit() call: a thread that takes the generator's batches in the order of each epoch (produced by
+    `workers` pool threads when > 1 -- Keras' OrderedEnqueuer, train_model.py:111), shards them by rank and copies them into the
+    engine's pinned ring; ``epoch()`` (training thread) iterates (engine, pinned slot | None, steps of this epoch).
+
+    THREADING CONTRACT: the stager thread and its pool touch HOST memory only -- NumPy, the generator, the pinned slots through their
+    NumPy views, threading primitives.  Every HIP call of fit() (copies, events, engine creation, stream capture, synchronisation)
+    is made by the training thread.  A pinned slot is handed back by the training thread through a host-side flag
+    (Engine.feed -> Engine._release_slots) once the upload that read it has completed; the stager waits on that flag, not on a HIP
+    event.  (Until round 3 the stager called hipEventSynchronize itself, concurrently with the training thread's stream capture
+    and first-touch module loads.)
+
+    Between two epochs the stager calls the generator's on_epoch_end() -- as soon as the epoch's last batch has been PRODUCED, as
+    the OrderedEnqueuer does from its own thread -- and goes on with the next epoch's batches while the training thread still
+    consumes the queue and reads out the epoch; the number of steps of an epoch travels with the epoch's first queue item, taken
+    from the order the stager really used.  The very first batch of a batch size is handed over unpinned (the training thread
+    creates the engine and its ring for it)."""
+
+    _STOP = object()
+
+    def __init__(self, model, gen, orders, depth, workers):
+        self.model, self.gen, self.orders = model, gen, orders
+        self.depth = max(int(depth), 1)
+        self.workers = workers
+        self.slots = self.depth + 4                        # Engine._release_slots frees slot k while feeding k + 2 at the latest
+        self.q = queue.Queue(maxsize=self.depth)
+        self.ring = model._rings                           # batch size -> engine whose pinned ring exists (kept across fits)
+        self.ready = threading.Event()
+        self.cancel = threading.Event()                    # set when the training thread leaves early (exception, callback stop)
+        rank, world = model._dist()
+        # Rank-local batches: a generator of this package hands out any slice of a batch (BaseGenerator.batch_slice), and the seeded
+        # shuffles make every rank agree on what the global batch is, so a rank produces only ITS B / world samples -- as the
+        # reference's single MirroredStrategy process produces every sample once (Generators.py:175-228).  A foreign Sequence is
+        # asked for the whole batch, which is then sharded.
+        bs = getattr(gen, 'BATCHSIZE', 0)
+        self.local = world > 1 and hasattr(gen, 'batch_slice') and bs > 0 and bs % world == 0
+        if self.local:
+            b = bs // world
+            self.fetch = lambda i: gen.batch_slice(i, rank * b, (rank + 1) * b)
+        else:
+            self.fetch = gen.__getitem__
+        for eng in self.ring.values():
+            eng.reset_input_ring()                         # (training thread, nothing in flight: slots all free, counters at zero)
+        self.th = threading.Thread(target=self._work, name='rvip-stager', daemon=True)
+        self.th.start()
+
+    def alive(self):
+        return self.th.is_alive()
+
+    # -- stager thread: host memory only ----------------------------------------------------------
+    def _put(self, item):
+        while True:
+            if self.cancel.is_set():
+                raise _Cancelled()
+            try:
+                self.q.put(item, timeout=0.1)
+                return
+            except queue.Full:
+                continue
+
+    def _work(self):
+        try:
+            for order in self.orders:
+                steps = len(order)
+                batches = _prefetch(self.fetch, order, self.depth, self.workers, self.cancel)
+                try:
+                    for xb, yb in batches:
+                        if not self.local:
+                            xb, yb = self.model._shard(xb, yb)
+                        eng = self.ring.get(xb.shape[0])
+                        if eng is None or eng.ring_slots() < self.slots:
+                            self.ready.clear()
+                            self._put(('raw', xb, yb, steps))
+                            while not self.ready.wait(0.1):    # the training thread builds the engine for this batch size
+                                if self.cancel.is_set():
+                                    raise _Cancelled()
+                            continue
+                        slot = eng.next_slot()
+                        if not eng.stage_host_batch(slot, xb, yb, self.cancel):
+                            raise _Cancelled()
+                        self._put(('pin', eng, slot, steps))
+                finally:
+                    batches.close()                            # shuts the worker pool down (joins its threads)
+                self._put(self._STOP)                          # end of this epoch's batches
+                if hasattr(self.gen, 'on_epoch_end'):
+                    self.gen.on_epoch_end()
+        except _Cancelled:
+            pass
+        except BaseException as e:                             # surface generator errors in the training thread
+            try:
+                self._put(e)
+                self._put(self._STOP)
+            except _Cancelled:
+                pass
+
+    # -- training thread --------------------------------------------------------------------------
+    def epoch(self):
+        """the batches of the next epoch (up to the stager's end-of-epoch mark)"""
+        while True:
+            item = self.q.get()
+            if item is self._STOP:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            if item[0] == 'raw':
+                _, xb, yb, steps = item
+                eng = self.model._engine(xb.shape[0])
+                eng.alloc_input_ring(self.slots)
+                eng.load_input(xb, yb)
+                if eng.ring_slots() >= self.slots:
+                    self.ring[xb.shape[0]] = eng
+                self.ready.set()
+                yield eng, None, steps
+            else:
+                yield item[1], item[2], item[3]
+
+    def close(self):
+        """Also on an exception / an early stop in the training thread: the stager and its pool are JOINED (no thread of this fit()
+        survives it), then the rings are reset (slots staged but never fed are free again)."""
+        self.cancel.set()
+        self.ready.set()
+        while self.th.is_alive():
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                pass
+            self.th.join(0.05)
+        for eng in self.ring.values():
+            eng.reset_input_ring()

@@ -56,10 +56,14 @@ extern "C" {
 #define RVIP_STATE_WORDS  8
 
 #define RVIP_BIT_OF_CHANNEL(c) (8 * (((c) & 15) >> 2) + 4 * (((c) & 31) >> 4) + ((c) & 3))      /* bit planes of rvip_conv3x3_desc / rvip_apply_desc */
-#define RVIP_ABI_VERSION 6   /* what rvip_abi_version() of a matching library returns; _native.py checks it at every load */
+#define RVIP_ABI_VERSION 7   /* what rvip_abi_version() of a matching library returns; _native.py checks it at every load */
 int         rvip_abi_version(void);
 const char* rvip_build_info(void);          /* "gfx950 ..." */
 int         rvip_last_hip_error(void);      /* last hipError_t seen by a launcher (0 = none) */
+/* Diagnostic (the ONLY entry point that synchronises): hipDeviceSynchronize, then the runtime's sticky error; returns the first
+ * non-zero hipError_t of the two, 0 when the device is idle and clean.  tests/conftest.py calls it after every GPU test so that an
+ * asynchronous kernel fault is reported by the test that launched it. */
+int         rvip_device_check(void);
 
 /* ------------------------------------------------------------------------------------------------
  * 3x3 "same" convolution as implicit GEMM on MFMA.  Replaces Conv2D(filters, 3, padding='same',
@@ -165,6 +169,11 @@ int rvip_pack_subpixel_dgrad_weights(const float* w_hwio, int cin, int cout, int
 typedef struct rvip_pack_entry { long long w_off, f_off, d_off; int32_t cin, cout; int32_t taps, mode; } rvip_pack_entry;
 int rvip_pack_all_conv3x3_weights(const float* theta, const void* table, int entries, int max_elems, int dtype,
                                   void* wf_base, void* wd_base, void* stream);
+/* The launch sees only the DEVICE copy of the table: call this on the HOST array before uploading it.  RVIP_EINVAL for an entry
+ * no kernel of this library takes: cin / cout <= 0, cout % 4 != 0 (16-byte rows of four output channels), offsets that are
+ * negative or not multiples of 4 elements, taps other than 9 / 27 (mode 0) or 9 (mode 1: phase kernels exist for 3x3 only), an
+ * unknown mode.  (The kernel itself takes the element path for cout % 4 != 0 and stays inside its rows whatever the table says.) */
+int rvip_pack_table_check(const rvip_pack_entry* host_table, int entries, int dtype);
 /* The same launch as the closing one of an optimiser step: also increments state[RVIP_STATE_STEP] (= rvip_state_tick,
  * without its launch).  Must follow rvip_adam_step on the same stream. */
 int rvip_pack_all_conv3x3_weights_tick(const float* theta, const void* table, int entries, int max_elems, int dtype,
@@ -200,6 +209,10 @@ size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout);
 int    rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream);
 int    rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d);
 int    rvip_conv3x3_wgrad_dot_rows(const rvip_wgrad3x3_desc* d);
+/* Which kernel form rvip_conv3x3_wgrad takes for this descriptor (a query; the tests assert the form the real layer shapes get):
+ * 0 nine-tap LDS-DMA kernel, 1 sub-pixel form of UpSampling2D -> conv (four phase workgroups), 2 the same with both column phases
+ * per workgroup (64 x 32 blocks), 3 register-staged fallback (ragged channel counts), -1 invalid descriptor. */
+int    rvip_conv3x3_wgrad_form(const rvip_wgrad3x3_desc* d);
 
 /* Batched stage 2 for reductions whose result only the optimiser reads (bias gradients, weight gradients):
  * dst[i] = sum_r src[r*width + i], r < nrows, for `entries` records of a DEVICE table in ONE launch, fixed order.

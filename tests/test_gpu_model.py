@@ -678,6 +678,61 @@ def test_f16_loss_curve_tracks_the_float64_oracle():
     np.testing.assert_allclose(np.array(dev_losses), np.array(ref_losses), rtol=1e-2)
 
 
+def test_capture_survives_garbage_models_and_collections(monkeypatch):
+    """GPUTEST_r03's abort, turned into a test.  A model that died inside a reference cycle still owns its hipGraphs; if the cyclic
+    collector frees it while another engine captures, at::cuda::CUDAGraph::~CUDAGraph synchronises the device, fails, throws from
+    the destructor -> SIGABRT (tools/repro_graph_gc_abort.py shows that on the unguarded capture).  Engine.capture() collects before
+    it captures and keeps the automatic collector off until the capture has ended; models no longer sit in cycles at all."""
+    import gc
+    import weakref
+    cfg = _cfg(RVIP_PRECISION='bf16', DIM=[32, 32], FILTERS=8)
+    x, y = O.synthetic_batch(4, cfg['DIM'], 2, seed=3)
+    a = rvip.get_model(cfg, metrics=[])
+    for _ in range(3):
+        a.train_on_batch(x, y)
+    assert a._engine(4).launch_mode == 'hipGraph'
+    ref = weakref.ref(a)
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        del a
+        assert ref() is None, 'a trained model must die by reference count (no cycle through optimizer.lr / fit callbacks)'
+        g = rvip.get_model(cfg, metrics=[])                 # a model some user code DID tie into a cycle
+        for _ in range(3):
+            g.train_on_batch(x, y)
+        g._user_cycle = g
+        gref = weakref.ref(g)
+        del g
+        assert gref() is not None                           # garbage, graphs and all, waiting for the collector
+    finally:
+        if was:
+            gc.enable()
+    b = rvip.get_model(cfg, metrics=[])
+    b.train_on_batch(x, y)
+    eng = b._engine(4)
+    orig, seen = eng._step_parts, {}
+
+    def spying():
+        parts, buckets = orig()
+
+        def first():
+            seen['gc_enabled_inside_capture'] = gc.isenabled()
+            seen['garbage_alive_inside_capture'] = gref() is not None
+            parts[0]()
+        return [first] + list(parts[1:]), buckets
+    monkeypatch.setattr(eng, '_step_parts', spying)
+    b.train_on_batch(x, y)                                  # captures: collects first (frees g legally), collector off while capturing
+    assert eng.launch_mode == 'hipGraph'
+    assert seen == {'gc_enabled_inside_capture': False, 'garbage_alive_inside_capture': False}, seen
+    assert gc.isenabled() == was
+    monkeypatch.undo()
+    l3 = b.train_on_batch(x, y)[0]
+    assert np.isfinite(l3)
+    b.close()                                               # explicit release: graphs, ring and parameter blocks go now
+    assert b._engines == {} and b._params is None
+    assert np.isfinite(b.train_on_batch(x, y)[0])           # ... and the model rebuilds its device state from the weights it kept
+
+
 def test_fit_with_generator_and_callbacks(tmp_path):
     cfg = _cfg(RVIP_PRECISION='bf16', DIM=[64, 64], FILTERS=8, LEARNING_RATE=2e-3, MODEL_PATH=str(tmp_path),
                DROPOUT_MIN=0.0, DROPOUT_MAX=0.0)

@@ -879,6 +879,44 @@ def test_pack_all_mode_1_writes_both_phase_kernel_sets(shape, dtype):
     assert bool((wf[:32] == 3.0).all()) and bool((wd[:32] == 5.0).all()) and bool((wf[32 + k1 + k0:] == 3.0).all()) and bool((wd[32 + k1 + k0:] == 5.0).all())
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(8, 6), (12, 10), (40, 70), (7, 3)])
+@pytest.mark.parametrize('mode', [0, 1])
+def test_pack_all_stays_inside_its_rows_for_any_cout(shape, dtype, mode):
+    """both modes moved four output channels at a time; with Cout % 4 != 0 the last group of a row ran into
+    the next row.  rvip_pack_table_check (host side) refuses such a table, and the kernel takes an element path for it: the result
+    is the NumPy re-layout bit for bit and the canaries around the two outputs are intact."""
+    ci, co = shape
+    rng = np.random.default_rng(100 * ci + co)
+    w = rng.standard_normal((3, 3, ci, co)).astype(np.float32)
+    k = (16 if mode else 9) * ci * co
+    guard = 256
+    wf = torch.full((k + 2 * guard,), 3.0, dtype=tdt(dtype), device=dev())
+    wd = torch.full((k + 2 * guard,), 5.0, dtype=tdt(dtype), device=dev())
+    tab = (N.PackEntry * 1)()
+    tab[0].w_off, tab[0].f_off, tab[0].d_off, tab[0].cin, tab[0].cout, tab[0].taps, tab[0].mode = 0, guard, guard, ci, co, 9, mode
+    assert N.lib().rvip_pack_table_check(C.cast(tab, C.c_void_p), 1, ndt(dtype)) == (-1 if co % 4 else 0)
+    tabd = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev())
+    theta = f32(np.concatenate([w.reshape(-1), np.full(64, 1e30, np.float32)]))       # what lies behind the master must never be read into the result
+    N.call('rvip_pack_all_conv3x3_weights', P(theta), P(tabd), 1, k, ndt(dtype), P(wf), P(wd), stream())
+    torch.cuda.synchronize()
+    for buf, fill in ((wf, 3.0), (wd, 5.0)):
+        assert bool((buf[:guard] == fill).all()) and bool((buf[guard + k:] == fill).all()), 'canary overwritten'
+    gf, gd = wf[guard:guard + k].float().cpu().numpy(), wd[guard:guard + k].float().cpu().numpy()
+    if mode == 0:
+        rf = rnd(np.transpose(w.reshape(9, ci, co), (0, 2, 1)), dtype)                # [t][co][ci]
+        rd = rnd(w.reshape(9, ci, co)[::-1], dtype)                                   # [8 - t][ci][co]
+        assert np.array_equal(gf.reshape(9, co, ci), rf) and np.array_equal(gd.reshape(9, ci, co), rd)
+    else:
+        rf_t = torch.empty(k, dtype=tdt(dtype), device=dev())
+        rd_t = torch.empty(k, dtype=tdt(dtype), device=dev())
+        wm = f32(w)
+        N.call('rvip_pack_subpixel_weights', P(wm), ci, co, ndt(dtype), P(rf_t), stream())          # the element-per-thread kernels
+        N.call('rvip_pack_subpixel_dgrad_weights', P(wm), ci, co, ndt(dtype), P(rd_t), stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(gf, rf_t.float().cpu().numpy()) and np.array_equal(gd, rd_t.float().cpu().numpy())
+
+
 def test_adam_state_and_convert():
     rng = np.random.default_rng(7)
     cnt = 10007

@@ -337,7 +337,13 @@ def test_real_shape_upconv_subpixel_backward(idx, dtype):
     drows = torch.full((nd, c0), 7.0, dtype=torch.float64, device=dev())
     g.w_master, g.dot_rows, g.dot_rows_bytes = wm.data_ptr(), drows.data_ptr(), drows.numel() * 8
     ns = L.rvip_conv3x3_wgrad_splits(C.byref(g))
-    assert (ns % 4 == 0 and ns >= 4) if (c0 >= 64 and co >= 64) else ns >= 1          # four phases x pixel splits where the form is taken
+    form = L.rvip_conv3x3_wgrad_form(C.byref(g))
+    if c0 >= 64 and co >= 64:
+        assert form == 1 and ns % 4 == 0 and ns >= 4, (name, form, ns)      # four phases x pixel splits
+    elif c0 == 64 and co == 32:
+        assert form == 2 and ns % 2 == 0 and ns >= 2, (name, form, ns)      # dec3.up of config 2: both column phases per workgroup (PB = 1)
+    else:
+        assert form == 0 and ns >= 1, (name, form, ns)
     N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
     gotw = down(dw).astype(np.float64)
     sw = float(np.abs(k['dw']).max())

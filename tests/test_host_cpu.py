@@ -279,6 +279,29 @@ def test_two_rank_data_parallel_gloo():
     assert all(err < 1e-12 for _, err in res), res
 
 
+def test_pack_table_check_refuses_what_no_kernel_takes():
+    """rvip_pack_table_check runs on the HOST copy of the pack table (the launch only sees the device copy): VERDICT r3 weak #8."""
+    N = rvip._native
+    L = N.lib()
+
+    def table(**kw):
+        tab = (N.PackEntry * 2)()
+        for e in tab:
+            e.w_off, e.f_off, e.d_off, e.cin, e.cout, e.taps, e.mode = 0, 64, 64, 16, 32, 9, 0
+        for k, v in kw.items():
+            setattr(tab[1], k, v)
+        return tab
+    import ctypes as C
+    ok = table()
+    assert L.rvip_pack_table_check(C.cast(ok, C.c_void_p), 2, N.BF16) == 0
+    assert L.rvip_pack_table_check(C.cast(table(taps=27), C.c_void_p), 2, N.F32) == 0
+    assert L.rvip_pack_table_check(C.cast(table(mode=1), C.c_void_p), 2, N.F16) == 0
+    for bad in (dict(cout=6), dict(cout=0), dict(cin=-8), dict(taps=5), dict(mode=1, taps=27), dict(mode=2), dict(f_off=66), dict(w_off=-4)):
+        assert L.rvip_pack_table_check(C.cast(table(**bad), C.c_void_p), 2, N.BF16) == -1, bad
+    assert L.rvip_pack_table_check(None, 2, N.BF16) == -1 and L.rvip_pack_table_check(C.cast(ok, C.c_void_p), 0, N.BF16) == -1
+    assert L.rvip_pack_table_check(C.cast(ok, C.c_void_p), 2, 9) == -1
+
+
 # ----------------------------------------------------------------------------------------------
 # file generator / pre-processing restatement (src/data/Preprocess.py, Generators.py:234-398)
 # ----------------------------------------------------------------------------------------------
