@@ -72,4 +72,5 @@ if __name__ == '__main__':
     for mode in ('old', 'new'):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), mode], capture_output=True, text=True, timeout=300)
         print('=== child %s: rc %d' % (mode, r.returncode))
-        print((r.stdout + r.stderr)[-1500:])
+        out = r.stdout + r.stderr
+        print(out if len(out) < 2400 else out[:1200] + '\n...\n' + out[-800:])
