@@ -28,8 +28,8 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0       # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = 'r03_pmc_summary.json'
-KERNEL_STATS = 'r03_bench_kernel_stats.csv'          # rocprofv3 --kernel-trace --stats of this command (tools/profile_round.sh), + .meta.json
+PMC_SUMMARY = 'r04_pmc_summary.json'
+KERNEL_STATS = 'r04_bench_kernel_stats.csv'          # rocprofv3 --kernel-trace --stats of this command (tools/profile_round.sh), + .meta.json
 
 
 def csrc_sha16():
@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--depth', type=int, default=4, help='U-Net levels (headline: 4; cfg 4: 5)')
     ap.add_argument('--frames', type=int, default=0, help='> 0: 3-D cine graph on [frames, dim, dim] volumes (cfg 5: 16), Conv3D 3x3x3, pool (1,2,2)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'], help='fp16: BASELINE.json configs[3] (static loss scaling)')
+    ap.add_argument('--loss', default='mse', choices=['mse', 'bce_dice'], help="bce_dice: the Train notebook's loss (Train_tests.ipynb:219, Loss_and_metrics.py:229-245); the headline is MSE (train_model.py:184)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--no-fit', action='store_true', help='skip the Model.fit throughput measurement')
@@ -70,6 +71,7 @@ def main():
     import numpy as np
     import torch
     rvip = importlib.import_module('cmr-landmark-detection_amd')
+    capture_guard = importlib.import_module('cmr-landmark-detection_amd.engine').capture_guard
     M = rvip.Loss_and_metrics
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -92,7 +94,7 @@ def main():
 
     cfg = dict(DIM=[args.dim, args.dim], FILTERS=args.filters, DEPTH=args.depth, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
                MASK_CLASSES=2, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-4, RVIP_PRECISION=args.precision,
-               LOSS_FUNCTION=M.mse, SEED=42)
+               LOSS_FUNCTION=M.mse if args.loss == 'mse' else M.bce_dice_loss, SEED=42)
     if args.frames > 0:
         cfg.update(DIM=[args.frames, args.dim, args.dim], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3])
     model = rvip.get_model(cfg, metrics=[])
@@ -213,7 +215,7 @@ def main():
         def family_ms(calls, nrep=20):
             """ms per step of `calls` launched back to back: a hipGraph of exactly these launches, replayed nrep times between two events"""
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_guard(), torch.cuda.graph(g):
                 cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
                 for fn, a in calls:
                     assert fn(*a, cs) == 0
@@ -331,17 +333,18 @@ def main():
             'value': round(value, 2), 'unit': 'slices/s' if args.frames <= 0 else 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'fp16': 'f16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': '%d-level %s U-Net F=%d, %s, batch %d per GPU, fwd+loss(MSE)+bwd+Adam%s' % (
+            'config': {'workload': '%d-level %s U-Net F=%d, %s, batch %d per GPU, fwd+loss(%s)+bwd+Adam%s' % (
                 args.depth, '3D cine (Conv3D 3x3x3, pool 1x2x2)' if args.frames > 0 else '2D', args.filters,
                 ('%dx%dx%d' % (args.frames, args.dim, args.dim)) if args.frames > 0 else '%dx%d' % (args.dim, args.dim), B,
-                ' + RCCL grad all-reduce' if world > 1 else ''),
+                'MSE' if args.loss == 'mse' else 'BCE-Dice',
+                (' + %s grad all-reduce' % ('RCCL' if backend == 'nccl' else backend)) if world > 1 else ''),
                 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch, 'collective': ('%s all-reduce of %d fp32 gradients' % (backend, model._params.count)) if world > 1 else None,
                 'gflop_per_slice_fwd_bwd': round(step_flops / 1e9, 3)},
             'fit_slices_per_s': fit_rate, 'fit': fit_info, 'predict_slices_per_s_eager': predict_rate, 'hbm_allocated_gib': hbm_gb,
             'hbm_bytes_per_step': hbm_step, 'algorithmic_bytes_per_step': round(plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * B),
             'wasted_traffic_ratio': round(hbm_step / (plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * B), 3) if hbm_step else None,
             'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),
-            'loss': loss, 'steps_executed_total': max(2, min(args.warmup, 3)) + args.warmup + args.steps + 3,
+            'loss': loss, 'steps_executed_total': max(2, min(args.warmup, 3)) + args.warmup + args.steps + (0 if args.no_roofline_pass else 3),
             'roofline': roof,
             'roofline_wgrad': roof_wg if roof is not None else None,
             'kernels': per_kernel,

@@ -17,6 +17,7 @@ Data layout in HBM (per rank)
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import gc
 import os
@@ -37,6 +38,33 @@ _CAPTURE_LOCK = threading.RLock()            # one stream capture at a time per 
 def _torch():
     import torch
     return torch
+
+
+@contextlib.contextmanager
+def capture_guard():
+    """Everything that captures a hipGraph in this process does it inside this guard (Engine.capture, bench.py's family graphs):
+    one capture at a time; the device idle and Python's garbage collected BEFORE it (dead engines release their graphs here, on
+    this thread, legally); the automatic collector off -- it is process-global, so for every thread -- until the capture has ended.
+    See Engine.capture for why."""
+    torch = _torch()
+    with _CAPTURE_LOCK:
+        torch.cuda.synchronize()
+        gc.collect()
+        was_on = gc.isenabled()
+        gc.disable()
+        try:
+            yield
+        finally:
+            if was_on:
+                gc.enable()
+
+
+def _dist_ready():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
 
 
 def require_gpu():
@@ -336,6 +364,9 @@ class Engine(InputRing):
                 raise NotImplementedError('IMG_CHANNELS = %d: built for 2..4 channels on 2-D graphs with FILTERS / %d a power of two' % (ci, ve))
         dev, T = P.device, P.tdtype
         self.world = world
+        # the data-parallel schedule (segments with the gradient all-reduce between them) -- also for a process group of ONE rank
+        # when RVIP_FORCE_DP_SCHEDULE=1: the 1-GPU lease's way to run communicator, stream ordering and segment capture against RCCL
+        self.dp = world > 1 or (os.environ.get('RVIP_FORCE_DP_SCHEDULE') == '1' and _dist_ready())
         self.loss_kind = N.LOSS_MSE if loss_kind == 'mse' else N.LOSS_BCE_DICE
         self.w_bce, self.w_dice = float(w_bce), float(w_dice)
         self.sum_reduction = bool(sum_reduction)     # BceDiceLoss class form: objective = SUM over the replica's B*H*W elements
@@ -955,13 +986,13 @@ class Engine(InputRing):
         self._run(self.opt, self.stream())
 
     def allreduce_grads(self):
-        if self.world > 1:
+        if self.dp:
             import torch.distributed as dist
             dist.all_reduce(self.P.grad)                   # RCCL sum over xGMI; loss is pre-divided by the global batch
 
     # -- overlapped data-parallel step: two gradient buckets ------------------------------------------------------
     def overlap_ok(self):
-        return (self.world > 1 and self.bwd_split and 0 < self.grad_split < self.P.grad.numel()
+        return (self.dp and self.bwd_split and 0 < self.grad_split < self.P.grad.numel()
                 and os.environ.get('RVIP_OVERLAP_ALLREDUCE', '1') != '0')
 
     def backward_part(self, part):
@@ -989,7 +1020,7 @@ class Engine(InputRing):
             self._run(self.fwd_train, self.stream())
             self.backward_part(0)
         opt = lambda: self._run(self.opt, self.stream())                                   # noqa: E731
-        if self.world == 1:
+        if not self.dp:
             return [lambda: (a_all(), opt())], []
         if self.overlap_ok():
             return [a_head, lambda: self.backward_part(1), opt], [0, 1]
@@ -1009,27 +1040,20 @@ class Engine(InputRing):
         torch = _torch()
         parts, _ = self._step_parts()
         graphs = []
-        with _CAPTURE_LOCK:
-            torch.cuda.synchronize()
-            gc.collect()                                       # dead engines release their graphs here, legally
-            gc_was_on = gc.isenabled()
-            gc.disable()
-            try:
+        try:
+            with capture_guard():
                 for fn in parts:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode='thread_local'):       # other threads' (host-only) work is not our capture's business
                         fn()
                     graphs.append(g)
-            except Exception as e:                                                        # pragma: no cover (needs a failing runtime)
-                import sys
-                sys.stderr.write('rvip: hipGraph capture failed (%s: %s); the step runs on eager launches\n' % (type(e).__name__, e))
-                torch.cuda.synchronize()
-                del graphs[:]
-                self._graphs, self.launch_mode = None, 'eager (capture failed)'
-                return False
-            finally:
-                if gc_was_on:
-                    gc.enable()
+        except Exception as e:                                                            # pragma: no cover (needs a failing runtime)
+            import sys
+            sys.stderr.write('rvip: hipGraph capture failed (%s: %s); the step runs on eager launches\n' % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            del graphs[:]
+            self._graphs, self.launch_mode = None, 'eager (capture failed)'
+            return False
         torch.cuda.synchronize()
         self._graphs, self.launch_mode = graphs, 'hipGraph' if len(graphs) == 1 else 'hipGraph x%d + RCCL between' % len(graphs)
         return True
