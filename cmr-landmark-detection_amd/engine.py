@@ -692,6 +692,17 @@ class Engine(InputRing):
                 del entries[:]
         # ---- weight- and data-gradient descriptors of every igemm stage (built first: the BN-backward planning below queries them) ----
         fuse_down_on = os.environ.get('RVIP_FUSE_DOWN2', '1') != '0'
+        # The sub-pixel data gradient (subpix = 2) multiplies with phase kernels = sums of 2 / 4 taps rounded ONCE to the activation
+        # type: its result g' differs from the nine-tap gradient g of the rounded taps Wr by a systematic 2^-9 (bf16).  The algebraic BN
+        # backward of the stage in FRONT of such a layer solves  sum g*xhat = (<Wr, dW> - beta * sum g) / gamma  with <Wr, dW> = sum g*y
+        # for the nine-tap g but  sum g  = the column sums of g': an inconsistency of 2^-9 |beta / gamma| |sum g| that does not
+        # average down over pixels and is invisible at initialisation (beta = 0) -- ADVICE r3.  RVIP_BNBWD_SUBPIX_CONSUMER says what
+        # such a stage does: 'exact' -- the classic reduction pass over the (g', z) it really uses; 'ninetap' -- the layer keeps the
+        # nine-tap data gradient with the 2x2 sums in its epilogue (consistent with <Wr, dW>); 'algebraic' -- round 3's behaviour.
+        sp_consumer = os.environ.get('RVIP_BNBWD_SUBPIX_CONSUMER', 'exact')
+        if sp_consumer not in ('exact', 'ninetap', 'algebraic'):
+            raise ValueError('RVIP_BNBWD_SUBPIX_CONSUMER=%r' % sp_consumer)
+        subpix_dgrad_on = os.environ.get('RVIP_SUBPIX_DGRAD', '1') != '0' and not (sp_consumer == 'ninetap' and alg_on)
         wg_desc, dg_desc = {}, {}
         for st in plan.stages:
             if st.src0 == 'input_1':
@@ -717,7 +728,7 @@ class Engine(InputRing):
                 dg.y, dg.y1, dg.csplit = self.grd[st.src0].data_ptr(), self.gskip[st.src1].data_ptr(), st.c0
             elif st.up0 == 1 and fuse_down_on:      # UpSampling2D: the 2x2 block sums leave the data-gradient epilogue directly
                 dg.y, dg.down2 = self.grd[st.src0].data_ptr(), 1
-                if st.conv in P.subpix_d and dt != N.F32 and self.kd == 1 and os.environ.get('RVIP_SUBPIX_DGRAD', '1') != '0':
+                if st.conv in P.subpix_d and dt != N.F32 and self.kd == 1 and subpix_dgrad_on:
                     # ... or, 16-bit types, the gradient arrives on the low-resolution grid at once: the sub-pixel form of the same launch
                     # (four source phases x 2x2 summed taps, 16 instead of 36 multiply-adds per low-resolution pixel)
                     sp = N.Conv3x3Desc.from_buffer_copy(dg)
@@ -754,6 +765,8 @@ class Engine(InputRing):
                 return False
             for c, which in cl:
                 if c.conv not in dg_desc or c.up0 == 2 or (c.up0 == 1 and not fuse_down_on) or (dropping and (c.src1 or c.up0)):
+                    return False
+                if dg_desc[c.conv].subpix == 2 and sp_consumer == 'exact':
                     return False
                 if L.rvip_conv3x3_fwd_sums_rows(C.byref(dg_desc[c.conv])) <= 0:
                     return False
