@@ -65,6 +65,7 @@ def main():
     ap.add_argument('--no-aux', action='store_true', help='skip the informational predict pass (PMC runs: only training-step kernels)')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--detail', default=None, help='write a per-launch timing table (conv / wgrad shapes) to this file')
+    ap.add_argument('--dump-labels', default=None, help='write the launch labels of one step, in launch order, as JSON (tools/step_timeline.py joins them with a kernel trace)')
     ap.add_argument('--no-roofline-pass', action='store_true', help='skip the eager per-launch and family-graph passes (profiling runs: only the captured step in the trace)')
     args = ap.parse_args()
 
@@ -105,6 +106,9 @@ def main():
     eng = model._engine(B)
     eng.load_input(x, y)                       # synthetic batch resident in HBM before the timed region
     torch.cuda.synchronize()
+    if args.dump_labels and rank == 0:
+        labs = ['rvip_convert (stage_input)'] + ['%s %s' % (th[0].__name__, th[2] if len(th) > 2 else '') for seq in (eng.fwd_train, eng.bwd, eng.opt) for th in seq]
+        json.dump(labs, open(args.dump_labels, 'w'))
 
     # The step is the product's: Engine.train_step (what Model.fit / train_on_batch call) runs eagerly once, captures the
     # step into a hipGraph on its second call (around the RCCL collectives when N > 1) and replays it from then on.

@@ -97,7 +97,9 @@ class HeadCoefDesc(C.Structure):
                 ('head_w', vp), ('dlogit', vp), ('k', C.c_int32), ('nrows', C.c_int32),
                 ('mse_rows', vp), ('head_dw', vp), ('head_db', vp),
                 ('sums', vp), ('loss_out', vp), ('inv_count', C.c_float),
-                ('flags', vp), ('min_gamma', C.c_float), ('max_beta_ratio', C.c_float)]
+                ('flags', vp), ('min_gamma', C.c_float), ('max_beta_ratio', C.c_float),
+                ('loss_kind', C.c_int32), ('w_bce', C.c_float), ('w_dice', C.c_float), ('local_over_global', C.c_float), ('dscale', C.c_float),
+                ('pred', vp), ('y_true', vp), ('dcoef', vp)]
 
 
 class FoldEntry(C.Structure):
@@ -158,6 +160,8 @@ SIGNATURES = {
     'rvip_bn_apply_head_mse': (C.c_int, [C.POINTER(ApplyDesc), vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float,
                                          vp, C.c_size_t, vp, C.c_size_t, vp]),
     'rvip_head_mse_coef': (C.c_int, [C.POINTER(HeadCoefDesc), vp]),
+    'rvip_bn_apply_head_bcedice': (C.c_int, [C.POINTER(ApplyDesc), vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]),
+    'rvip_bn_bwd_apply_head_lazy': (C.c_int, [C.POINTER(BnBwdDesc), vp, vp, vp, vp, C.c_int, vp]),
     'rvip_bn_bwd_reduce_head': (C.c_int, [C.POINTER(BnBwdDesc), vp, vp, C.c_int, vp, vp, vp]),
     'rvip_bn_bwd_apply_head': (C.c_int, [C.POINTER(BnBwdDesc), vp, vp, C.c_int, vp]),
     'rvip_head_grad': (C.c_int, [vp, vp, vp, vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp]),

@@ -938,7 +938,18 @@ struct PostHeadBwd {                   // ws columns: [2*kmax][cin]: rows 0..kma
 //             (no gy tensor); dW_h[c][k] = sum_p y[p][c] * dlogit[p][k] and db_h ride along in the reduce stage.
 // Thread = (channel vector cgi, pixel slot prow); the cg = C / VE lanes of a pixel are adjacent (cg a power of two).
 // ------------------------------------------------------------------------------------------------
-struct HeadFuse { const float* w; const float* b; const float* dlogit; int k; };
+// dlogit == NULL: the logit gradient is not materialised (BCE-Dice form of the fused last stage): it is rebuilt per pixel from the
+// stored heat-map and target,  d = ca * (p - t) + (cb * t + cc) * p (1 - p),  with the three global coefficients rvip_head_mse_coef
+// wrote to dcoef (head_lazy_begin loads them)
+struct HeadFuse { const float* w; const float* b; const float* dlogit; int k;
+                  const float* pred = nullptr; const float* yt = nullptr; const float* dcoef = nullptr; float ca = 0.f, cb = 0.f, cc = 0.f; };
+__device__ __forceinline__ HeadFuse head_lazy_begin(HeadFuse hd) {
+    if (!hd.dlogit && hd.dcoef) { hd.ca = hd.dcoef[0]; hd.cb = hd.dcoef[1]; hd.cc = hd.dcoef[2]; }
+    return hd;
+}
+__device__ __forceinline__ float head_lazy_d(const HeadFuse& hd, float p, float t) {
+    return fmaf(hd.ca, p - t, fmaf(hd.cb, t, hd.cc) * (p * (1.f - p)));
+}
 
 // KK = class capacity of the instantiation (2 for the reference's two heat-maps): half the shuffles and logit registers of the
 // MAXK-sized form; the target values of the round are loaded with its z rows, not after the arithmetic that depends on them.
@@ -948,13 +959,15 @@ struct HeadFuse { const float* w; const float* b; const float* dlogit; int k; };
 // `sum g*y - beta * sum g` difference (which loses what the float partial sums cannot hold when the gradient is mostly common-mode);
 // the head's weight gradient adds beta * Q back, where nothing cancels.
 struct HeadMse { float* dlogit; float* rows; const float* beta; float inv_count, dscale; };
-template <typename T, int KK, int SPEC = 0, int MSE = 0>
+// FAST: the default graph's geometry at compile time -- four 16-byte channel vectors per pixel (C = 32 in the 16-bit types) and exactly
+// KK classes: the generic form's run-time loops over lanes and classes were 70 branches and 74 ds_bpermute in a VALU-bound kernel.
+template <typename T, int KK, int SPEC = 0, int MSE = 0, int FAST = 0>
 __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFuse hd, float* __restrict__ pred, const float* __restrict__ yt,
                                                             long long rows, long long chunk, int reduce, float* __restrict__ ws, HeadMse mse) {
     constexpr int VE = Vec<T>::VE, U = 2;
     __shared__ float red[4][16];
-    const int tid = threadIdx.x, k = hd.k;
-    const int cg = a.c / VE, rpi = 256 / cg, cgi = tid % cg, prow = tid / cg;
+    const int tid = threadIdx.x, k = FAST ? KK : hd.k;
+    const int cg = FAST ? 4 : a.c / VE, rpi = 256 / cg, cgi = tid % cg, prow = tid / cg;
     const long long r0 = blockIdx.x * chunk, r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
     float sc[VE], sh[VE], wr[VE][KK], bias[KK];
 #pragma unroll
@@ -968,14 +981,20 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
     float s[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) s[i] = 0.f;
-    static_assert(!MSE || KK <= VE, "the Q row holds one column per class");
-    float hp[MSE ? KK + 1 : 1][VE], bt[MSE ? VE : 1];
+    // MSE == 1: the logit gradient is written here and ONE row set S, Q is kept (see HeadMse).  MSE == 2 (BCE-Dice): the gradient is
+    // d = ca (p - t) + cb t p(1-p) + cc p(1-p) with coefficients that need the batch's Dice sums first, so THREE row sets are kept, one
+    // per pixel term  t0 = p - t,  t1 = t p (1 - p),  t2 = p (1 - p):  rows j * KK + kk = S_{j,kk}[c], row 3 KK = Q_{j,kk} in column
+    // j * KK + kk; nothing is written per pixel beyond the heat-map (rvip_head_mse_coef combines the sets, rvip_bn_bwd_apply_head_lazy
+    // rebuilds d from the heat-map and the target).
+    constexpr int NT = MSE == 2 ? 3 : 1, NR = MSE ? NT * KK + 1 : 1;
+    static_assert(!MSE || NT * KK <= VE, "the Q row holds one column per (term, class)");
+    float hp[NR][VE], bt[MSE ? VE : 1];
     if constexpr (MSE) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) bt[e] = mse.beta ? mse.beta[cgi * VE + e] : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < (MSE ? KK + 1 : 1); ++q)
+    for (int q = 0; q < NR; ++q)
 #pragma unroll
         for (int e = 0; e < VE; ++e) hp[q][e] = 0.f;
     for (long long rb = r0 + prow; rb < r1; rb += (long long)U * rpi) {
@@ -993,7 +1012,7 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long r = rb + (long long)u * rpi;
-            float lg[KK], dl[MSE ? KK : 1];
+            float lg[KK], dl[MSE ? NT * KK : 1];
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) lg[kk] = 0.f;
 #pragma unroll
@@ -1001,10 +1020,11 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
                 const float y = Vec<T>::round(act_fwd(fmaf(v[u][e], sc[e], sh[e]), SPEC ? RVIP_ACT_NONE : a.act));   // what rvip_bn_apply would have stored
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) lg[kk] = fmaf(y, wr[e][kk], lg[kk]);
+                if constexpr (MSE) v[u][e] = y;              // y takes z's register: the rows below read it again (the kernel is VALU-bound)
             }
             if constexpr (MSE) {
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk) dl[kk] = 0.f;
+                for (int kk = 0; kk < NT * KK; ++kk) dl[kk] = 0.f;
             }
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
@@ -1028,12 +1048,21 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
                 if (yt) {
                     const float t = kk == cgi ? tv[u] : yt[(size_t)r * k + kk];
                     const float d = pv - t;
-                    if constexpr (MSE) {
+                    if constexpr (MSE == 1) {
                         float dd = 2.f * (pv - t) * mse.inv_count * pv * (1.f - pv);          // rvip_head_grad's expression, then rvip_scale_f32's
                         if (mse.dscale != 1.f) dd *= mse.dscale;
                         mse.dlogit[(size_t)r * k + kk] = dd;
 #pragma unroll
                         for (int q = 0; q < KK; ++q) dl[q] = (kk == q) ? dd : dl[q];
+                    }
+                    if constexpr (MSE == 2) {
+                        const float pq = pv * (1.f - pv);
+#pragma unroll
+                        for (int q = 0; q < KK; ++q) {
+                            dl[q] = (kk == q) ? d : dl[q];
+                            dl[KK + q] = (kk == q) ? t * pq : dl[KK + q];
+                            dl[2 * KK + q] = (kk == q) ? pq : dl[2 * KK + q];
+                        }
                     }
                     s[0] = fmaf(d, d, s[0]);
                     if (kk >= k - 3) {
@@ -1047,27 +1076,27 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
             if constexpr (MSE) {
                 // every class was finished by exactly one lane of the pixel: a sum over its cg lanes hands d[.] to all of them
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk) {
+                for (int kk = 0; kk < NT * KK; ++kk) {
                     if (cg == 4) {
                         dl[kk] += lane_xor2_dpp(dl[kk]);
                         dl[kk] += lane_xor1_dpp(dl[kk]);
                     } else {
                         for (int o = cg >> 1; o > 0; o >>= 1) dl[kk] += __shfl_xor(dl[kk], o);
                     }
-                    if (cgi == 0) hp[KK][kk] += dl[kk];
+                    if (cgi == 0) hp[NT * KK][kk] += dl[kk];
                 }
 #pragma unroll
-                for (int e = 0; e < VE; ++e) {                          // y again from z (its registers are still live; keeping y cost eight more)
-                    const float yb = Vec<T>::round(act_fwd(fmaf(v[u][e], sc[e], sh[e]), SPEC ? RVIP_ACT_NONE : a.act)) - bt[e];
+                for (int e = 0; e < VE; ++e) {
+                    const float yb = v[u][e] - bt[e];
 #pragma unroll
-                    for (int kk = 0; kk < KK; ++kk) hp[kk][e] = fmaf(yb, dl[kk], hp[kk][e]);
+                    for (int kk = 0; kk < NT * KK; ++kk) hp[kk][e] = fmaf(yb, dl[kk], hp[kk][e]);
                 }
             }
         }
     }
     if constexpr (MSE) {
         __shared__ float fold_lds[256 * VE];
-        block_fold<KK + 1, VE>(hp, true, tid, a.c, rpi, fold_lds, mse.rows + (size_t)blockIdx.x * (KK + 1) * a.c);
+        block_fold<NR, VE>(hp, true, tid, a.c, rpi, fold_lds, mse.rows + (size_t)blockIdx.x * NR * a.c);
     }
     if (!reduce) return;
 #pragma unroll
@@ -1084,8 +1113,13 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(ApplyArgs a, HeadFus
 // incoming gradient of pixel r for this thread's channels, from the head's logit gradient
 template <typename T, int VE, int KK = RVIP_MAXK>
 __device__ __forceinline__ void head_grad_vec(const HeadFuse& hd, long long r, const float (&wr)[VE][KK], float (&d)[KK], float (&g)[VE]) {
+    if (hd.dlogit) {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) d[kk] = kk < hd.k ? hd.dlogit[(size_t)r * hd.k + kk] : 0.f;
+        for (int kk = 0; kk < KK; ++kk) d[kk] = kk < hd.k ? hd.dlogit[(size_t)r * hd.k + kk] : 0.f;
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) d[kk] = kk < hd.k ? head_lazy_d(hd, hd.pred[(size_t)r * hd.k + kk], hd.yt[(size_t)r * hd.k + kk]) : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
         float acc = 0.f;
@@ -1162,8 +1196,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_head_kernel(BnBwdArgs a, He
 }
 
 template <typename T, int KK, int SPEC = 0>
-__global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(BnBwdArgs a, HeadFuse hd, RedGeom gm, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(BnBwdArgs a, HeadFuse hd0, RedGeom gm, float* __restrict__ ws) {
     constexpr int VE = Vec<T>::VE;
+    const HeadFuse hd = head_lazy_begin(hd0);
     __shared__ float lds[256 * VE];
     const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
     const bool active = prow < gm.rpi;
@@ -1672,48 +1707,68 @@ struct HeadCoefArgs {
     const float* gamma; const float* beta; const float* mean; const float* invstd;
     float* dgamma; float* dbeta; float* coef; int* flags;
     double n; int c; float min_gamma, max_beta_ratio;
+    // MODE 2 (BCE-Dice): rows are [nrows][3 KK + 1][C] (three term sets, see bn_apply_head_kernel); the coefficients come from the folded sums
+    float w_bce, w_dice, lg, dscale; const float* pred; const float* yt; float* dcoef;
 };
-template <typename T>
+// the three global coefficients of the BCE-Dice logit gradient  d = ca (p - t) + (cb t + cc) p (1 - p)  (rvip_head_grad's expression
+// times dscale):  ca = w_bce / count,  cb = -w_dice lg 2 / den,  cc = w_dice lg (2 I + 1) / den^2,  den = sum t + sum p + 1
+__device__ __forceinline__ void bcedice_coefs(const HeadCoefArgs& a, float& ca, float& cb, float& cc) {
+    const float inter = a.sums[2], den = a.sums[3] + a.sums[4] + 1.f;
+    ca = a.w_bce * a.inv_count * a.dscale;
+    cb = -a.w_dice * a.lg * (2.f / den) * a.dscale;
+    cc = a.w_dice * a.lg * ((2.f * inter + 1.f) / (den * den)) * a.dscale;
+}
+template <typename T, int MODE = 1>
 __global__ __launch_bounds__(1024) void head_mse_coef_kernel(HeadCoefArgs a) {
-    constexpr int VE = Vec<T>::VE, NV = 32 / VE, NS = 1024 / NV, KK = 2;
+    constexpr int VE = Vec<T>::VE, NV = 32 / VE, NS = 1024 / NV, KK = 2, NT = MODE == 2 ? 3 : 1, NC = NT * KK;
     __shared__ double sh[KK + 1][32][32];
     __shared__ float part_lds[NS][32];
     __shared__ int bad[32];
     __shared__ int sbad;
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int ch = blockIdx.x * 32 + c;
-    const size_t rs = (size_t)(KK + 1) * a.c;
-    double s[KK + 1];
+    const size_t rs = (size_t)(NC + 1) * a.c;
+    float ca = 1.f, cb = 0.f, cc = 0.f;
+    if constexpr (MODE == 2) bcedice_coefs(a, ca, cb, cc);
+    double s[NC + 1];
 #pragma unroll
-    for (int q = 0; q <= KK; ++q) s[q] = 0.0;
+    for (int q = 0; q <= NC; ++q) s[q] = 0.0;
     {
-        // one latency chain on one CU: 16 rows (S of both classes, and Q for the threads that fold it) are requested together
-        const bool mine = ch < a.c, qmine = c < KK;           // every workgroup folds the Q row itself (T1 of each channel needs all of it)
+        // one latency chain on one CU: D rows (S of every (term, class), and Q for the threads that fold it) are requested together
+        const bool mine = ch < a.c, qmine = c < NC;           // every workgroup folds the Q row itself (T1 of each channel needs all of it)
         const __amdgpu_buffer_rsrc_t rr = rows_rsrc(a.rows, (size_t)a.nrows * rs * 4);
         constexpr unsigned NONE = 0x80000000u;
-        const unsigned vs = mine ? (unsigned)((size_t)g * rs + ch) * 4u : NONE, vq = qmine ? (unsigned)((size_t)g * rs + (size_t)KK * a.c + c) * 4u : NONE;
-        constexpr int D = 16;
+        const unsigned vs = mine ? (unsigned)((size_t)g * rs + ch) * 4u : NONE, vq = qmine ? (unsigned)((size_t)g * rs + (size_t)NC * a.c + c) * 4u : NONE;
+        constexpr int D = MODE == 2 ? 8 : 16;
         for (int b = 0; b < a.nrows; b += 32 * D) {
-            float v[D][KK], qv[D];
+            float v[D][NC], qv[D];
 #pragma unroll
             for (int u = 0; u < D; ++u) {
                 // (a scalar offset past the end would make the range check's `records - soffset` wrap: such rows get offset 0 + NONE)
                 const bool any = b + 32 * u < a.nrows;                             // wave-uniform
                 const unsigned so = any ? (unsigned)((size_t)(b + 32 * u) * rs) * 4u : 0u;
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk) v[u][kk] = buf_f32(rr, any ? vs : NONE, any ? so + (unsigned)(kk * a.c) * 4u : 0u);
+                for (int kk = 0; kk < NC; ++kk) v[u][kk] = buf_f32(rr, any ? vs : NONE, any ? so + (unsigned)(kk * a.c) * 4u : 0u);
                 qv[u] = buf_f32(rr, any ? vq : NONE, so);
             }
 #pragma unroll
             for (int u = 0; u < D; u += 4) {
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk) s[kk] += ((double)v[u][kk] + (double)v[u + 1][kk]) + ((double)v[u + 2][kk] + (double)v[u + 3][kk]);
-                s[KK] += ((double)qv[u] + (double)qv[u + 1]) + ((double)qv[u + 2] + (double)qv[u + 3]);
+                for (int kk = 0; kk < NC; ++kk) s[kk] += ((double)v[u][kk] + (double)v[u + 1][kk]) + ((double)v[u + 2][kk] + (double)v[u + 3][kk]);
+                s[NC] += ((double)qv[u] + (double)qv[u + 1]) + ((double)qv[u + 2] + (double)qv[u + 3]);
             }
         }
     }
+    if constexpr (MODE == 2) {
+        // the gradient is linear in the three terms: combine this thread's partial sums with the global coefficients, then fold as before
+        // (column c of the Q row belongs to term c / KK)
 #pragma unroll
-    for (int q = 0; q <= KK; ++q) sh[q][g][c] = s[q];
+        for (int kk = 0; kk < KK; ++kk) s[kk] = (double)ca * s[kk] + (double)cb * s[KK + kk] + (double)cc * s[2 * KK + kk];
+        s[NC] *= (double)(c < KK ? ca : (c < 2 * KK ? cb : cc));
+    }
+#pragma unroll
+    for (int q = 0; q < KK; ++q) sh[q][g][c] = s[q];
+    sh[KK][g][c] = s[NC];
     __syncthreads();
     double t1 = 0.0, t2 = 0.0;
     float gm = 1.f, bt = 0.f;
@@ -1723,7 +1778,11 @@ __global__ __launch_bounds__(1024) void head_mse_coef_kernel(HeadCoefArgs a) {
         for (int kk = 0; kk < KK; ++kk) {
             S[kk] = Q[kk] = 0.0;
 #pragma unroll
-            for (int gg = 0; gg < 32; ++gg) { S[kk] += sh[kk][gg][c]; Q[kk] += sh[KK][gg][kk]; }
+            for (int gg = 0; gg < 32; ++gg) {
+                S[kk] += sh[kk][gg][c];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) Q[kk] += sh[KK][gg][j * KK + kk];
+            }
         }
         int isbad = 0;
         if (ch < a.c) {
@@ -1742,7 +1801,13 @@ __global__ __launch_bounds__(1024) void head_mse_coef_kernel(HeadCoefArgs a) {
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk)
                 if (kk < a.k) a.head_db[kk] = (float)Q[kk];
-            if (a.loss_out) a.loss_out[0] = a.sums[0] * a.inv_count;
+            if constexpr (MODE == 2) {
+                a.dcoef[0] = ca; a.dcoef[1] = cb; a.dcoef[2] = cc;          // what rvip_bn_bwd_apply_head_lazy rebuilds the gradient with
+                if (a.loss_out) {
+                    const float den = a.sums[3] + a.sums[4] + 1.f;
+                    a.loss_out[0] = a.w_bce * a.sums[1] * a.inv_count - a.w_dice * a.lg * (2.f * a.sums[2] + 1.f) / den;      // rvip_head_grad's value
+                }
+            } else if (a.loss_out) a.loss_out[0] = a.sums[0] * a.inv_count;
         }
         bad[c] = isbad;
     }
@@ -1761,7 +1826,8 @@ __global__ __launch_bounds__(1024) void head_mse_coef_kernel(HeadCoefArgs a) {
     // ---------------- exact route for this block: sum g and sum g*xhat over every pixel, as rvip_bn_bwd_reduce_head computes them ----------------
     const int cv = threadIdx.x % NV, slot = threadIdx.x / NV, cgi = blockIdx.x * NV + cv, cg = a.c / VE;
     const bool active = cgi < cg;
-    const HeadFuse hd{a.w, nullptr, a.dlogit, a.k};
+    HeadFuse hd{a.w, nullptr, a.dlogit, a.k};
+    if constexpr (MODE == 2) { hd.dlogit = nullptr; hd.pred = a.pred; hd.yt = a.yt; hd.ca = ca; hd.cb = cb; hd.cc = cc; }
     float part[2][VE], mu[VE], is[VE], wr[VE][KK];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
@@ -1979,7 +2045,8 @@ extern "C" int rvip_bn_apply_head(const rvip_apply_desc* d, const float* head_w,
     HeadFuse hd{head_w, head_b, nullptr, k};
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
-        if (k <= 2 && a.act == RVIP_ACT_NONE) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws, HeadMse{});
+        if (k == 2 && a.act == RVIP_ACT_NONE && a.c / Vec<T>::VE == 4) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws, HeadMse{});
+        else if (k <= 2 && a.act == RVIP_ACT_NONE) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws, HeadMse{});
         else if (k <= 2) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws, HeadMse{});
         else hipLaunchKernelGGL((bn_apply_head_kernel<T, RVIP_MAXK>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, y_true ? 1 : 0, ws, HeadMse{});
         return 0;
@@ -2029,9 +2096,9 @@ extern "C" int rvip_bn_bwd_reduce_head(const rvip_bnbwd_desc* d, const float* he
     return launch_fold_k<PostHeadBwd>(ws_hd, g.nblk, d->c, 2 * kcap, ph, s);
 }
 
-extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* head_w, const float* dlogit, int k, void* stream) {
-    (void)hipGetLastError();
-    if (!d || !d->z || !d->dz || !head_w || !dlogit || !RVIP_DT_OK(d->dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
+static int bn_bwd_apply_head_impl(const rvip_bnbwd_desc* d, HeadFuse hd, void* stream) {
+    const int k = hd.k;
+    if (!d || !d->z || !d->dz || !hd.w || !RVIP_DT_OK(d->dtype) || k <= 0 || k > RVIP_MAXK) return RVIP_EINVAL;
     if ((!d->dbias && !d->bias_rows) || (d->gamma && !d->coef) || d->drop_rate > 0.f) return RVIP_EINVAL;
     RedGeom g;
     if (!red_geom(d->rows, d->c, RVIP_VE(d->dtype), g, RVIP_APPLY_HEAD_CAP(k))) return RVIP_EINVAL;
@@ -2046,7 +2113,6 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     a.rows = d->rows; a.c = d->c;
     hipStream_t s = (hipStream_t)stream;
     float* ws = defer ? d->bias_rows : (float*)d->workspace;
-    HeadFuse hd{head_w, nullptr, dlogit, k};
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
         if (k <= 2 && a.act == RVIP_ACT_RELU && !a.act_after_bn) hipLaunchKernelGGL((bn_bwd_apply_head_kernel<T, 2, 1>), dim3(g.nblk), dim3(256), 0, s, a, hd, g, ws);
@@ -2058,6 +2124,24 @@ extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* hea
     if (rc || defer) return rc;
     PostSum p{d->dbias};
     return launch_fold<1, PostSum>(ws, g.nblk, d->c, p, s);
+}
+
+extern "C" int rvip_bn_bwd_apply_head(const rvip_bnbwd_desc* d, const float* head_w, const float* dlogit, int k, void* stream) {
+    (void)hipGetLastError();
+    if (!dlogit) return RVIP_EINVAL;
+    return bn_bwd_apply_head_impl(d, HeadFuse{head_w, nullptr, dlogit, k}, stream);
+}
+
+// the same pass with the logit gradient rebuilt from the heat-map, the target and the three coefficients rvip_head_mse_coef (BCE-Dice
+// form) left in dcoef: no dlogit tensor exists in that form of the step
+extern "C" int rvip_bn_bwd_apply_head_lazy(const rvip_bnbwd_desc* d, const float* head_w, const float* pred, const float* y_true,
+                                           const float* dcoef, int k, void* stream) {
+    (void)hipGetLastError();
+    if (!pred || !y_true || !dcoef) return RVIP_EINVAL;
+    if (k > 2) return RVIP_EUNSUPPORTED;
+    HeadFuse hd{head_w, nullptr, nullptr, k};
+    hd.pred = pred; hd.yt = y_true; hd.dcoef = dcoef;
+    return bn_bwd_apply_head_impl(d, hd, stream);
 }
 
 // The MSE form of the fused last stage (include/rvip_hip.h, ABI 6): same grid as rvip_bn_apply_head.
@@ -2100,7 +2184,47 @@ extern "C" int rvip_bn_apply_head_mse(const rvip_apply_desc* d, const float* hea
     HeadMse mse{dlogit, mse_rows, beta, inv_count, dscale};
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
-        hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, 1, ws, mse);
+        if (cg == 4 && k == 2) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1, 1, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, 1, ws, mse);
+        else hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, 1, ws, mse);
+        return 0;
+    });
+    int rc = check_launch();
+    if (rc) return rc;
+    PostHeadSums p{sums};
+    return launch_fold<1, PostHeadSums>(ws, (int)nb, 16, p, s);
+}
+
+// BCE-Dice form of the fused last stage (Loss_and_metrics.py:229-245, the Train notebook's loss): three row sets, nothing per pixel
+// beyond the heat-map; rows [rvip_bn_apply_head_mse_rows()][3 k_cap + 1][C]
+extern "C" int rvip_bn_apply_head_bcedice(const rvip_apply_desc* d, const float* head_w, const float* head_b, const float* beta, int k, float* pred,
+                                          const float* y_true, float* sums, float* rows_out, size_t rows_bytes,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!d || !d->z || !head_w || !pred || !y_true || !sums || !workspace || !rows_out || !RVIP_DT_OK(d->dtype) || k <= 0) return RVIP_EINVAL;
+    const int ve = RVIP_VE(d->dtype);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->c % ve || d->drop_rate > 0.f) return RVIP_EINVAL;
+    const int cg = d->c / ve;
+    if (k > 2 || d->act != RVIP_ACT_NONE || cg > 64 || (cg & (cg - 1))) return RVIP_EUNSUPPORTED;
+    if (d->dtype == RVIP_F32) return RVIP_EUNSUPPORTED;       // the Q row carries six columns per lane: 8-element channel vectors only
+    ApplyArgs a;
+    a.z = (const unsigned char*)d->z; a.y = nullptr; a.pooled = nullptr; a.argmax = nullptr;
+    a.scale = d->scale; a.shift = d->shift; a.act = d->act;
+    a.inv_keep = 1.f; a.thr = 0; a.mask = nullptr; a.state = nullptr; a.layer_id = 0; a.drop = 0;
+    a.n = d->n; a.h = d->h; a.w = d->w; a.c = d->c;
+    const long long rows = (long long)d->n * d->h * d->w;
+    long long chunk;
+    const long long nb = head_fwd_blocks(rows, &chunk);
+    if (workspace_bytes < (size_t)nb * 16 * sizeof(float) || rows_bytes < (size_t)nb * 7 * d->c * sizeof(float)) return RVIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    HeadFuse hd{head_w, head_b, nullptr, k};
+    HeadMse mse{nullptr, rows_out, beta, 0.f, 1.f};
+    by_dtype(d->dtype, [&](auto t) {
+        using T = decltype(t);
+        if constexpr (sizeof(T) == 2) {
+            if (cg == 4 && k == 2) hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1, 2, 1>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, 1, ws, mse);
+            else hipLaunchKernelGGL((bn_apply_head_kernel<T, 2, 1, 2>), dim3((unsigned)nb), dim3(256), 0, s, a, hd, pred, y_true, rows, chunk, 1, ws, mse);
+        }
         return 0;
     });
     int rc = check_launch();
@@ -2111,7 +2235,10 @@ extern "C" int rvip_bn_apply_head_mse(const rvip_apply_desc* d, const float* hea
 
 extern "C" int rvip_head_mse_coef(const rvip_headcoef_desc* d, void* stream) {
     (void)hipGetLastError();
-    if (!d || !d->bn || !d->head_w || !d->dlogit || !d->mse_rows || !d->head_dw || !d->head_db || !d->flags || d->nrows <= 0) return RVIP_EINVAL;
+    if (!d || !d->bn || !d->head_w || !d->mse_rows || !d->head_dw || !d->head_db || !d->flags || d->nrows <= 0) return RVIP_EINVAL;
+    const bool bcedice = d->loss_kind == RVIP_LOSS_BCE_DICE;
+    if (d->loss_kind != RVIP_LOSS_MSE && !bcedice) return RVIP_EINVAL;
+    if (bcedice ? (!d->pred || !d->y_true || !d->dcoef || !d->sums || !(d->dscale > 0.f)) : !d->dlogit) return RVIP_EINVAL;
     const rvip_bnbwd_desc* b = d->bn;
     if (!b->z || !RVIP_DT_OK(b->dtype) || b->c <= 0 || b->c % RVIP_VE(b->dtype) || b->rows <= 0) return RVIP_EINVAL;
     if (!b->gamma || !b->mean || !b->invstd || !b->dgamma || !b->dbeta || !b->coef || b->drop_rate > 0.f) return RVIP_EINVAL;
@@ -2124,8 +2251,12 @@ extern "C" int rvip_head_mse_coef(const rvip_headcoef_desc* d, void* stream) {
     a.gamma = b->gamma; a.beta = d->beta; a.mean = b->mean; a.invstd = b->invstd;
     a.dgamma = b->dgamma; a.dbeta = b->dbeta; a.coef = b->coef; a.flags = d->flags;
     a.n = (double)b->rows; a.c = b->c; a.min_gamma = d->min_gamma; a.max_beta_ratio = d->max_beta_ratio;
+    a.w_bce = d->w_bce; a.w_dice = d->w_dice; a.lg = d->local_over_global; a.dscale = d->dscale;
+    a.pred = d->pred; a.yt = d->y_true; a.dcoef = d->dcoef;
     by_dtype(b->dtype, [&](auto t) {
-        hipLaunchKernelGGL(head_mse_coef_kernel<decltype(t)>, dim3((unsigned)cdiv(b->c, 32)), dim3(1024), 0, (hipStream_t)stream, a);
+        using T = decltype(t);
+        if (bcedice) hipLaunchKernelGGL((head_mse_coef_kernel<T, 2>), dim3((unsigned)cdiv(b->c, 32)), dim3(1024), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((head_mse_coef_kernel<T, 1>), dim3((unsigned)cdiv(b->c, 32)), dim3(1024), 0, (hipStream_t)stream, a);
         return 0;
     });
     return check_launch();

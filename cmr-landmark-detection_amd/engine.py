@@ -487,9 +487,14 @@ class Engine(InputRing):
         last_apply = None
         # MSE head: the logit gradient and the sums of the head's / the stage's BN backward leave the forward pass
         # (rvip_bn_apply_head_mse + rvip_head_mse_coef replace rvip_head_grad, rvip_bn_bwd_reduce_head and their finalisers)
-        self.head_alg = bool(self.fuse_head and self.loss_kind == N.LOSS_MSE and plan.head['k'] <= 2 and not last.act_post
+        # BCE-Dice (round 4): the same with three row sets and a logit gradient rebuilt per pixel in the backward apply pass
+        # (rvip_bn_apply_head_bcedice + rvip_head_mse_coef(loss_kind BCE_DICE) + rvip_bn_bwd_apply_head_lazy); 4-class heads keep the classic launches
+        self.head_alg = bool(self.fuse_head and plan.head['k'] <= 2 and not last.act_post
                              and N.ACT[last.act_conv] == N.ACT['relu'] and os.environ.get('RVIP_BNBWD_ALGEBRAIC', '1') != '0'
                              and os.environ.get('RVIP_HEAD_ALGEBRAIC', '1') != '0')
+        if self.loss_kind == N.LOSS_BCE_DICE and dt == N.F32:
+            self.head_alg = False                   # (rvip_bn_apply_head_bcedice: 16-bit types; the fp32 parity path keeps the classic launches)
+        self.head_bcedice = self.head_alg and self.loss_kind == N.LOSS_BCE_DICE
         # who reads what: tensor name -> producing stage, stage -> [(consumer stage, 0 = as src0 / 1 = as the skip half)]
         producer = {}
         for st in plan.stages:
@@ -647,7 +652,13 @@ class Engine(InputRing):
         else:
             self.loss_scale = 1.0
         P.grad_unscale = 1.0 / self.loss_scale
-        if self.head_alg:
+        if self.head_bcedice:
+            nr = L.rvip_bn_apply_head_mse_rows(hrows, last.cout, dt, hd['k'])
+            self.head_rows = torch.empty(nr * 7 * last.cout, dtype=torch.float32, device=self.ws.device)
+            self.head_dcoef = torch.zeros(4, dtype=torch.float32, device=self.ws.device)
+            fwd_t.append((L.rvip_bn_apply_head_bcedice, (C.byref(last_apply), hw_, hb_, P.p(last.bn, 'beta'), hd['k'], _ptr(self.pred), _ptr(self.y_true),
+                                                         _ptr(self.sums), _ptr(self.head_rows), C.c_size_t(self.head_rows.numel() * 4), ws, wsb)))
+        elif self.head_alg:
             nr = L.rvip_bn_apply_head_mse_rows(hrows, last.cout, dt, hd['k'])
             self.head_rows = torch.empty(nr * 3 * last.cout, dtype=torch.float32, device=self.ws.device)
             fwd_t.append((L.rvip_bn_apply_head_mse, (C.byref(last_apply), hw_, hb_, P.p(last.bn, 'beta'), hd['k'], _ptr(self.pred), _ptr(self.y_true),
@@ -699,10 +710,18 @@ class Engine(InputRing):
         # average down over pixels and is invisible at initialisation (beta = 0) -- ADVICE r3.  RVIP_BNBWD_SUBPIX_CONSUMER says what
         # such a stage does: 'exact' -- the classic reduction pass over the (g', z) it really uses; 'ninetap' -- the layer keeps the
         # nine-tap data gradient with the 2x2 sums in its epilogue (consistent with <Wr, dW>); 'algebraic' -- round 3's behaviour.
-        sp_consumer = os.environ.get('RVIP_BNBWD_SUBPIX_CONSUMER', 'exact')
-        if sp_consumer not in ('exact', 'ninetap', 'algebraic'):
+        # 'auto' (default) picks per layer whichever of the two consistent forms is cheaper (measured, round 4: the nine-tap data gradient
+        # costs +7 .. +20 us per layer, the reduction pass of the stage in front +8 .. +25 us, in opposite order of map size): 'ninetap'
+        # for the HBM-bound full-resolution layer (c0 * cout <= 64 * 32), 'exact' for the others.
+        sp_consumer = os.environ.get('RVIP_BNBWD_SUBPIX_CONSUMER', 'auto')
+        if sp_consumer not in ('auto', 'exact', 'ninetap', 'algebraic'):
             raise ValueError('RVIP_BNBWD_SUBPIX_CONSUMER=%r' % sp_consumer)
-        subpix_dgrad_on = os.environ.get('RVIP_SUBPIX_DGRAD', '1') != '0' and not (sp_consumer == 'ninetap' and alg_on)
+
+        def sp_mode(st):
+            if sp_consumer != 'auto':
+                return sp_consumer
+            return 'ninetap' if st.c0 * st.cout <= 64 * 32 else 'exact'
+        self.sp_modes = {}
         wg_desc, dg_desc = {}, {}
         for st in plan.stages:
             if st.src0 == 'input_1':
@@ -728,7 +747,8 @@ class Engine(InputRing):
                 dg.y, dg.y1, dg.csplit = self.grd[st.src0].data_ptr(), self.gskip[st.src1].data_ptr(), st.c0
             elif st.up0 == 1 and fuse_down_on:      # UpSampling2D: the 2x2 block sums leave the data-gradient epilogue directly
                 dg.y, dg.down2 = self.grd[st.src0].data_ptr(), 1
-                if st.conv in P.subpix_d and dt != N.F32 and self.kd == 1 and subpix_dgrad_on:
+                if (st.conv in P.subpix_d and dt != N.F32 and self.kd == 1 and os.environ.get('RVIP_SUBPIX_DGRAD', '1') != '0'
+                        and not (alg_on and sp_mode(st) == 'ninetap')):
                     # ... or, 16-bit types, the gradient arrives on the low-resolution grid at once: the sub-pixel form of the same launch
                     # (four source phases x 2x2 summed taps, 16 instead of 36 multiply-adds per low-resolution pixel)
                     sp = N.Conv3x3Desc.from_buffer_copy(dg)
@@ -766,8 +786,10 @@ class Engine(InputRing):
             for c, which in cl:
                 if c.conv not in dg_desc or c.up0 == 2 or (c.up0 == 1 and not fuse_down_on) or (dropping and (c.src1 or c.up0)):
                     return False
-                if dg_desc[c.conv].subpix == 2 and sp_consumer == 'exact':
-                    return False
+                if dg_desc[c.conv].subpix == 2:
+                    self.sp_modes[c.conv] = sp_mode(c)
+                    if sp_mode(c) == 'exact':
+                        return False
                 if L.rvip_conv3x3_fwd_sums_rows(C.byref(dg_desc[c.conv])) <= 0:
                     return False
                 if dropping and (c.cin % 8 or gated_probe(c, c.cin) <= 0):      # Dropout backward: the keep bits gate the consumer's data gradient
@@ -871,7 +893,11 @@ class Engine(InputRing):
                     hc = N.HeadCoefDesc()
                     hc.bn, hc.beta = C.pointer(b), P.p(st.bn, 'beta').value
                     hc.head_w, hc.dlogit, hc.k = hw_.value, self.dlogit.data_ptr(), hd['k']
-                    hc.mse_rows, hc.nrows = self.head_rows.data_ptr(), self.head_rows.numel() // (3 * st.cout)
+                    hc.mse_rows, hc.nrows = self.head_rows.data_ptr(), self.head_rows.numel() // ((7 if self.head_bcedice else 3) * st.cout)
+                    if self.head_bcedice:
+                        hc.loss_kind, hc.w_bce, hc.w_dice, hc.local_over_global = N.LOSS_BCE_DICE, self.w_bce, self.w_dice, 1.0 / self.world
+                        hc.dscale = self.loss_scale * self.grad_factor
+                        hc.pred, hc.y_true, hc.dcoef = self.pred.data_ptr(), self.y_true.data_ptr(), self.head_dcoef.data_ptr()
                     hc.head_dw, hc.head_db = P.g(hd['conv'], 'kernel').value, P.g(hd['conv'], 'bias').value
                     hc.sums, hc.loss_out, hc.inv_count = self.sums.data_ptr(), self.loss.data_ptr(), self._inv_count
                     flags = torch.zeros(-(-st.cout // 32), dtype=torch.int32, device=self.ws.device)
@@ -883,7 +909,10 @@ class Engine(InputRing):
                 else:
                     bwd.append((L.rvip_bn_bwd_reduce_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'], P.g(hd['conv'], 'kernel'),
                                                             P.g(hd['conv'], 'bias'))))
-                bwd.append((L.rvip_bn_bwd_apply_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'])))
+                if self.head_bcedice:
+                    bwd.append((L.rvip_bn_bwd_apply_head_lazy, (C.byref(b), hw_, _ptr(self.pred), _ptr(self.y_true), _ptr(self.head_dcoef), hd['k'])))
+                else:
+                    bwd.append((L.rvip_bn_bwd_apply_head, (C.byref(b), hw_, _ptr(self.dlogit), hd['k'])))
             elif st.conv in self.upact:              # dz was written, ReLU backward applied, by the reader's data gradient; bias gradient = its column sums
                 c = self.upact[st.conv]
                 sbuf_, nr = sums_rows[c.conv]

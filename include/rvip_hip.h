@@ -440,8 +440,30 @@ typedef struct rvip_headcoef_desc {
     const float* sums; float* loss_out; float inv_count;     /* loss_out[0] = sums[0] * inv_count (NULL: not written) */
     int32_t*     flags;                   /* [ceil(c / 32)] */
     float        min_gamma, max_beta_ratio;
+    /* ABI 7 -- loss_kind RVIP_LOSS_BCE_DICE: the rows are rvip_bn_apply_head_bcedice's [nrows][7][C]; the logit gradient is
+     *   d = ca (p - t) + (cb t + cc) p (1 - p),   ca = w_bce inv_count dscale,  cb = -w_dice local_over_global (2 / den) dscale,
+     *   cc = w_dice local_over_global ((2 I + 1) / den^2) dscale,   I = sums[2], den = sums[3] + sums[4] + 1
+     * (rvip_head_grad's expression times dscale); the three coefficients are written to dcoef for rvip_bn_bwd_apply_head_lazy,
+     * loss_out[0] = w_bce sums[1] inv_count - w_dice local_over_global (2 I + 1) / den; dlogit is not read (none exists: the exact
+     * route rebuilds the gradient from pred / y_true).  loss_kind RVIP_LOSS_MSE (0): the fields below are ignored. */
+    int32_t      loss_kind;
+    float        w_bce, w_dice, local_over_global, dscale;
+    const float* pred; const float* y_true;
+    float*       dcoef;                   /* [3] */
 } rvip_headcoef_desc;
 int rvip_head_mse_coef(const rvip_headcoef_desc* d, void* stream);
+/* ABI 7 -- the BCE-Dice form of the fused last stage (Loss_and_metrics.py:229-245 `bce_dice_loss`, the Train notebook's loss; also
+ * the class form): the logit gradient's coefficients need the batch's Dice sums, so the forward pass keeps THREE row sets, one per
+ * pixel term t0 = p - t, t1 = t p (1 - p), t2 = p (1 - p):  rows_out [rvip_bn_apply_head_mse_rows()][3 k_cap + 1][C], row
+ * j k_cap + kk = sum_p (y[p][c] - beta[c]) t_j[p][kk], row 3 k_cap column j k_cap + kk = sum_p t_j[p][kk]  (k_cap = 2).  Nothing is written
+ * per pixel beyond the heat-map; rvip_head_mse_coef (loss_kind BCE_DICE) combines the sets, rvip_bn_bwd_apply_head_lazy rebuilds
+ * the gradient per pixel.  rvip_head_grad, rvip_scale_f32, rvip_bn_bwd_reduce_head and their finalisers drop out of the BCE-Dice
+ * step as they did from the MSE step.  Same limits as rvip_bn_apply_head_mse (k <= 2: a 4-class head keeps the classic launches). */
+int rvip_bn_apply_head_bcedice(const rvip_apply_desc* d, const float* head_w, const float* head_b, const float* beta, int k, float* pred,
+                               const float* y_true, float* sums, float* rows_out, size_t rows_bytes,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int rvip_bn_bwd_apply_head_lazy(const rvip_bnbwd_desc* d, const float* head_w, const float* pred, const float* y_true,
+                                const float* dcoef, int k, void* stream);
 
 /* Per-(slice, class) argmax of the heat-map, row-major first-max (north_star landmark index), and the
  * >0.5 label mask of predict_model.py:149-156.  idx_out[n][k] int64; mask_out uint8 [rows][K] or NULL. */

@@ -1202,3 +1202,144 @@ def test_mse_head_gradients_from_the_forward_pass(dtype, shape):
     hc2.min_gamma = 0.0
     assert L.rvip_head_mse_coef(C.byref(hc2), stream()) == -1
     assert L.rvip_bn_apply_head_mse_rows(C.c_longlong(rows), c, ndt(dtype), 3) == 0
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(3, 12, 20, 16, 2, 1.0, 1.0), (2, 64, 96, 32, 2, 4096.0, 0.5), (2, 40, 24, 8, 1, 1.0, 1.0), (1, 64, 64, 64, 2, 2.0, 1.0)])
+def test_bce_dice_head_gradients_from_the_forward_pass(dtype, shape):
+    """The BCE-Dice form of the fused last stage (round 4): rvip_bn_apply_head_bcedice (three row sets, no logit gradient written) +
+    rvip_head_mse_coef(loss_kind BCE_DICE) + rvip_bn_bwd_apply_head_lazy (the gradient rebuilt per pixel from the heat-map, the target and
+    three coefficients) against the classic launches rvip_bn_apply_head + rvip_head_grad + rvip_scale_f32 + rvip_bn_bwd_reduce_head +
+    rvip_bn_bwd_apply_head (Loss_and_metrics.py:229-245 as restated there), on the same inputs: pred / loss sums bit for bit, the loss value
+    and every gradient to summation order; the BN terms of the algebraic route are held to the float64 straight-through values like the
+    MSE form's, the in-kernel exact route to the classic launch."""
+    n, h, w, c, k, dscale, lg = shape
+    rows = n * h * w
+    rng = np.random.default_rng(29 + c)
+    z = rnd(np.maximum(rng.standard_normal((n, h, w, c)) * 1.5 + 0.2, 0), dtype)
+    gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    hw = (rng.standard_normal((c, k)) * 0.3).astype(np.float32)
+    hb = (rng.standard_normal(k) * 0.1).astype(np.float32)
+    _, yt = O.synthetic_batch(n, (h, w), k, seed=3)
+    L = N.lib()
+    wsb = L.rvip_reduce_workspace(rows, 16 * c)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    zd, gd, bd, hwd, hbd, ytd = up(z, dtype), f32(gamma), f32(beta), f32(hw), f32(hb), f32(yt)
+    mm, mv = f32(np.zeros(c)), f32(np.ones(c))
+    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev()) for _ in range(4))
+    N.call('rvip_bn_train_stats', P(zd), C.c_longlong(rows), c, ndt(dtype), P(gd), P(bd), P(mm), P(mv), 0.99, 1e-3, 1,
+           P(mean), P(invstd), P(scale), P(shift), P(ws), C.c_size_t(wsb), stream())
+    state = torch.zeros(8, dtype=torch.int32, device=dev())
+    a = N.ApplyDesc()
+    a.z, a.y, a.pooled = zd.data_ptr(), None, None
+    a.scale, a.shift, a.act = scale.data_ptr(), shift.data_ptr(), 0
+    a.drop_rate, a.mask, a.state, a.layer_id = 0.0, None, state.data_ptr(), 0
+    a.n, a.h, a.w, a.c, a.dtype = n, h, w, c, ndt(dtype)
+    inv_count = 1.0 / (rows * k)
+    w_bce, w_dice = 0.5, 1.0
+
+    def outputs():
+        o = {'dz': torch.full((n, h, w, c), 3.0, dtype=tdt(dtype), device=dev())}
+        for nm in ('dgamma', 'dbeta', 'dbias'):
+            o[nm] = torch.full((c,), 7.0, dtype=torch.float32, device=dev())
+        o['coef'] = torch.full((3 * c,), 7.0, dtype=torch.float32, device=dev())
+        o['hdw'] = torch.full((c, k), 7.0, dtype=torch.float32, device=dev())
+        o['hdb'] = torch.full((k,), 7.0, dtype=torch.float32, device=dev())
+        o['pred'] = torch.empty((n, h, w, k), dtype=torch.float32, device=dev())
+        o['sums'] = torch.zeros(16, dtype=torch.float32, device=dev())
+        o['dlogit'] = torch.full((n, h, w, k), 7.0, dtype=torch.float32, device=dev())
+        o['loss'] = torch.full((1,), 7.0, dtype=torch.float32, device=dev())
+        return o
+
+    def bwd_desc(o):
+        b = N.BnBwdDesc()
+        b.dy, b.z, b.dz = None, zd.data_ptr(), o['dz'].data_ptr()
+        b.gamma, b.mean, b.invstd = gd.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+        b.scale, b.shift = scale.data_ptr(), shift.data_ptr()
+        b.dgamma, b.dbeta, b.dbias, b.coef = o['dgamma'].data_ptr(), o['dbeta'].data_ptr(), o['dbias'].data_ptr(), o['coef'].data_ptr()
+        b.act, b.act_after_bn = N.ACT['relu'], 0
+        b.drop_rate, b.mask, b.state, b.layer_id = 0.0, None, state.data_ptr(), 0
+        b.rows, b.c, b.dtype = rows, c, ndt(dtype)
+        b.workspace, b.workspace_bytes = ws.data_ptr(), wsb
+        return b
+    # classic
+    o0 = outputs()
+    N.call('rvip_bn_apply_head', C.byref(a), P(hwd), P(hbd), k, P(o0['pred']), P(ytd), P(o0['sums']), P(ws), C.c_size_t(wsb), stream())
+    N.call('rvip_head_grad', P(o0['pred']), P(ytd), P(o0['sums']), P(o0['dlogit']), P(o0['loss']), C.c_longlong(rows), k, N.LOSS_BCE_DICE,
+           C.c_float(inv_count), C.c_float(lg), C.c_float(w_bce), C.c_float(w_dice), stream())
+    if dscale != 1.0:
+        N.call('rvip_scale_f32', P(o0['dlogit']), C.c_longlong(rows * k), C.c_float(dscale), stream())
+    b0 = bwd_desc(o0)
+    N.call('rvip_bn_bwd_reduce_head', C.byref(b0), P(hwd), P(o0['dlogit']), k, P(o0['hdw']), P(o0['hdb']), stream())
+    N.call('rvip_bn_bwd_apply_head', C.byref(b0), P(hwd), P(o0['dlogit']), k, stream())
+    nr = L.rvip_bn_apply_head_mse_rows(C.c_longlong(rows), c, ndt(dtype), k)
+
+    def forward_side(min_gamma):
+        o = outputs()
+        frows = torch.full((nr * 7 * c,), 7.0, dtype=torch.float32, device=dev())
+        dcoef = torch.full((4,), 7.0, dtype=torch.float32, device=dev())
+        N.call('rvip_bn_apply_head_bcedice', C.byref(a), P(hwd), P(hbd), P(bd), k, P(o['pred']), P(ytd), P(o['sums']),
+               P(frows), C.c_size_t(frows.numel() * 4), P(ws), C.c_size_t(wsb), stream())
+        b = bwd_desc(o)
+        hc = N.HeadCoefDesc()
+        hc.bn, hc.beta = C.pointer(b), bd.data_ptr()
+        hc.head_w, hc.dlogit, hc.k, hc.nrows = hwd.data_ptr(), None, k, nr
+        hc.mse_rows, hc.head_dw, hc.head_db = frows.data_ptr(), o['hdw'].data_ptr(), o['hdb'].data_ptr()
+        hc.sums, hc.loss_out, hc.inv_count = o['sums'].data_ptr(), o['loss'].data_ptr(), inv_count
+        o['flags'] = torch.full((-(-c // 32),), 7, dtype=torch.int32, device=dev())
+        hc.flags, hc.min_gamma, hc.max_beta_ratio = o['flags'].data_ptr(), min_gamma, 64.0
+        hc.loss_kind, hc.w_bce, hc.w_dice, hc.local_over_global, hc.dscale = N.LOSS_BCE_DICE, w_bce, w_dice, lg, dscale
+        hc.pred, hc.y_true, hc.dcoef = o['pred'].data_ptr(), ytd.data_ptr(), dcoef.data_ptr()
+        N.call('rvip_head_mse_coef', C.byref(hc), stream())
+        N.call('rvip_bn_bwd_apply_head_lazy', C.byref(b), P(hwd), P(o['pred']), P(ytd), P(dcoef), k, stream())
+        torch.cuda.synchronize()
+        o['dcoef'] = dcoef
+        return o, (a, b, hc, frows)
+    dl64, z64 = down(o0['dlogit']).astype(np.float64).reshape(rows, k), down(zd).astype(np.float64).reshape(rows, c)
+    g64 = dl64 @ hw.astype(np.float64).T
+    xh = (z64 - down(mean).astype(np.float64)) * down(invstd).astype(np.float64)
+    want_db, want_dg = g64.sum(0), (g64 * xh).sum(0)
+    gm_, is_, mu_ = gamma.astype(np.float64), down(invstd).astype(np.float64), down(mean).astype(np.float64)
+    c2 = -gm_ * is_ * is_ * want_dg / rows
+    exact = {'dbeta': want_db, 'dgamma': want_dg, 'coef': np.concatenate([gm_ * is_, c2, -gm_ * is_ * want_db / rows - c2 * mu_])}
+    classic = {nm: down(o0[nm]).astype(np.float64) for nm in exact}
+    loose = {'bf16': 8e-3, 'f16': 1.2e-3}[dtype] * max(1.0, (12288.0 / rows) ** 0.5)
+    # the coefficients against the closed form from the folded sums
+    sm = down(o0['sums']).astype(np.float64)
+    den = sm[3] + sm[4] + 1.0
+    want_coef = np.array([w_bce * inv_count, -w_dice * lg * 2.0 / den, w_dice * lg * (2.0 * sm[2] + 1.0) / den ** 2]) * dscale
+    for min_gamma, want, tol in ((1.0 / 64, exact, loose), (1e9, classic, 2e-5)):
+        o1, keep = forward_side(min_gamma)
+        assert torch.equal(o1['pred'], o0['pred']) and torch.equal(o1['sums'], o0['sums'])
+        assert bool((o1['dlogit'] == 7.0).all())                                  # no logit gradient is written in this form
+        np.testing.assert_allclose(down(o1['loss']), down(o0['loss']), rtol=2e-6)
+        np.testing.assert_allclose(down(o1['dcoef'])[:3], want_coef, rtol=3e-6)
+        assert bool(down(o1['flags']).all()) == (min_gamma > 1) and bool(down(o1['flags']).any()) == (min_gamma > 1)
+        for nm in ('hdw', 'hdb'):
+            sc_ = float(np.abs(down(o0[nm])).max())
+            np.testing.assert_allclose(down(o1[nm]), down(o0[nm]), atol=3e-5 * sc_ + 1e-12, err_msg=nm)
+        for nm in ('dgamma', 'dbeta', 'coef'):
+            got, ref = down(o1[nm]).reshape(-1, c).astype(np.float64), want[nm].reshape(-1, c)
+            for i in range(got.shape[0]):
+                assert np.abs(got[i] - ref[i]).max() <= tol * np.abs(ref[i]).max() + 1e-12, (nm, i, min_gamma, np.abs(got[i] - ref[i]).max(), np.abs(ref[i]).max())
+        # the apply pass on the rebuilt gradient: dz and the bias-gradient rows against the classic launch (same coefficients up to `tol`)
+        dz1, dz0 = down(o1['dz']).astype(np.float64), down(o0['dz']).astype(np.float64)
+        scd = float(np.abs(dz0).max())
+        assert np.abs(dz1 - dz0).max() <= (3 * tol + {'bf16': 2.0 ** -7, 'f16': 2.0 ** -10}[dtype]) * scd, (min_gamma, np.abs(dz1 - dz0).max() / scd)
+        np.testing.assert_allclose(down(o1['dbias']), down(o0['dbias']), atol=(3 * tol + 1e-3) * float(np.abs(down(o0['dbias'])).max()) + 1e-12)
+    # what the entry points refuse
+    a2, b2, hc2, frows2 = keep
+    args = lambda kk, nbytes: (C.byref(a2), P(hwd), P(hbd), P(bd), kk, P(o1['pred']), P(ytd), P(o1['sums']), P(frows2), C.c_size_t(nbytes),  # noqa: E731
+                               P(ws), C.c_size_t(wsb), stream())
+    assert L.rvip_bn_apply_head_bcedice(*args(3, frows2.numel() * 4)) == -2
+    assert L.rvip_bn_apply_head_bcedice(*args(k, frows2.numel() * 4 - 4)) == -3
+    a2.dtype = N.F32
+    assert L.rvip_bn_apply_head_bcedice(*args(k, frows2.numel() * 4)) == -2
+    a2.dtype = ndt(dtype)
+    hc2.dcoef = None
+    assert L.rvip_head_mse_coef(C.byref(hc2), stream()) == -1
+    hc2.loss_kind = 5
+    assert L.rvip_head_mse_coef(C.byref(hc2), stream()) == -1
+    assert L.rvip_bn_bwd_apply_head_lazy(C.byref(b2), P(hwd), None, P(ytd), P(o1['dcoef']), k, stream()) == -1
+    assert L.rvip_bn_bwd_apply_head_lazy(C.byref(b2), P(hwd), P(o1['pred']), P(ytd), P(o1['dcoef']), 3, stream()) == -2
