@@ -1327,7 +1327,9 @@ def test_bce_dice_head_gradients_from_the_forward_pass(dtype, shape):
         dz1, dz0 = down(o1['dz']).astype(np.float64), down(o0['dz']).astype(np.float64)
         scd = float(np.abs(dz0).max())
         assert np.abs(dz1 - dz0).max() <= (3 * tol + {'bf16': 2.0 ** -7, 'f16': 2.0 ** -10}[dtype]) * scd, (min_gamma, np.abs(dz1 - dz0).max() / scd)
-        np.testing.assert_allclose(down(o1['dbias']), down(o0['dbias']), atol=(3 * tol + 1e-3) * float(np.abs(down(o0['dbias'])).max()) + 1e-12)
+        # (the bias gradient is the column sum of dz, which BatchNormalization's backward makes cancel: the two launches' per-element
+        #  differences, zero-mean roundings, add up like a random walk over the rows)
+        np.testing.assert_allclose(down(o1['dbias']), down(o0['dbias']), atol=(3 * tol + {'bf16': 2.0 ** -7, 'f16': 2.0 ** -10}[dtype]) * scd * np.sqrt(rows))
     # what the entry points refuse
     a2, b2, hc2, frows2 = keep
     args = lambda kk, nbytes: (C.byref(a2), P(hwd), P(hbd), P(bd), kk, P(o1['pred']), P(ytd), P(o1['sums']), P(frows2), C.c_size_t(nbytes),  # noqa: E731
