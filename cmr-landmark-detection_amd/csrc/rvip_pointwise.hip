@@ -1116,6 +1116,10 @@ __device__ __forceinline__ void head_grad_vec(const HeadFuse& hd, long long r, c
     if (hd.dlogit) {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) d[kk] = kk < hd.k ? hd.dlogit[(size_t)r * hd.k + kk] : 0.f;
+    } else if (KK == 2 && hd.k == 2) {                            // both classes of the pixel in one 8-byte load per tensor
+        const float2 p2 = *reinterpret_cast<const float2*>(hd.pred + (size_t)r * 2), t2 = *reinterpret_cast<const float2*>(hd.yt + (size_t)r * 2);
+        d[0] = head_lazy_d(hd, p2.x, t2.x);
+        d[KK - 1] = head_lazy_d(hd, p2.y, t2.y);
     } else {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) d[kk] = kk < hd.k ? head_lazy_d(hd, hd.pred[(size_t)r * hd.k + kk], hd.yt[(size_t)r * hd.k + kk]) : 0.f;
