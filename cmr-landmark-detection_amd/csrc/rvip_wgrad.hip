@@ -704,14 +704,23 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     }
 }
 
-// dw[i] = sum_k slab[k][i] in a fixed order (reproducible).  A thread owns four consecutive elements (one 16-byte
-// load per slab); a workgroup = 32 such threads x G split groups, and every thread has all of its (<= U) loads in
-// flight before the first add: the fold of a small kernel over hundreds of slabs is a chain of load latencies.
-template <int G, int U>
-__global__ __launch_bounds__(32 * G) void wgrad_fold_kernel(const float4* __restrict__ slab, int nsplit, long long count4, float4* __restrict__ dw) {
-    __shared__ float4 sh[G][32];
-    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const long long i = blockIdx.x * 32LL + e;
+// dw[i] = sum_k slab[k][i] in a fixed order (reproducible).  A thread owns four consecutive elements (one 16-byte load per slab);
+// G split groups of 32 such threads share a segment, every thread has U = 8 loads in flight before the first add, and R segments
+// make up the workgroup.  G is a function of the slab count alone (fold_groups): about eight slabs per thread -- the round-3 geometry
+// (32 groups above 32 slabs, 8 groups above 4, 4 below) left a thread of the 64-, 8- and 4-slab layers with one or two loads in
+// flight and thousands of tiny workgroups (2.2-2.4 TB/s where the 256-slab layers reached 3.4).  The order of the sum -- per group
+// its slabs in steps of G, eight at a time; then the groups in order -- depends on the slab count only, and both folds below use it:
+// same bits from either.
+static int fold_groups(int nsplit) {
+    int g = 1;
+    while (g < 32 && g * 8 < nsplit) g <<= 1;
+    return g;
+}
+template <int G, int U, int R>
+__global__ __launch_bounds__(32 * G * R) void wgrad_fold_kernel(const float4* __restrict__ slab, int nsplit, long long count4, float4* __restrict__ dw) {
+    __shared__ float4 sh[R][G][32];
+    const int e = threadIdx.x & 31, g = (threadIdx.x >> 5) % G, r = threadIdx.x / (32 * G);
+    const long long i = ((long long)blockIdx.x * R + r) * 32 + e;
     float4 acc = {0.f, 0.f, 0.f, 0.f};
     if (i < count4) {
         for (int k0 = g; k0 < nsplit; k0 += G * U) {
@@ -725,12 +734,16 @@ __global__ __launch_bounds__(32 * G) void wgrad_fold_kernel(const float4* __rest
             for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
     }
-    sh[g][e] = acc;
+    if constexpr (G == 1) {
+        if (i < count4) dw[i] = acc;
+        return;
+    }
+    sh[r][g][e] = acc;
     __syncthreads();
     if (g == 0 && i < count4) {
-        float4 t = sh[0][e];
+        float4 t = sh[r][0][e];
 #pragma unroll
-        for (int gg = 1; gg < G; ++gg) { t.x += sh[gg][e].x; t.y += sh[gg][e].y; t.z += sh[gg][e].z; t.w += sh[gg][e].w; }
+        for (int gg = 1; gg < G; ++gg) { t.x += sh[r][gg][e].x; t.y += sh[r][gg][e].y; t.z += sh[r][gg][e].z; t.w += sh[r][gg][e].w; }
         dw[i] = t;
     }
 }
@@ -738,12 +751,17 @@ __global__ __launch_bounds__(32 * G) void wgrad_fold_kernel(const float4* __rest
 static int launch_wgrad_fold(const float* slab, int nsplit, long long count, float* dw, hipStream_t s) {
     if (count % 4 || ((uintptr_t)slab & 15) || ((uintptr_t)dw & 15)) return RVIP_EINVAL;
     const long long count4 = count / 4;
-    const dim3 grid((unsigned)cdiv(count4, 32));
     const float4* sl = reinterpret_cast<const float4*>(slab);
     float4* out = reinterpret_cast<float4*>(dw);
-    if (nsplit > 32) hipLaunchKernelGGL((wgrad_fold_kernel<32, 8>), grid, dim3(1024), 0, s, sl, nsplit, count4, out);
-    else if (nsplit > 4) hipLaunchKernelGGL((wgrad_fold_kernel<8, 4>), grid, dim3(256), 0, s, sl, nsplit, count4, out);
-    else hipLaunchKernelGGL((wgrad_fold_kernel<4, 1>), grid, dim3(128), 0, s, sl, nsplit, count4, out);
+    const long long segs = cdiv(count4, 32);
+    switch (fold_groups(nsplit)) {
+        case 1: hipLaunchKernelGGL((wgrad_fold_kernel<1, 8, 8>), dim3((unsigned)cdiv(segs, 8)), dim3(256), 0, s, sl, nsplit, count4, out); break;
+        case 2: hipLaunchKernelGGL((wgrad_fold_kernel<2, 8, 4>), dim3((unsigned)cdiv(segs, 4)), dim3(256), 0, s, sl, nsplit, count4, out); break;
+        case 4: hipLaunchKernelGGL((wgrad_fold_kernel<4, 8, 2>), dim3((unsigned)cdiv(segs, 2)), dim3(256), 0, s, sl, nsplit, count4, out); break;
+        case 8: hipLaunchKernelGGL((wgrad_fold_kernel<8, 8, 1>), dim3((unsigned)segs), dim3(256), 0, s, sl, nsplit, count4, out); break;
+        case 16: hipLaunchKernelGGL((wgrad_fold_kernel<16, 8, 1>), dim3((unsigned)segs), dim3(512), 0, s, sl, nsplit, count4, out); break;
+        default: hipLaunchKernelGGL((wgrad_fold_kernel<32, 8, 1>), dim3((unsigned)segs), dim3(1024), 0, s, sl, nsplit, count4, out); break;
+    }
     return check_launch();
 }
 
@@ -754,21 +772,23 @@ static int launch_wgrad_fold(const float* slab, int nsplit, long long count, flo
 // inner product of an input channel with its own gradient can be read off the weight gradient (rvip_bn_bwd_coef uses it as the
 // sum g*y of the producer's BatchNormalization backward; no pass over g and y).
 // A (tap, ci) row of the kernel = cout4 float4s handled by LW = min(32, pow2 >= cout4) lanes of the 32 "element" lanes; 32 / LW
-// rows per workgroup, nchunk = ceil(cout4 / 32) workgroups per row.  G split groups as in wgrad_fold_kernel.
-template <typename T, int G, int U>
-__global__ __launch_bounds__(32 * G) void wgrad_fold_dot_kernel(const float4* __restrict__ slab, int nsplit, long long count4, float4* __restrict__ dw,
-                                                                const float4* __restrict__ w, int cout4, int cin, int nrow, int lw, int nchunk,
-                                                                double* __restrict__ rows) {
+// rows per segment, nchunk = ceil(cout4 / 32) segments per row.  G split groups, U loads in flight and R segments per workgroup as in
+// wgrad_fold_kernel.
+template <typename T, int G, int U, int R>
+__global__ __launch_bounds__(32 * G * R) void wgrad_fold_dot_kernel(const float4* __restrict__ slab, int nsplit, long long count4, float4* __restrict__ dw,
+                                                                    const float4* __restrict__ w, int cout4, int cin, int nrow, int lw, int nchunk,
+                                                                    int nseg, double* __restrict__ rows) {
     // The dot product is carried in DOUBLE from the slabs on: sum W*dW is a small difference of large terms whenever the
     // gradient reaching the producer is mostly common-mode (BatchNormalization removes that part), and float partial sums over
     // the 9 * Cout terms of a channel would lose to that cancellation what the pass over (g, xhat) it replaces does not.  dw
     // itself is the float sum in the plain fold's order (bit-identical to wgrad_fold_kernel).
-    __shared__ float4 sh[G][32];
-    __shared__ double shd[G][32][4];
-    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    __shared__ float4 sh[R][G][32];
+    __shared__ double shd[R][G][32][4];
+    const int e = threadIdx.x & 31, g = (threadIdx.x >> 5) % G, r = threadIdx.x / (32 * G);
+    const int seg = blockIdx.x * R + r;
     const int rpw = 32 / lw, rl = e / lw, l = e - rl * lw;
-    const int chunk = blockIdx.x % nchunk, row = (blockIdx.x / nchunk) * rpw + rl, col4 = chunk * 32 + l;
-    const bool valid = row < nrow && col4 < cout4;
+    const int chunk = seg % nchunk, row = (seg / nchunk) * rpw + rl, col4 = chunk * 32 + l;
+    const bool valid = seg < nseg && row < nrow && col4 < cout4;
     const long long i = (long long)row * cout4 + col4;
     float4 acc = {0.f, 0.f, 0.f, 0.f};
     double da[4] = {0.0, 0.0, 0.0, 0.0};
@@ -787,27 +807,36 @@ __global__ __launch_bounds__(32 * G) void wgrad_fold_dot_kernel(const float4* __
             }
         }
     }
-    sh[g][e] = acc;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) shd[g][e][q] = da[q];
-    __syncthreads();
-    if (g >= 2) return;                                   // the first wave (element lanes 0..31 twice) finishes
     double p = 0.0;
-    if (g == 0 && valid) {
-        float4 t = sh[0][e];
-        double d[4] = {shd[0][e][0], shd[0][e][1], shd[0][e][2], shd[0][e][3]};
-#pragma unroll
-        for (int gg = 1; gg < G; ++gg) {
-            t.x += sh[gg][e].x; t.y += sh[gg][e].y; t.z += sh[gg][e].z; t.w += sh[gg][e].w;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) d[q] += shd[gg][e][q];
+    if constexpr (G == 1) {
+        if (valid) {
+            dw[i] = acc;
+            const float4 wv = w[i];
+            p = (double)Vec<T>::round(wv.x) * da[0] + (double)Vec<T>::round(wv.y) * da[1] + (double)Vec<T>::round(wv.z) * da[2] + (double)Vec<T>::round(wv.w) * da[3];
         }
-        dw[i] = t;
-        const float4 wv = w[i];
-        p = (double)Vec<T>::round(wv.x) * d[0] + (double)Vec<T>::round(wv.y) * d[1] + (double)Vec<T>::round(wv.z) * d[2] + (double)Vec<T>::round(wv.w) * d[3];
+    } else {
+        sh[r][g][e] = acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) shd[r][g][e][q] = da[q];
+        __syncthreads();
+        if (g != 0) return;                                   // group 0 of every segment finishes (its 32 element lanes = one half wave)
+        if (valid) {
+            float4 t = sh[r][0][e];
+            double d[4] = {shd[r][0][e][0], shd[r][0][e][1], shd[r][0][e][2], shd[r][0][e][3]};
+#pragma unroll
+            for (int gg = 1; gg < G; ++gg) {
+                t.x += sh[r][gg][e].x; t.y += sh[r][gg][e].y; t.z += sh[r][gg][e].z; t.w += sh[r][gg][e].w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d[q] += shd[r][gg][e][q];
+            }
+            dw[i] = t;
+            const float4 wv = w[i];
+            p = (double)Vec<T>::round(wv.x) * d[0] + (double)Vec<T>::round(wv.y) * d[1] + (double)Vec<T>::round(wv.z) * d[2] + (double)Vec<T>::round(wv.w) * d[3];
+        }
     }
-    for (int o = 1; o < lw; o <<= 1) p += __shfl_xor(p, o);        // lw is a power of two <= 32: stays inside the row's lanes
-    if (g == 0 && l == 0 && row < nrow) {
+    // lw is a power of two <= 32 and a row's lanes are lw consecutive lanes of one 32-lane half wave: the butterfly stays inside them
+    for (int o = 1; o < lw; o <<= 1) p += __shfl_xor(p, o);
+    if (l == 0 && seg < nseg && row < nrow) {
         const int tap = row / cin, ci = row - tap * cin;
         rows[((size_t)tap * nchunk + chunk) * cin + ci] = p;
     }
@@ -830,13 +859,20 @@ static int launch_wgrad_fold_dot(const float* slab, int nsplit, int cin, int cou
     const long long count = 9LL * cin * cout;
     if (cout % 4 || ((uintptr_t)slab & 15) || ((uintptr_t)dw & 15) || ((uintptr_t)w & 15)) return RVIP_EINVAL;
     const DotGeom g = dot_geometry(9, cin, cout);
-    const dim3 grid((unsigned)(cdiv(g.nrow, 32 / g.lw) * g.nchunk));
+    const int nseg = (int)(cdiv(g.nrow, 32 / g.lw) * g.nchunk);
     const float4* sl = reinterpret_cast<const float4*>(slab);
     const float4* w4 = reinterpret_cast<const float4*>(w);
     float4* out = reinterpret_cast<float4*>(dw);
-    if (nsplit > 32) hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, 32, 8>), grid, dim3(1024), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, rows);
-    else if (nsplit > 4) hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, 8, 4>), grid, dim3(256), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, rows);
-    else hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, 4, 1>), grid, dim3(128), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, rows);
+#define RVIP_FOLD_DOT(G_, R_) hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, G_, 8, R_>), dim3((unsigned)cdiv(nseg, R_)), dim3(32 * G_ * R_), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, nseg, rows)
+    switch (fold_groups(nsplit)) {
+        case 1: RVIP_FOLD_DOT(1, 8); break;
+        case 2: RVIP_FOLD_DOT(2, 4); break;
+        case 4: RVIP_FOLD_DOT(4, 2); break;
+        case 8: RVIP_FOLD_DOT(8, 1); break;
+        case 16: RVIP_FOLD_DOT(16, 1); break;
+        default: RVIP_FOLD_DOT(32, 1); break;
+    }
+#undef RVIP_FOLD_DOT
     return check_launch();
 }
 
