@@ -292,6 +292,7 @@ struct ConvArgs2 {
     const uint32_t* mbits; unsigned mbits_bytes; int mbits_c; float mscale; int lds_mb_off;      // see ConvArgs; STATS == 3 kernels
     uint32_t* sbits; unsigned sbits_bytes;   // STATS == 0 kernels
     int sums_from;                           // STATS >= 2: columns below this channel are not needed (left unwritten or partial)
+    int nstg;                                // input stages in LDS: 2, or 3 (conv3x3_igemm_ws16 with resident weights where LDS allows: two items in flight)
 };
 
 // Gate four consecutive channels of one pixel by four bits of a mask word (STATS == 3): v = bit ? v * scale : 0.  The bit is
@@ -849,8 +850,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     static_assert(TW == 32 ? (NPT % 2 == 0) : true, "whole tile rows per wave");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* lin = smem;                       // [2][IN_BYTES]
-    unsigned char* lw = smem + 2 * IN_BYTES;         // [wres or 2][W_BYTES]
+    unsigned char* lin = smem;                       // [nstg][IN_BYTES]
+    unsigned char* lw = smem + a.nstg * IN_BYTES;    // [wres or 2][W_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -942,7 +943,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             const int kdi = a.kd > 1 ? kc / nch : 0;
             const int cbase = (kc - kdi * nch) * KCE;
             const int tapbase = ((kdi + ph) * TAPS * a.cout * a.cin + cbase) * (int)sizeof(T);
-            const unsigned lw0 = lds_base + 2 * IN_BYTES + wstage * W_BYTES + lwv * 1024;      // + i * 4096 per piece
+            const unsigned lw0 = lds_base + a.nstg * IN_BYTES + wstage * W_BYTES + lwv * 1024; // + i * 4096 per piece
             if (a.cin - cbase >= KCE) {                  // full chunk: valid rows carry all their channels
 #pragma unroll
                 for (int i = 0; i < QW; ++i) {
@@ -973,7 +974,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             if constexpr (STATS == 3) {
                 if (kc == 0) {                               // first chunk of a tile: its mask words ride along (wave-uniform)
                     if (lwv < NCT * NPM) dma16(rsm, p_mb, lds_base + a.lds_mb_off + mb_par * MB_TILE + lwv * 1024);
-                    mb_par ^= 1;
+                    mb_par = mb_par + 1 == a.nstg ? 0 : mb_par + 1;      // one buffer of mask words per input stage
                 }
             }
             if (crem >= KCE && !a.nt_in) {                   // full chunk inside the volume: offset = prepared + base
@@ -1003,23 +1004,43 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
         };
         if (resident) for (int kc = 0; kc < nchunks; ++kc) issue_weights(kc, kc);
         else issue_weights(0, 0);
-        prep_tile(first_tile);
-        issue_input(0, 0);
-        if (nchunks == 1 && first_tile + (int)gridDim.x < a.ntiles) prep_tile(first_tile + gridDim.x);
-        int it = 0;
+        // The loaders run nstg - 1 items ahead of the compute waves.  Two stages (the original form): the next item is requested behind
+        // the barrier that frees its stage and must have landed one item later -- a one-chunk tile then has ONE tile's bytes in flight
+        // per CU and its compute waves wait for the DMA at every barrier.  Three stages (weights resident, LDS permitting): the item
+        // requested here is consumed TWO barriers later, and the wait in front of a barrier is a COUNTED one -- s_waitcnt vmcnt(n) with
+        // n = this wave's DMA instructions of the younger item, which may stay in flight (loads return in order).
+        constexpr int NIN_FULL = QI, NIN_LAST = QI - 1;      // input pieces of a wave per item: QI, or QI - 1 for the waves past the last piece
+        const int nin = (lwv + 4 * (QI - 1) < NQI) ? NIN_FULL : NIN_LAST;
+        int itile = first_tile, ikc = 0, istg = 0;
+        prep_tile(itile);
+        auto issue_next = [&]() __attribute__((always_inline)) -> int {     // requests the cursor's item; returns this wave's DMA count for it (0: none)
+            if (itile >= a.ntiles) return 0;
+            int cnt = nin;
+            if constexpr (STATS == 3) cnt += (ikc == 0 && lwv < NCT * NPM) ? 1 : 0;
+            issue_input(ikc, istg);
+            if (!resident) issue_weights(ikc, istg);                          // (rotating weights: two stages only, host-checked)
+            if (++ikc == nchunks) {
+                ikc = 0;
+                itile += gridDim.x;
+                if (itile < a.ntiles) prep_tile(itile);                        // its offsets, while the DMAs fly
+            }
+            istg = istg + 1 == a.nstg ? 0 : istg + 1;
+            return cnt;
+        };
+        issue_next();
+        if (a.dbg & 1) itile = a.ntiles;                  // (ablation: nothing is requested after the first item)
+        int cyoung = a.nstg == 3 ? issue_next() : 0;      // DMAs of the item BEHIND the one the next barrier hands over
         for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
-            for (int kc = 0; kc < nchunks; ++kc, ++it) {
-                // my pieces of item `it` have landed; after the barrier: everybody's have, and the compute waves are done
-                // with item it-1, whose stage the next item may now overwrite
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                int ntile = tile, nkc = kc + 1;
-                if (nkc == nchunks) { nkc = 0; ntile = tile + gridDim.x; }
-                if (ntile < a.ntiles && !(a.dbg & 1)) {
-                    issue_input(nkc, (it + 1) & 1);          // the prepared tile is ntile (see below)
-                    if (!resident) issue_weights(nkc, (it + 1) & 1);
-                    // ntile's last chunk is on its way: prepare its successor while the DMAs fly
-                    if (nkc == nchunks - 1 && ntile + (int)gridDim.x < a.ntiles) prep_tile(ntile + gridDim.x);
-                }
+            for (int kc = 0; kc < nchunks; ++kc) {
+                // my pieces of the item about to be consumed have landed; after the barrier: everybody's have, and the compute waves
+                // are done with the item before it, whose stage the next request may now overwrite
+                if (cyoung == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (cyoung == QI + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QI + 1) : "memory");
+                else if (cyoung == QI) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QI > 1 ? QI - 1 : 0) : "memory");
+                asm volatile("s_barrier" ::: "memory");
+                const int c = issue_next();
+                if (a.nstg == 3) cyoung = c;
             }
         }
         if constexpr (STATS) {                           // the compute waves' reduction uses two more workgroup barriers
@@ -1079,8 +1100,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                                                                           STATS == 0 && a.sbits ? a.sbits_bytes : 0u, 0x00020000);
     int mb_par = 0;
 
-    int it = 0;
-    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x, mb_par ^= 1) {
+    int it = 0, stg = 0;
+    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x, mb_par = (mb_par + 1 == a.nstg ? 0 : mb_par + 1)) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
@@ -1088,12 +1109,14 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
         const int ty0 = ty_i * TH, tx0 = tx_i * TW;
         for (int kc = 0; kc < nchunks; ++kc, ++it) {
             asm volatile("s_barrier" ::: "memory");              // item `it` is in LDS (the loaders waited for their DMAs)
+            const int cur = stg;
+            stg = stg + 1 == a.nstg ? 0 : stg + 1;
             if (a.dbg & 2) continue;
-            const unsigned char* sin = lin + (it & 1) * IN_BYTES + (TAPS == 4 ? pa * HWD * 64 : 0);
+            const unsigned char* sin = lin + cur * IN_BYTES + (TAPS == 4 ? pa * HWD * 64 : 0);
             if constexpr (TAPS == 4) {
                 if (s2d) {                                           // source phase of this chunk -> window origin (wave-uniform)
                     const int kdi = kc / nch;
-                    sin = lin + (it & 1) * IN_BYTES + (1 - (kdi >> 1)) * HWD * 64;
+                    sin = lin + cur * IN_BYTES + (1 - (kdi >> 1)) * HWD * 64;
                     const bool c1st = (kdi & 1) != 0;                // be = 1: window starts at halo column 0
                     in_base[0] = c1st ? in_base3[0] : in_base3[1];
                     in_base[1] = c1st ? in_base3[1] : in_base3[2];
@@ -1367,10 +1390,15 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if ((gated || b.sbits) && (a0.cout % 8 || a0.down2 || (gated && a0.mbits_c % 32 && a0.mbits_c != a0.cout))) return RVIP_OK;      // (not served: the caller sees used == false)
     b.tiles_x = (int)cdiv(a0.w, TW); b.tiles_y = (int)cdiv(a0.h, TH);
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
-    const int mb_bytes = gated ? 2 * NCT * TH * TW * 4 : 0;      // two tiles of mask words behind the bias table
-    const bool res = 2 * IN_BYTES + nchunks * W_BYTES + 256 + mb_bytes <= LDS_MAX;
+    const int mb_tile = gated ? NCT * TH * TW * 4 : 0;           // one tile of mask words per input stage, behind the bias table
+    // a third input stage (two items in flight per CU) where the 16-bit kernel keeps every weight chunk resident beside it
+    static const bool stg3_on = [] { const char* e = getenv("RVIP_IGEMM_STAGES"); return !(e && e[0] == '2'); }();
+    const bool res3 = WS16 && stg3_on && 3 * IN_BYTES + nchunks * W_BYTES + 256 + 3 * mb_tile <= LDS_MAX;
+    b.nstg = res3 ? 3 : 2;
+    const int mb_bytes = b.nstg * mb_tile;
+    const bool res = res3 || 2 * IN_BYTES + nchunks * W_BYTES + 256 + mb_bytes <= LDS_MAX;
     b.wres = res ? nchunks : 0;
-    b.lds_bias_off = 2 * IN_BYTES + (res ? nchunks : 2) * W_BYTES;
+    b.lds_bias_off = b.nstg * IN_BYTES + (res ? nchunks : 2) * W_BYTES;
     b.lds_mb_off = b.lds_bias_off + 256;
     const int lds = b.lds_bias_off + 256 + mb_bytes;
     if (lds > LDS_MAX) return RVIP_OK;
