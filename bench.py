@@ -243,7 +243,7 @@ def main():
                 d0 = th[1][0]._obj
                 d1 = type(d0).from_buffer_copy(d0)
                 if max(d0.kd, 1) == 1:
-                    d1.defer_fold, d1.dot_rows, d1.w_master = 1, None, None
+                    d1.defer_fold, d1.dot_rows, d1.w_master, d1.w_phase = 1, None, None, None
                     d1.workspace, d1.workspace_bytes = eng.ws_wg.data_ptr(), eng.ws_wg_bytes
                 wg_keep.append(d1)
                 wg_calls.append((wgrad_fn, (C.byref(d1),)))

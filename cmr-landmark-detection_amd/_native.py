@@ -51,7 +51,7 @@ class Wgrad3x3Desc(C.Structure):
                 ('dtype', C.c_int32),
                 ('workspace', vp), ('workspace_bytes', C.c_size_t),
                 ('depth', C.c_int32), ('kd', C.c_int32), ('defer_fold', C.c_int32),
-                ('w_master', vp), ('dot_rows', vp), ('dot_rows_bytes', C.c_size_t)]
+                ('w_master', vp), ('dot_rows', vp), ('dot_rows_bytes', C.c_size_t), ('w_phase', vp)]
 
 
 class ApplyDesc(C.Structure):

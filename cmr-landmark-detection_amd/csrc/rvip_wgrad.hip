@@ -774,16 +774,20 @@ static int launch_wgrad_fold(const float* slab, int nsplit, long long count, flo
 // A (tap, ci) row of the kernel = cout4 float4s handled by LW = min(32, pow2 >= cout4) lanes of the 32 "element" lanes; 32 / LW
 // rows per segment, nchunk = ceil(cout4 / 32) segments per row.  G split groups, U loads in flight and R segments per workgroup as in
 // wgrad_fold_kernel.
-template <typename T, int G, int U, int R>
+// SPD (the layer's data gradient runs in sub-pixel form; the slabs come from the four-phase weight-gradient form, slab k = phase
+// (k >> 3) & 3 when the grid was XCD-mapped, k & 3 otherwise): the rows are dotted against the PHASE kernels wph[phase][u][v][ci][co]
+// of rvip_pack_subpixel_dgrad_weights instead of the rounded taps.  A phase's slab holds its summed-tap block (u, v) at every 3x3 tap
+// position the block covers; the first such position (in kh, kw order) represents it.
+template <typename T, int G, int U, int R, int SPD = 0>
 __global__ __launch_bounds__(32 * G * R) void wgrad_fold_dot_kernel(const float4* __restrict__ slab, int nsplit, long long count4, float4* __restrict__ dw,
                                                                     const float4* __restrict__ w, int cout4, int cin, int nrow, int lw, int nchunk,
-                                                                    int nseg, double* __restrict__ rows) {
+                                                                    int nseg, double* __restrict__ rows, const T* __restrict__ wph = nullptr, int xcd_map = 0) {
     // The dot product is carried in DOUBLE from the slabs on: sum W*dW is a small difference of large terms whenever the
     // gradient reaching the producer is mostly common-mode (BatchNormalization removes that part), and float partial sums over
     // the 9 * Cout terms of a channel would lose to that cancellation what the pass over (g, xhat) it replaces does not.  dw
     // itself is the float sum in the plain fold's order (bit-identical to wgrad_fold_kernel).
     __shared__ float4 sh[R][G][32];
-    __shared__ double shd[R][G][32][4];
+    __shared__ double shd[R][G][32][SPD ? 1 : 4];
     const int e = threadIdx.x & 31, g = (threadIdx.x >> 5) % G, r = threadIdx.x / (32 * G);
     const int seg = blockIdx.x * R + r;
     const int rpw = 32 / lw, rl = e / lw, l = e - rl * lw;
@@ -791,7 +795,12 @@ __global__ __launch_bounds__(32 * G * R) void wgrad_fold_dot_kernel(const float4
     const bool valid = seg < nseg && row < nrow && col4 < cout4;
     const long long i = (long long)row * cout4 + col4;
     float4 acc = {0.f, 0.f, 0.f, 0.f};
-    double da[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int NPH = SPD ? 4 : 1;
+    double da[NPH][4];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) da[ph][q] = 0.0;
     if (valid) {
         for (int k0 = g; k0 < nsplit; k0 += G * U) {
             float4 v[U];
@@ -803,7 +812,38 @@ __global__ __launch_bounds__(32 * G * R) void wgrad_fold_dot_kernel(const float4
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
-                da[0] += (double)v[u].x; da[1] += (double)v[u].y; da[2] += (double)v[u].z; da[3] += (double)v[u].w;
+                if constexpr (SPD) {
+                    const int k = k0 + u * G, phk = xcd_map ? (k >> 3) & 3 : k & 3;      // (slabs past nsplit carry zeros)
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph) {
+                        const bool m = phk == ph;
+                        da[ph][0] += m ? (double)v[u].x : 0.0; da[ph][1] += m ? (double)v[u].y : 0.0;
+                        da[ph][2] += m ? (double)v[u].z : 0.0; da[ph][3] += m ? (double)v[u].w : 0.0;
+                    }
+                } else {
+                    da[0][0] += (double)v[u].x; da[0][1] += (double)v[u].y; da[0][2] += (double)v[u].z; da[0][3] += (double)v[u].w;
+                }
+            }
+        }
+    }
+    // SPD: this thread's slabs against the phase kernels, before the groups are folded (the product is linear in the slabs)
+    double pt = 0.0;
+    if constexpr (SPD) {
+        if (valid) {
+            const int t9 = row / cin, ci = row - t9 * cin, kh = t9 / 3, kw = t9 - 3 * kh;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const int pa = ph >> 1, pb = ph & 1;
+                // forward convention: phase 0 covers tap 0 | taps 1, 2;  phase 1 covers taps 0, 1 | tap 2  (per axis)
+                const int uf = pa ? (kh == 2 ? 1 : 0) : (kh != 0 ? 1 : 0), vf = pb ? (kw == 2 ? 1 : 0) : (kw != 0 ? 1 : 0);
+                const bool rep = (pa ? kh != 1 : kh != 2) && (pb ? kw != 1 : kw != 2);       // first tap position of its block, per axis
+                if (rep) {
+                    // the data-gradient phase kernels index the window mirrored: (u, v)_d = (1 - u, 1 - v)_f
+                    const T* wp = wph + (((size_t)(ph * 4 + 2 * (1 - uf) + (1 - vf)) * cin + ci) * (size_t)(cout4 * 4) + (size_t)col4 * 4);
+                    const uint2 w2 = *reinterpret_cast<const uint2*>(wp);
+                    pt += (double)Vec<T>::dec((uint16_t)(w2.x & 0xffffu)) * da[ph][0] + (double)Vec<T>::dec((uint16_t)(w2.x >> 16)) * da[ph][1]
+                        + (double)Vec<T>::dec((uint16_t)(w2.y & 0xffffu)) * da[ph][2] + (double)Vec<T>::dec((uint16_t)(w2.y >> 16)) * da[ph][3];
+                }
             }
         }
     }
@@ -811,27 +851,38 @@ __global__ __launch_bounds__(32 * G * R) void wgrad_fold_dot_kernel(const float4
     if constexpr (G == 1) {
         if (valid) {
             dw[i] = acc;
-            const float4 wv = w[i];
-            p = (double)Vec<T>::round(wv.x) * da[0] + (double)Vec<T>::round(wv.y) * da[1] + (double)Vec<T>::round(wv.z) * da[2] + (double)Vec<T>::round(wv.w) * da[3];
+            if constexpr (SPD) p = pt;
+            else {
+                const float4 wv = w[i];
+                p = (double)Vec<T>::round(wv.x) * da[0][0] + (double)Vec<T>::round(wv.y) * da[0][1] + (double)Vec<T>::round(wv.z) * da[0][2] + (double)Vec<T>::round(wv.w) * da[0][3];
+            }
         }
     } else {
         sh[r][g][e] = acc;
+        if constexpr (SPD) shd[r][g][e][0] = pt;
+        else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) shd[r][g][e][q] = da[q];
+            for (int q = 0; q < 4; ++q) shd[r][g][e][q] = da[0][q];
+        }
         __syncthreads();
         if (g != 0) return;                                   // group 0 of every segment finishes (its 32 element lanes = one half wave)
         if (valid) {
             float4 t = sh[r][0][e];
-            double d[4] = {shd[r][0][e][0], shd[r][0][e][1], shd[r][0][e][2], shd[r][0][e][3]};
+            double d[SPD ? 1 : 4];
+#pragma unroll
+            for (int q = 0; q < (SPD ? 1 : 4); ++q) d[q] = shd[r][0][e][q];
 #pragma unroll
             for (int gg = 1; gg < G; ++gg) {
                 t.x += sh[r][gg][e].x; t.y += sh[r][gg][e].y; t.z += sh[r][gg][e].z; t.w += sh[r][gg][e].w;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) d[q] += shd[r][gg][e][q];
+                for (int q = 0; q < (SPD ? 1 : 4); ++q) d[q] += shd[r][gg][e][q];
             }
             dw[i] = t;
-            const float4 wv = w[i];
-            p = (double)Vec<T>::round(wv.x) * d[0] + (double)Vec<T>::round(wv.y) * d[1] + (double)Vec<T>::round(wv.z) * d[2] + (double)Vec<T>::round(wv.w) * d[3];
+            if constexpr (SPD) p = d[0];
+            else {
+                const float4 wv = w[i];
+                p = (double)Vec<T>::round(wv.x) * d[0] + (double)Vec<T>::round(wv.y) * d[1] + (double)Vec<T>::round(wv.z) * d[2] + (double)Vec<T>::round(wv.w) * d[3];
+            }
         }
     }
     // lw is a power of two <= 32 and a row's lanes are lw consecutive lanes of one 32-lane half wave: the butterfly stays inside them
@@ -855,7 +906,8 @@ static DotGeom dot_geometry(int taps, int cin, int cout) {
 }
 
 template <typename T>
-static int launch_wgrad_fold_dot(const float* slab, int nsplit, int cin, int cout, float* dw, const float* w, double* rows, hipStream_t s) {
+static int launch_wgrad_fold_dot(const float* slab, int nsplit, int cin, int cout, float* dw, const float* w, double* rows, hipStream_t s,
+                                 const void* w_phase = nullptr, int xcd_map = 0) {
     const long long count = 9LL * cin * cout;
     if (cout % 4 || ((uintptr_t)slab & 15) || ((uintptr_t)dw & 15) || ((uintptr_t)w & 15)) return RVIP_EINVAL;
     const DotGeom g = dot_geometry(9, cin, cout);
@@ -863,7 +915,12 @@ static int launch_wgrad_fold_dot(const float* slab, int nsplit, int cin, int cou
     const float4* sl = reinterpret_cast<const float4*>(slab);
     const float4* w4 = reinterpret_cast<const float4*>(w);
     float4* out = reinterpret_cast<float4*>(dw);
-#define RVIP_FOLD_DOT(G_, R_) hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, G_, 8, R_>), dim3((unsigned)cdiv(nseg, R_)), dim3(32 * G_ * R_), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, nseg, rows)
+#define RVIP_FOLD_DOT(G_, R_) do { \
+        if constexpr (sizeof(T) == 2) { \
+            if (w_phase) { hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, G_, 8, R_, 1>), dim3((unsigned)cdiv(nseg, R_)), dim3(32 * G_ * R_), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, nseg, rows, (const T*)w_phase, xcd_map); break; } \
+        } \
+        hipLaunchKernelGGL((wgrad_fold_dot_kernel<T, G_, 8, R_>), dim3((unsigned)cdiv(nseg, R_)), dim3(32 * G_ * R_), 0, s, sl, nsplit, count / 4, out, w4, g.cout4, cin, g.nrow, g.lw, g.nchunk, nseg, rows, (const T*)nullptr, 0); \
+    } while (0)
     switch (fold_groups(nsplit)) {
         case 1: RVIP_FOLD_DOT(1, 8); break;
         case 2: RVIP_FOLD_DOT(2, 4); break;
@@ -997,6 +1054,7 @@ static int launch_wgrad(const WgArgs& a, hipStream_t s) {
 using namespace rvip;
 
 extern "C" int rvip_conv3x3_wgrad_dot_rows(const rvip_wgrad3x3_desc* d);
+extern "C" int rvip_conv3x3_wgrad_form(const rvip_wgrad3x3_desc* d);
 extern "C" size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout) {
     int tw, tx, ty, nt, ns;
     wgrad_geometry(n, h, w, cin, cout, tw, tx, ty, nt, ns);
@@ -1024,6 +1082,8 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     int rc = RVIP_OK;
     const int depth = d->depth > 0 ? d->depth : 1, kd = d->kd > 0 ? d->kd : 1;
     if ((kd != 1 && kd != 3) || d->n % depth) return RVIP_EINVAL;
+    if (d->w_phase && !d->dot_rows) return RVIP_EINVAL;
+    if (d->w_phase && (d->dtype == RVIP_F32 || rvip_conv3x3_wgrad_form(d) != 1)) return RVIP_EUNSUPPORTED;
     if (d->dot_rows) {
         if (!d->w_master || d->defer_fold) return RVIP_EINVAL;
         if (d->dot_rows_bytes < (size_t)rvip_conv3x3_wgrad_dot_rows(d) * (d->c0 + d->c1) * sizeof(double) || ((uintptr_t)d->dot_rows & 7)) return RVIP_EWORKSPACE;
@@ -1072,7 +1132,8 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
                 const int rpp = 9 * dot_geometry(9, a.cin, a.cout).nchunk;            // rows per depth-tap pass
                 rc = by_dtype(d->dtype, [&](auto t) {
                     return launch_wgrad_fold_dot<decltype(t)>(a.slab, b.nsplit, a.cin, a.cout, d->dw + (size_t)kdi * count2,
-                                                              d->w_master + (size_t)kdi * count2, d->dot_rows + (size_t)kdi * rpp * a.cin, s);
+                                                              d->w_master + (size_t)kdi * count2, d->dot_rows + (size_t)kdi * rpp * a.cin, s,
+                                                              d->w_phase, (b.sp == 1 && b.nsplit % 32 == 0) ? 1 : 0);
                 });
             } else rc = launch_wgrad_fold(a.slab, b.nsplit, count2, d->dw + (size_t)kdi * count2, s);
             if (rc) return rc;

@@ -713,14 +713,21 @@ class Engine(InputRing):
         # 'auto' (default) picks per layer whichever of the two consistent forms is cheaper (measured, round 4: the nine-tap data gradient
         # costs +7 .. +20 us per layer, the reduction pass of the stage in front +8 .. +25 us, in opposite order of map size): 'ninetap'
         # for the HBM-bound full-resolution layer (c0 * cout <= 64 * 32), 'exact' for the others.
+        # 'phase' (round 4, where the layer's weight gradient runs in the four-phase sub-pixel form): <W, dW> is formed against the PHASE
+        # kernels from the phase-resolved slabs (rvip_wgrad3x3_desc.w_phase) -- consistent with the sub-pixel data gradient by construction,
+        # at no cost: the stage in front keeps the algebraic route.  'auto' = 'phase' where it exists, else the cheaper of the other two.
         sp_consumer = os.environ.get('RVIP_BNBWD_SUBPIX_CONSUMER', 'auto')
-        if sp_consumer not in ('auto', 'exact', 'ninetap', 'algebraic'):
+        if sp_consumer not in ('auto', 'phase', 'exact', 'ninetap', 'algebraic'):
             raise ValueError('RVIP_BNBWD_SUBPIX_CONSUMER=%r' % sp_consumer)
 
         def sp_mode(st):
-            if sp_consumer != 'auto':
-                return sp_consumer
-            return 'ninetap' if st.c0 * st.cout <= 64 * 32 else 'exact'
+            if sp_consumer in ('auto', 'phase'):
+                if dt != N.F32 and st.conv in wg_desc and L.rvip_conv3x3_wgrad_form(C.byref(wg_desc[st.conv])) == 1:
+                    return 'phase'
+                if sp_consumer == 'phase':
+                    return 'exact'
+                return 'ninetap' if st.c0 * st.cout <= 64 * 32 else 'exact'
+            return sp_consumer
         self.sp_modes = {}
         wg_desc, dg_desc = {}, {}
         for st in plan.stages:
@@ -734,6 +741,7 @@ class Engine(InputRing):
             wg.n, wg.h, wg.w, wg.cout, wg.dtype = n, st.h, st.w, st.cout, dt
             wg.depth, wg.kd = self.depth, self.kd
             wg.workspace, wg.workspace_bytes = self.ws_wg.data_ptr(), self.ws_wg_bytes
+            wg_desc[st.conv] = wg
             dg = N.Conv3x3Desc()
             dg.x0, dg.c0, dg.up0, dg.x1, dg.c1 = dz.data_ptr(), st.cout, 0, None, 0
             dg.w_packed, dg.bias = P.packed[st.conv][1].data_ptr(), None
@@ -811,6 +819,8 @@ class Engine(InputRing):
                     dbuf = torch.zeros(nd * c.cin, dtype=torch.float64, device=self.ws.device)
                     dot_rows[c.conv] = (dbuf, nd)
                     wg.w_master, wg.dot_rows, wg.dot_rows_bytes = P.p(c.conv, 'kernel').value, dbuf.data_ptr(), dbuf.numel() * 8
+                    if dg.subpix == 2 and self.sp_modes.get(c.conv) == 'phase':
+                        wg.w_phase = P.subpix_d[c.conv].data_ptr()
                 if p.drop and p.drop[1] > 0:          # Dropout backward rides in the consumer's data-gradient epilogue: the forward
                     kb = torch.zeros(-(-p.cout // 32) * n * p.h * p.w, dtype=torch.int32, device=self.ws.device)      # pass leaves its keep bits
                     self.keep_bits[p.conv] = kb

@@ -203,6 +203,14 @@ typedef struct rvip_wgrad3x3_desc {
      * channel i of X, without a pass over g and y (rvip_bn_bwd_coef). */
     const float* w_master;            /* [taps][C0+C1][Cout] fp32, the layer's HWIO kernel */
     double*      dot_rows; size_t dot_rows_bytes;     /* double: the sum cancels heavily when the gradient is mostly common-mode */
+    /* ABI 7 -- w_phase != NULL (with dot_rows, UpSampling2D -> conv layers whose rvip_conv3x3_wgrad_form() is 1): the layer's DATA gradient
+     * runs in sub-pixel form (rvip_conv3x3_desc.subpix = 2), i.e. it multiplies with the phase kernels of
+     * rvip_pack_subpixel_dgrad_weights -- sums of two / four taps rounded ONCE to `dtype`, not the rounded taps themselves.  The rows
+     * are then dotted against THOSE kernels, phase by phase (the four-phase form's slabs still hold the phase-resolved gradients:
+     * dw[kh][kw] of a phase's slab is that phase's summed-tap block):  T2'[i] = sum_{phase, u, v, o} w_phase[phase][u][v][i][o] *
+     * dW_phase[phase][u][v][i][o] = sum_pixels X[., i] * dX'[., i]  for the dX' the sub-pixel data gradient really writes, so that
+     * T2' and the column sums of dX' describe the same gradient (rvip_bn_bwd_coef).  RVIP_EUNSUPPORTED for every other form. */
+    const void*  w_phase;             /* [4][4][C0][Cout] in `dtype` */
 } rvip_wgrad3x3_desc;
 
 size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout);

@@ -351,6 +351,42 @@ def test_real_shape_upconv_subpixel_backward(idx, dtype):
     wr = k['wt'].astype(np.float64)                                               # on the grid: exact in every storage type
     t2 = (wr * gotw).sum((0, 1, 3))
     assert np.abs(drows.cpu().numpy().sum(0) - t2).max() <= 2e-6 * (np.abs(wr) * np.abs(gotw)).sum((0, 1, 3)).max()
+    # ---- the same rows against the PHASE kernels (round 4, four-phase form only): T2' = sum_pixels X * dX' for the dX' the sub-pixel data
+    # gradient above really wrote -- where <Wr, dW> describes the nine-tap gradient, whose phase kernels are summed taps rounded once
+    g.w_phase = wph.data_ptr()
+    if form != 1:
+        assert L.rvip_conv3x3_wgrad(C.byref(g), stream()) == -2                   # only the four-phase slabs hold phase-resolved gradients
+        return
+    drows2 = torch.full((nd, c0), 7.0, dtype=torch.float64, device=dev())
+    dw_b = torch.full((3, 3, c0, co), 7.0, dtype=torch.float32, device=dev())
+    g.dw, g.dot_rows = dw_b.data_ptr(), drows2.data_ptr()
+    N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dw_b, dw)                                                  # dw itself is untouched by the choice of rows
+    t2p = drows2.cpu().numpy().sum(0)
+    # float64 restatement with the device's own phase kernels and slabs' content: the phase-resolved weight gradients from the oracle's
+    # per-phase correlation, dotted with the phase kernels as the device rounded them
+    wph_h = down(wph).astype(np.float64).reshape(4, 4, c0, co)                    # [phase][2u+v (data-gradient convention)][ci][co]
+    x64, dy64 = k['x0'].astype(np.float64), k['dy'].astype(np.float64)
+    xp = np.pad(x64, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    want = np.zeros(c0)
+    for a_ in range(2):
+        for b_ in range(2):
+            dyp = dy64[:, a_::2, b_::2, :]                                        # phase image of the gradient, on the low-resolution grid
+            for uf in range(2):
+                for vf in range(2):
+                    # forward convention: phase 0 reads low-res offsets (-1, 0), phase 1 reads (0, +1), per axis
+                    oy, ox = (uf - 1 if a_ == 0 else uf), (vf - 1 if b_ == 0 else vf)
+                    xs = xp[:, 1 + oy:1 + oy + h // 2, 1 + ox:1 + ox + h // 2, :]
+                    dwp = np.einsum('nhwi,nhwo->io', xs, dyp)
+                    want += (wph_h[2 * a_ + b_, 2 * (1 - uf) + (1 - vf)] * dwp).sum(1)
+    scale2 = np.abs(want).max()
+    assert np.abs(t2p - want).max() <= 3e-5 * max(scale2, (np.abs(wr) * np.abs(gotw)).sum((0, 1, 3)).max()), (name, np.abs(t2p - want).max(), scale2)
+    # ... which IS sum_pixels X * dX' of the gradient the sub-pixel launch wrote (up to ITS storage rounding, zero-mean per element)
+    ident = (x64 * got).sum((0, 1, 2))
+    bound = {'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}[dtype] * np.sqrt(((x64 * got) ** 2).sum((0, 1, 2))).max() * 4 + 1e-9
+    assert np.abs(t2p - ident).max() <= bound + 3e-5 * scale2, (name, np.abs(t2p - ident).max(), bound)
+    print('%s %s: |T2 (taps) - T2\' (phase kernels)| / |T2| = %.2e' % (name, dtype, np.abs(t2 - t2p).max() / np.abs(t2).max()))
 
 
 @functools.lru_cache(maxsize=1)
