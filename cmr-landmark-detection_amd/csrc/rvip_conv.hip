@@ -1582,11 +1582,21 @@ __global__ __launch_bounds__(256) void conv3x3_c1_tiled(const T* __restrict__ x,
 #pragma unroll
             for (int t = 0; t < 9; ++t) xin[t] = xs[(py + t / 3) * 34 + px + t % 3];
             float v[VE];
+            // two channels per instruction (v_pk_fma_f32): the pass is VALU-bound -- 72 scalar FMAs per 16 bytes stored were most of it.
+            // Per output the nine multiply-adds run in the same order as before: same bits.
+            rvip_f32x2 acc2[VE / 2];
+#pragma unroll
+            for (int e2 = 0; e2 < VE / 2; ++e2) acc2[e2] = rvip_f32x2{br[2 * e2], br[2 * e2 + 1]};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const rvip_f32x2 x2 = {xin[t], xin[t]};
+#pragma unroll
+                for (int e2 = 0; e2 < VE / 2; ++e2)
+                    acc2[e2] = __builtin_elementwise_fma(x2, rvip_f32x2{wr[t][2 * e2], wr[t][2 * e2 + 1]}, acc2[e2]);
+            }
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
-                float acc = br[e];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc = fmaf(xin[t], wr[t][e], acc);
+                const float acc = acc2[e >> 1][e & 1];
                 v[e] = act_fwd(acc, ACT < 0 ? act : ACT);
                 if constexpr (STATS) {
                     const float q = Vec<T>::round(v[e]);          // statistics of what is stored

@@ -1323,11 +1323,16 @@ __global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, c
             if (gy >= h || gx >= w) continue;
             float g[VE];
             Vec<T>::load(dy + ((((size_t)img * h + gy) * w + gx) * cout + cv * VE) * sizeof(T), g);
+            // two channels per instruction (v_pk_fma_f32; the pass is VALU-bound); every sum keeps its order
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float xv = xs[(py + t / 3) * 34 + px + t % 3];
+                const rvip_f32x2 x2 = {xv, xv};
 #pragma unroll
-                for (int e = 0; e < VE; ++e) part[t][e] = fmaf(xv, g[e], part[t][e]);
+                for (int e2 = 0; e2 < VE / 2; ++e2) {
+                    const rvip_f32x2 r2 = __builtin_elementwise_fma(x2, rvip_f32x2{g[2 * e2], g[2 * e2 + 1]}, rvip_f32x2{part[t][2 * e2], part[t][2 * e2 + 1]});
+                    part[t][2 * e2] = r2.x; part[t][2 * e2 + 1] = r2.y;
+                }
             }
         }
     }
