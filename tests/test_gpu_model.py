@@ -806,6 +806,50 @@ def test_capture_survives_garbage_models_and_collections(monkeypatch):
     assert np.isfinite(b.train_on_batch(x, y)[0])           # ... and the model rebuilds its device state from the weights it kept
 
 
+def test_fit_under_garbage_collection_pressure():
+    """The conditions of GPUTEST_r03's abort, made as hostile as they get: models that die inside USER-made reference cycles (graphs and
+    all), a thread that churns cyclic garbage so that the collector runs all the time on whatever thread allocates, generator pool threads,
+    and one fit() after the other each capturing its step.  With an unguarded capture some collection lands inside a capture window
+    sooner or later and the process aborts (tools/repro_graph_gc_abort.py); with Engine.capture's guard nothing can."""
+    import gc
+    import threading
+    cfg = _cfg(RVIP_PRECISION='bf16', DIM=[32, 32], FILTERS=8, LEARNING_RATE=1e-3)
+    gcfg = dict(DIM=[32, 32], BATCHSIZE=4, GAUS=True, SIGMA=2, SHUFFLE=True, SEED=3)
+    stop = threading.Event()
+    collections = [0]
+
+    def churn():
+        class Node:
+            pass
+        while not stop.is_set():
+            for _ in range(2000):
+                a_, b_ = Node(), Node()
+                a_.o, b_.o = b_, a_                     # a cycle: only the collector frees it
+            collections[0] = sum(st['collections'] for st in gc.get_stats())
+    th = threading.Thread(target=churn, daemon=True)
+    old_thr = gc.get_threshold()
+    gc.set_threshold(200, 3, 3)                         # every generation collects often
+    th.start()
+    try:
+        before = sum(st['collections'] for st in gc.get_stats())
+        for i in range(3):
+            gen = rvip.Generators.SyntheticSAXGenerator(16, dict(gcfg, SEED=3 + i), in_memory=False)
+            model = rvip.get_model(cfg, metrics=[])
+            hist = model.fit(x=gen, epochs=2, verbose=0, max_queue_size=2, workers=2)
+            assert np.isfinite(hist.history['loss']).all()
+            assert model._engine(4).launch_mode == 'hipGraph'
+            model._user_cycle = model                   # dies in the collector, whenever that runs, with its graphs
+            del model
+        after = sum(st['collections'] for st in gc.get_stats())
+        assert after - before > 30, 'the collector was meant to be busy during this test'
+    finally:
+        stop.set()
+        th.join(10)
+        gc.set_threshold(*old_thr)
+    gc.collect()
+    torch.cuda.synchronize()
+
+
 def test_fit_with_generator_and_callbacks(tmp_path):
     cfg = _cfg(RVIP_PRECISION='bf16', DIM=[64, 64], FILTERS=8, LEARNING_RATE=2e-3, MODEL_PATH=str(tmp_path),
                DROPOUT_MIN=0.0, DROPOUT_MAX=0.0)
