@@ -2146,7 +2146,9 @@ extern "C" int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* b
 
 static int c1_tiled_blocks(int n, int h, int w_) {
     const long long nt = (long long)n * cdiv(w_, 32) * cdiv(h, 8);
-    return (int)(nt < 2048 ? nt : 2048);
+    // 1 024 workgroups (four per CU): the statistics fold behind the launch reads one partial row per workgroup, and at 2 048 that
+    // single-workgroup fold was a chain of 32 round trips (conv 43.2 + fold 8.0 us against 41.5 + 5.3; 512: 47.7 + 3.9, 256: 67 + 4)
+    return (int)(nt < 1024 ? nt : 1024);
 }
 
 // rows of partial statistics rvip_conv3x3_c1_fwd_stats writes (0 = the shape runs on the untiled kernel: use rvip_bn_train_stats)
