@@ -1107,7 +1107,12 @@ class Engine(InputRing):
             self._graphs, self.launch_mode = None, 'eager (capture failed)'
             return False
         torch.cuda.synchronize()
-        self._graphs, self.launch_mode = graphs, 'hipGraph' if len(graphs) == 1 else 'hipGraph x%d + RCCL between' % len(graphs)
+        coll = 'RCCL'
+        if len(graphs) > 1 and _dist_ready():
+            import torch.distributed as dist
+            be = str(dist.get_backend())
+            coll = 'RCCL' if be == 'nccl' else be          # ('gloo': the one-GPU rehearsals of the N > 1 path)
+        self._graphs, self.launch_mode = graphs, 'hipGraph' if len(graphs) == 1 else 'hipGraph x%d + %s between' % (len(graphs), coll)
         return True
 
     def release(self):
