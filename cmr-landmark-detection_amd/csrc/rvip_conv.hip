@@ -870,6 +870,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
 
     if (wv >= NCW) {
         // ------------------------------------------------ loader waves ------------------------------------------------
+        __builtin_amdgcn_s_setprio(3);                       // their few instructions go ahead of the compute waves' streams
         const int lwv = wv - NCW;
         const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
         const i32x4 rs0 = make_rsrc(a.x0, a.x0_bytes);

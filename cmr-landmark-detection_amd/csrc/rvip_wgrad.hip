@@ -533,6 +533,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     };
 
     if (loader) {
+        __builtin_amdgcn_s_setprio(3);                       // the loaders' few instructions go ahead of the compute waves' streams
         if (split < a.ntiles) issue(split, 0);
         if constexpr (NST == 3) { if (split + nsplit < a.ntiles) issue(split + nsplit, 1); }
         // DMA instructions this wave issues per tile (the pieces are dealt round-robin to the four loader waves)
