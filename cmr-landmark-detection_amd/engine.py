@@ -239,7 +239,7 @@ class InputRing:
     hooks, feed, reset_input_ring) belongs to the training thread.  Slot protocol: item i uses slot i % slots; feeding item k hands
     back every slot up to item k - 2 (their uploads were queued two steps ago) and newer ones whose upload happens to be complete.
     With a queue of `depth` items between the threads the generator thread can be at most depth + 2 items ahead of the last feed, so
-    slots >= depth + 4 never deadlocks (tests/test_host_cpu.py drives exactly that worst case)."""
+    slots >= depth + 4 never deadlocks (tests/test_fit_pipeline_cpu.py drives exactly that worst case)."""
 
     pin_x = None
 
