@@ -851,7 +851,10 @@ class Engine(InputRing):
 
         for si, st in reversed(list(enumerate(plan.stages))):
             if si == n_enc - 1:
-                flush_folds()                  # bucket 0 (head, decoder, bottleneck) is complete here
+                if self.dp or os.environ.get('RVIP_FOLD_BUCKETS') == '2':
+                    flush_folds()              # bucket 0 (head, decoder, bottleneck) is complete here: its all-reduce starts behind it
+                # (one process: nobody reads the gradients before the optimiser -- every deferred fold waits for the final flush,
+                #  two launches instead of four)
                 self.bwd_split = len(bwd)
             rows = n * st.h * st.w
             first = st.src0 == 'input_1'
