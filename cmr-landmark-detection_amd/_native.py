@@ -137,6 +137,7 @@ SIGNATURES = {
     'rvip_conv3x3_c1_fwd_stats_rows': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'rvip_conv3x3_c1_fwd_stats': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'rvip_conv3x3_c1_wgrad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    'rvip_conv3x3_c1_wgrad_rows': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'rvip_conv3d_c1_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rvip_conv3d_c1_wgrad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     'rvip_conv3x3_cn_fwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

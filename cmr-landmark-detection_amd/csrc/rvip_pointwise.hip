@@ -2300,13 +2300,24 @@ extern "C" int rvip_head_bwd(const void* x, const float* w, const float* dlogit,
     return launch_fold_k<PostHeadBwd>(ws, g.nblk, cin, 2 * RVIP_MAXK, p, s);
 }
 
+// rows the first-layer weight gradient leaves in its workspace: [rows][9][cout] (the fold rvip_conv3x3_c1_wgrad runs behind its kernel,
+// or -- dw == NULL -- leaves to the caller: one entry {nrows = rows, width = 9 * cout} of rvip_fold_rows_batch(..., wide = 0))
+extern "C" int rvip_conv3x3_c1_wgrad_rows(int n, int h, int w_, int cout, int dtype) {
+    RedGeom g;
+    if (!RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w_ <= 0 || !red_geom((long long)n * h * w_, cout, RVIP_VE(dtype), g)) return 0;
+    if (256 % g.cg == 0) {
+        const long long nt = (long long)n * cdiv(w_, 32) * cdiv(h, 8);
+        return (int)(nt < 1024 ? nt : 1024);
+    }
+    return g.nblk;
+}
+
 extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cout, int dtype,
                                      void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
-    if (!x || !dy || !dw || !workspace || !RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w_ <= 0) return RVIP_EINVAL;
+    if (!x || !dy || !workspace || !RVIP_DT_OK(dtype) || n <= 0 || h <= 0 || w_ <= 0) return RVIP_EINVAL;
     RedGeom g;
     if (!red_geom((long long)n * h * w_, cout, RVIP_VE(dtype), g)) return RVIP_EINVAL;
-    if (workspace_bytes < (size_t)g.nblk * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
     if (256 % g.cg == 0) {
@@ -2318,15 +2329,16 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
         else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_tiled<f16_t>, dim3(nb), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, 1, 0);
         else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, 1, 0);
         int rc2 = check_launch();
-        if (rc2) return rc2;
+        if (rc2 || !dw) return rc2;                            // dw == NULL: the rows stay for the caller's batched fold
         PostC1Wgrad p2{dw, cout, cout};
         return launch_fold_k<PostC1Wgrad>(ws, nb, cout, 9, p2, s);
     }
+    if (workspace_bytes < (size_t)g.nblk * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
     if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_kernel<bf16_t>, dim3(g.nblk), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_kernel<f16_t>, dim3(g.nblk), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     else hipLaunchKernelGGL(c1_wgrad_kernel<float>, dim3(g.nblk), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, g, ws);
     int rc = check_launch();
-    if (rc) return rc;
+    if (rc || !dw) return rc;
     PostC1Wgrad p{dw, cout, cout};
     return launch_fold_k<PostC1Wgrad>(ws, g.nblk, cout, 9, p, s);
 }

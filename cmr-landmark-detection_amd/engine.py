@@ -970,8 +970,16 @@ class Engine(InputRing):
                                                       self.cimg, st.cout, dt, _ptr(self.ws_wg), C.c_size_t(self.ws_wg_bytes))))
                 continue
             if first:
-                bwd.append((L.rvip_conv3x3_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, st.h, st.w,
-                                                      st.cout, dt, _ptr(self.ws_wg), C.c_size_t(self.ws_wg_bytes))))
+                nr1 = L.rvip_conv3x3_c1_wgrad_rows(n, st.h, st.w, st.cout, dt) if (defer and os.environ.get('RVIP_C1_FOLD_BATCHED', '1') != '0') else 0
+                if nr1 > 0:       # its partial rows join the step's batched fold of narrow rows (one launch fewer, and a 1 024-row fold off the end of the step)
+                    rb1 = torch.empty(nr1 * 9 * st.cout, dtype=torch.float32, device=self.ws.device)
+                    self._fold_bufs.append(rb1)
+                    bwd.append((L.rvip_conv3x3_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), None, n, st.h, st.w,
+                                                          st.cout, dt, _ptr(rb1), C.c_size_t(rb1.numel() * 4))))
+                    narrow.append((rb1, P.g(st.conv, 'kernel'), nr1, 9 * st.cout))
+                else:
+                    bwd.append((L.rvip_conv3x3_c1_wgrad, (_ptr(self.act['input_1']), _ptr(dz), P.g(st.conv, 'kernel'), n, st.h, st.w,
+                                                          st.cout, dt, _ptr(self.ws_wg), C.c_size_t(self.ws_wg_bytes))))
                 continue
             wg, dg = wg_desc[st.conv], dg_desc[st.conv]
             if defer and st.conv not in dot_rows:   # (a layer whose kernel gradient feeds rvip_bn_bwd_coef is folded at once, with the dot rows)

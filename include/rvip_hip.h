@@ -243,6 +243,10 @@ int rvip_conv3x3_c1_fwd_stats(const void* x, const float* w, const float* bias, 
                               int act, int dtype, float* stats_ws, size_t stats_ws_bytes, void* stream);
 int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w_, int cout,
                           int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* ABI 7: dw == NULL leaves the fold to the caller -- the rvip_conv3x3_c1_wgrad_rows() partial rows [rows][9][cout] stay in `workspace`
+ * (which must then be private to the layer until they are folded), e.g. as one entry {nrows = rows, width = 9 * cout} of
+ * rvip_fold_rows_batch(..., wide = 0) together with the step's other deferred folds. */
+int rvip_conv3x3_c1_wgrad_rows(int n, int h, int w_, int cout, int dtype);
 /* The same first layer of the 3-D graph: Conv3D(3x3x3, 'same') with Cin = 1 on n = N*depth slices (volumes of `depth`
  * consecutive slices), weights fp32 DHWIO [27][1][Cout]; wgrad writes dw[27][Cout].  Cout/VE must divide 256. */
 int rvip_conv3d_c1_fwd(const void* x, const float* w, const float* bias, void* y,

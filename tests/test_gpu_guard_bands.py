@@ -186,6 +186,19 @@ def test_first_layer_kernels_stay_inside_their_tensors(shape, dtype):
     dw = Fenced((3, 3, 1, co), torch.float32, 3.0)
     N.call('rvip_conv3x3_c1_wgrad', P(x), P(dy), P(dw.t), n, h, w, co, ndt(dtype), P(ws.t), C.c_size_t(wsb), stream())
     _fences_ok(dw=dw, workspace=ws)
+    # rows-only form (dw = NULL): exactly rvip_conv3x3_c1_wgrad_rows() rows of 9 * cout floats in a private region, folded by the batch fold
+    nr = L.rvip_conv3x3_c1_wgrad_rows(n, h, w, co, ndt(dtype))
+    assert nr > 0
+    rows = Fenced((nr * 9 * co,), torch.float32, 3.0)
+    dw2 = Fenced((3, 3, 1, co), torch.float32, 3.0)
+    N.call('rvip_conv3x3_c1_wgrad', P(x), P(dy), None, n, h, w, co, ndt(dtype), P(rows.t), C.c_size_t(rows.n * 4), stream())
+    assert L.rvip_conv3x3_c1_wgrad(P(x), P(dy), None, n, h, w, co, ndt(dtype), P(rows.t), C.c_size_t(rows.n * 4 - 4), stream()) == -3
+    tab = (N.FoldEntry * 1)()
+    tab[0].src, tab[0].dst, tab[0].nrows, tab[0].stride, tab[0].width = rows.t.data_ptr(), dw2.t.data_ptr(), nr, 0, 9 * co
+    tabd = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev())
+    N.call('rvip_fold_rows_batch', P(tabd), 1, C.c_longlong(9 * co), 0, stream())
+    _fences_ok(rows=rows, dw_batched=dw2)
+    np.testing.assert_allclose(dw2.t.cpu().numpy(), dw.t.cpu().numpy(), rtol=2e-6, atol=2e-6 * float(dw.t.abs().max()))
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'f16'])
