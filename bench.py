@@ -365,8 +365,8 @@ def main():
 
 def cpu_baseline(cfg, batch):
     """The same step on the host cores: PyTorch-CPU (oneDNN) fp32 port in oracle/torch_ref.py -- the stand-in for the
-    reference's TF2-CPU path, which cannot be imported here.  Bounded sample: `batch` slices per step, 1 warm-up + 2
-    timed steps (about 10-30 s)."""
+    reference's TF2-CPU path, which cannot be imported here.  Bounded sample: `batch` slices per step, 1 warm-up + 8
+    timed steps (about 12 s at config 2 on 16 cores)."""
     import torch
     from oracle import torch_ref
     cores = len(os.sched_getaffinity(0))
@@ -378,10 +378,11 @@ def cpu_baseline(cfg, batch):
         pass
     cores = min(cores, int(os.environ.get('RVIP_CPU_BASELINE_THREADS', 16)))
     cpu_cfg = {k: v for k, v in cfg.items() if k not in ('LOSS_FUNCTION', 'RVIP_PRECISION')}
-    sec = torch_ref.time_train_steps(cpu_cfg, batch, steps=2, warmup=1, threads=cores)
+    nsteps = 8
+    sec = torch_ref.time_train_steps(cpu_cfg, batch, steps=nsteps, warmup=1, threads=cores)
     return {'value': round(batch / sec, 3), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d slices/step x 2 timed steps of the same %dx%d training step, PyTorch-CPU fp32 (stand-in for TF2-CPU)' % (
-                batch, cfg['DIM'][0], cfg['DIM'][1]), 'threads': torch.get_num_threads()}
+            'sample': '%d slices/step x %d timed steps of the same %dx%d training step, PyTorch-CPU fp32 (stand-in for TF2-CPU)' % (
+                batch, nsteps, cfg['DIM'][0], cfg['DIM'][1]), 'threads': torch.get_num_threads()}
 
 
 if __name__ == '__main__':
