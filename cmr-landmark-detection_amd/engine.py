@@ -259,8 +259,12 @@ class InputRing:
         the compute stream (only that last copy is ordered with the step).  Returns the event recorded after the H2D copy."""
         torch = _torch()
         cs, main = self.copy_stream, torch.cuda.current_stream()
+        # The HOST waits until the copies that last read this staging pair have run (two feeds ago: the training thread stays at most
+        # two steps ahead of the device, which it was anyway through _release_slots).  A device-side wait here -- the copy stream
+        # waiting for an event of the compute stream that is still pending when it is queued -- cost 0.10 ms of idle device time at
+        # every step boundary (tools/probe_fit_gap.py: 4.84 -> 4.74 ms per fit step against 4.70 for bare replays).
         if self.ev_free[d] is not None:
-            cs.wait_event(self.ev_free[d])
+            self.ev_free[d].synchronize()
         with torch.cuda.stream(cs):
             self.dev_in[d][0].copy_(self.pin_x[slot], non_blocking=True)
             self.dev_in[d][1].copy_(self.pin_y[slot], non_blocking=True)
