@@ -85,9 +85,11 @@ def main():
     ndev = max(torch.cuda.device_count(), 1)
     os.environ['LOCAL_RANK'] = str(local % ndev)                 # the engine picks its device from LOCAL_RANK
     torch.cuda.set_device(local % ndev)
-    if world > 1:
+    one_rank_pg = world == 1 and os.environ.get('RVIP_FORCE_DP_SCHEDULE') == '1'   # rehearsal on one GPU: the data-parallel schedule against a one-rank group
+    if world > 1 or one_rank_pg:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29512')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local % ndev))
         else:
@@ -120,7 +122,7 @@ def main():
     torch.cuda.synchronize()
     launch = eng.launch_mode
     overlap = eng.overlap_ok()
-    if world > 1 and launch.startswith('hipGraph'):
+    if (world > 1 or one_rank_pg) and launch.startswith('hipGraph'):
         launch += ' (two overlapped all-reduce buckets)' if overlap else ' (one all-reduce)'
 
     def barrier():
@@ -341,7 +343,7 @@ def main():
                 args.depth, '3D cine (Conv3D 3x3x3, pool 1x2x2)' if args.frames > 0 else '2D', args.filters,
                 ('%dx%dx%d' % (args.frames, args.dim, args.dim)) if args.frames > 0 else '%dx%d' % (args.dim, args.dim), B,
                 'MSE' if args.loss == 'mse' else 'BCE-Dice',
-                (' + %s grad all-reduce' % ('RCCL' if backend == 'nccl' else backend)) if world > 1 else ''),
+                (' + %s grad all-reduce%s' % ('RCCL' if backend == 'nccl' else backend, ' (ONE-rank group: schedule rehearsal)' if one_rank_pg else '')) if (world > 1 or one_rank_pg) else ''),
                 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch, 'collective': ('%s all-reduce of %d fp32 gradients' % (backend, model._params.count)) if world > 1 else None,
                 'gflop_per_slice_fwd_bwd': round(step_flops / 1e9, 3)},
             'fit_slices_per_s': fit_rate, 'fit': fit_info, 'predict_slices_per_s_eager': predict_rate, 'hbm_allocated_gib': hbm_gb,
@@ -355,7 +357,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_batch)
-    if world > 1:
+    if world > 1 or one_rank_pg:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
