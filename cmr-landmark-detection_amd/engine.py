@@ -335,6 +335,18 @@ class InputRing:
         self._release_slots(keep=2)
 
 
+class EvalRing(InputRing):
+    """A second input ring in front of the SAME engine's staging buffers, for Model.evaluate(): validation runs on the training thread
+    between two epochs of fit(), while fit()'s stager thread may already hold batches of the next epoch in the engine's own ring.
+    Used from one thread (stage, feed, forward, next batch): four slots are enough -- feeding batch k hands back slot k - 2."""
+
+    SLOTS = 4
+
+    def __init__(self, eng):
+        self.x_stage, self.y_true, self.P = eng.x_stage, eng.y_true, eng.P
+        self.alloc_input_ring(self.SLOTS)
+
+
 class Engine(InputRing):
     """Activation/gradient buffers and pre-built launch lists for ONE (batch size, loss) configuration."""
 
