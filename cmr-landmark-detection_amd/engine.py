@@ -266,13 +266,16 @@ class InputRing:
         if self.ev_free[d] is not None:
             self.ev_free[d].synchronize()
         with torch.cuda.stream(cs):
+            has_y = self.slot_has_y[slot]
             self.dev_in[d][0].copy_(self.pin_x[slot], non_blocking=True)
-            self.dev_in[d][1].copy_(self.pin_y[slot], non_blocking=True)
+            if has_y:
+                self.dev_in[d][1].copy_(self.pin_y[slot], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(cs)
         main.wait_event(ev)
         self.x_stage.copy_(self.dev_in[d][0], non_blocking=True)
-        self.y_true.copy_(self.dev_in[d][1], non_blocking=True)
+        if has_y:
+            self.y_true.copy_(self.dev_in[d][1], non_blocking=True)
         evf = torch.cuda.Event()
         evf.record(main)
         self.ev_free[d] = evf
@@ -284,6 +287,7 @@ class InputRing:
             return
         self._ring_alloc(slots)
         self.slot_free = [threading.Event() for _ in range(slots)]     # set: the generator thread may overwrite the pinned slot
+        self.slot_has_y = [True] * slots
         self._uploads = deque()
         self.reset_input_ring()
 
@@ -317,7 +321,9 @@ class InputRing:
                 return False
         flag.clear()
         np.copyto(self.pin_x_np[slot], np.asarray(x, np.float32).reshape(self.pin_x_np[slot].shape))
-        np.copyto(self.pin_y_np[slot], np.asarray(y, np.float32).reshape(self.pin_y_np[slot].shape))
+        if y is not None:
+            np.copyto(self.pin_y_np[slot], np.asarray(y, np.float32).reshape(self.pin_y_np[slot].shape))
+        self.slot_has_y[slot] = y is not None              # (predict: inputs only)
         return True
 
     def _release_slots(self, keep):
@@ -345,6 +351,40 @@ class EvalRing(InputRing):
     def __init__(self, eng):
         self.x_stage, self.y_true, self.P = eng.x_stage, eng.y_true, eng.P
         self.alloc_input_ring(self.SLOTS)
+        self.out = None
+
+    def download(self, src):
+        """(predict) queue the device-to-host copy of `src` (the engine's heat-maps of the batch just launched) and return a handle
+        for `fetch`.  `src` is first copied into one of two device staging tensors on the compute stream -- the next forward pass may
+        overwrite it at once -- and from there into pinned memory on a stream of its own, next to the input stream."""
+        torch = _torch()
+        if self.out is None:
+            self.out = dict(dev=[torch.empty_like(src) for _ in range(2)],
+                            pin=[torch.empty(src.shape, dtype=src.dtype).pin_memory() for _ in range(2)],
+                            done=[None, None], k=0, stream=torch.cuda.Stream(device=self.P.device))
+            self.out['np'] = [t.numpy() for t in self.out['pin']]
+        o = self.out
+        d = o['k'] & 1
+        o['k'] += 1
+        if o['done'][d] is not None:
+            o['done'][d].synchronize()                     # HOST wait (see _ring_upload): the pair's previous download has left it
+        main = torch.cuda.current_stream()
+        o['dev'][d].copy_(src, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        o['stream'].wait_event(ev)
+        with torch.cuda.stream(o['stream']):
+            o['pin'][d].copy_(o['dev'][d], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(o['stream'])
+        o['done'][d] = done
+        return d, done
+
+    def fetch(self, handle, dst):
+        """wait for a download and copy it out of the pinned buffer into `dst` (a NumPy view of the caller's result)"""
+        d, done = handle
+        done.synchronize()
+        np.copyto(dst, self.out['np'][d].reshape(dst.shape))
 
 
 class Engine(InputRing):

@@ -1162,3 +1162,35 @@ def test_bf16_loss_curve_tracks_the_float64_oracle():
     xt, _ = O.synthetic_batch(2, cfg['DIM'], 2, seed=13)
     diff = np.abs(model.predict(xt) - ref.predict(xt.astype(np.float64)))
     assert diff.max() < 3e-2 and diff.mean() < 3e-3, (diff.mean(), diff.max())
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_pipelined_predict_and_evaluate_equal_the_batch_calls(precision):
+    """Model.predict / Model.evaluate run through pinned rings with the copies of batch k +- 1 under batch k (round 4): the result
+    must be what predict_on_batch / test_on_batch give batch by batch -- ragged last batch, ndarray and Sequence inputs, several
+    calls in a row (the rings are reused), and a training step in between (the staging buffers are shared with fit)."""
+    cfg = _cfg(RVIP_PRECISION=precision, DIM=[32, 32], FILTERS=8, DEPTH=2)
+    model = rvip.get_model(cfg, metrics=[M.dice_coef_labels])
+    x, y = O.synthetic_batch(70, cfg['DIM'], 2, seed=3)
+    model.train_on_batch(x[:16], y[:16])
+    ref = np.concatenate([model.predict_on_batch(x[i:i + 16]) for i in range(0, 70, 16)], 0)
+    for _ in range(2):
+        got = model.predict(x, batch_size=16)
+        assert got.shape == ref.shape and got.dtype == np.float32
+        np.testing.assert_array_equal(got, ref)
+
+    class Seq:
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return x[i * 16:(i + 1) * 16], y[i * 16:(i + 1) * 16]
+    np.testing.assert_array_equal(model.predict(Seq()), ref)
+    want = np.mean([model.test_on_batch(*Seq()[i]) for i in range(5)], 0)
+    for _ in range(2):
+        np.testing.assert_allclose(model.evaluate(Seq()), want, rtol=2e-6, atol=1e-9)
+    model.train_on_batch(x[:16], y[:16])                   # the weights move: the pipelined calls must see the new ones
+    ref2 = np.concatenate([model.predict_on_batch(x[i:i + 16]) for i in range(0, 70, 16)], 0)
+    assert np.abs(ref2 - ref).max() > 0
+    np.testing.assert_array_equal(model.predict(x, batch_size=16), ref2)
+    np.testing.assert_allclose(model.evaluate(x[:64], y[:64]), model.test_on_batch(x[:64], y[:64]), rtol=2e-6, atol=1e-9)

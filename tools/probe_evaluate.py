@@ -2,6 +2,7 @@
 
     python tools/probe_evaluate.py"""
 import importlib
+import numpy as np
 import os
 import sys
 import time
@@ -34,6 +35,20 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     print('evaluate(288 slices)           %.1f ms = %.0f slices/s   %s' % (1e3 * dt, 288 / dt, v), flush=True)
+    xs = np.concatenate([val[i][0] for i in range(len(val))], 0)
+    model.predict(xs, batch_size=32)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        p = model.predict(xs, batch_size=32)
+    dt = (time.perf_counter() - t0) / 3
+    print('predict(288 slices, ndarray)   %.1f ms = %.0f slices/s   out %s' % (1e3 * dt, 288 / dt, p.shape), flush=True)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fl, pts, sz = [], [], []
+        for i in range(0, 288, 32):
+            a_, b_, c_ = model.predict_rvip(xs[i:i + 32])
+    dt = (time.perf_counter() - t0) / 3
+    print('predict_rvip(288 slices)       %.1f ms = %.0f slices/s' % (1e3 * dt, 288 / dt), flush=True)
     t0 = time.perf_counter()
     for _ in range(3):
         for i in range(len(val)):
