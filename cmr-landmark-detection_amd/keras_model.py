@@ -407,6 +407,18 @@ class Model:
         vals = self._batch_logs(eng, kind, w_bce, w_dice).cpu().numpy().tolist()
         return dict(zip(self.metrics_names, vals)) if return_dict else vals
 
+    def _eval_ring(self, eng, batch, used):
+        """evaluate() / predict(): the pinned ring of this batch size, reset at its first use in a call (a call that ended in an
+        exception may have left staged slots behind)"""
+        from .engine import EvalRing
+        ring = self._eval_rings.get(batch)
+        if ring is None or ring.x_stage is not eng.x_stage:
+            ring = self._eval_rings[batch] = EvalRing(eng)
+        if batch not in used:
+            ring.reset_input_ring()
+            used.add(batch)
+        return ring
+
     def predict_on_batch(self, x):
         x = np.asarray(x, np.float32)
         eng = self._engine(x.shape[0])
@@ -419,7 +431,6 @@ class Model:
 
         Pipelined (round 4): inputs through a pinned ring (H2D under the previous batch's forward pass), heat-maps back through two
         pinned buffers on a stream of their own; the host copies batch k - 1 into the result while batch k runs."""
-        from .engine import EvalRing
         if isinstance(x, np.ndarray):
             bs = batch_size or min(32, x.shape[0])
             batches = (x[i:i + bs] for i in range(0, x.shape[0], bs))
@@ -430,7 +441,7 @@ class Model:
                     b = x[i]
                     yield b[0] if isinstance(b, (tuple, list)) else b
             batches, total = seq(), None
-        result, outs, off, pending = None, [], 0, None
+        result, outs, off, pending, used = None, [], 0, None, set()
 
         def land(p):
             ring_, handle, n_, shape_, off_ = p
@@ -443,9 +454,7 @@ class Model:
         for xb in batches:
             xb = np.asarray(xb, np.float32)
             eng = self._engine(xb.shape[0])
-            ring = self._eval_rings.get(xb.shape[0])
-            if ring is None or ring.x_stage is not eng.x_stage:
-                ring = self._eval_rings[xb.shape[0]] = EvalRing(eng)
+            ring = self._eval_ring(eng, xb.shape[0], used)
             if total is not None and result is None:
                 result = np.empty((total,) + tuple(eng.out_shape[1:]), np.float32)
             slot = ring.next_slot()
@@ -460,8 +469,6 @@ class Model:
             off += xb.shape[0]
         if pending is not None:
             land(pending)
-        for ring in self._eval_rings.values():
-            ring.reset_input_ring()
         if result is not None:
             return result
         return np.concatenate(outs, 0) if outs else np.zeros((0,), np.float32)
@@ -507,7 +514,6 @@ class Model:
         statistics are mean-reduced over the replicas first (a collective: every rank calls evaluate)."""
         self.sync_moving_statistics()
         import torch
-        from .engine import EvalRing
         kind, w_bce, w_dice, _ = self._loss_spec()
         rank, world = self._dist()
         local = (world > 1 and not isinstance(x, np.ndarray) and hasattr(x, 'batch_slice')
@@ -522,15 +528,13 @@ class Model:
         # Pipelined like fit(): pinned slot -> H2D on the copy stream under the previous batch's forward pass -> forward; the folded
         # sums of every batch stay on the device (one row each) and are read once at the end.  (Until round 4 every batch was a
         # pageable copy, a forward pass and a blocking read-out: 10 900 slices/s at config 2 -- tools/probe_evaluate.py.)
-        rows, counts = [], []
+        rows, counts, used = [], [], set()
         for xb, yb in batches:
             xb, yb = np.asarray(xb), np.asarray(yb)
             if not local:
                 xb, yb = self._shard(xb, yb)
             eng = self._engine(xb.shape[0])
-            ring = self._eval_rings.get(xb.shape[0])
-            if ring is None or ring.x_stage is not eng.x_stage:
-                ring = self._eval_rings[xb.shape[0]] = EvalRing(eng)
+            ring = self._eval_ring(eng, xb.shape[0], used)
             slot = ring.next_slot()
             ring.stage_host_batch(slot, xb, yb)
             ring.feed(slot)
@@ -546,8 +550,6 @@ class Model:
             import torch.distributed as dist
             dist.all_reduce(hist)
         per_batch = self._values_from_sums(hist.cpu().numpy().astype(np.float64), np.asarray(counts, np.float64), kind, w_bce, w_dice)
-        for ring in self._eval_rings.values():
-            ring.reset_input_ring()                            # nothing in flight, every slot free for the next call
         vals = per_batch.mean(0).tolist()
         return dict(zip(self.metrics_names, vals)) if return_dict else vals
 
