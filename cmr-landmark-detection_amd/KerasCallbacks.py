@@ -90,7 +90,12 @@ class ModelCheckpoint(Callback):
             self.best = cur
         if self._is_chief():
             os.makedirs(os.path.dirname(os.path.abspath(filepath)), exist_ok=True)
-        self.model.save_weights(filepath, overwrite=True)         # collective-safe: save_weights itself writes on rank 0 only
+        # collective-safe: save_weights itself writes on rank 0 only.  The file is serialised and written by a background thread
+        # (RVIP_ASYNC_CHECKPOINT=0: in this call, as Keras does); it is complete under its name when fit() returns.
+        if os.environ.get('RVIP_ASYNC_CHECKPOINT', '1') != '0' and hasattr(self.model, 'wait_for_checkpoint'):
+            self.model.save_weights(filepath, overwrite=True, background=True)
+        else:
+            self.model.save_weights(filepath, overwrite=True)
         self.saved_epochs.append(epoch)
 
     @staticmethod

@@ -130,6 +130,10 @@ class H5Writer:
 
     # -- serialisation ------------------------------------------------------------------------------------------------
     def tobytes(self):
+        return bytes(self.serialise())
+
+    def serialise(self):
+        """the file image as a bytearray (no further copy: save_keras_weights hands it to write())"""
         self._buf = bytearray(96)                                  # superblock (56 bytes) + root symbol-table entry (40)
         root_oh, root_bt, root_hp = self._write_group(self.root)
         eof = len(self._buf)
@@ -138,7 +142,7 @@ class H5Writer:
         sb += struct.pack('<QQII', 0, root_oh, 1, 0) + struct.pack('<QQ', root_bt, root_hp)
         assert len(sb) == 96
         self._buf[0:96] = sb
-        return bytes(self._buf)
+        return self._buf
 
     def _alloc(self, data):
         while len(self._buf) % 8:
@@ -152,8 +156,8 @@ class H5Writer:
         return self._alloc(struct.pack('<BBHII', 1, 0, len(messages), 1, len(body)) + b'\0' * 4 + body)
 
     def _write_dataset(self, arr):
-        raw = arr.tobytes()
-        addr = self._alloc(raw) if raw else UNDEF
+        raw = memoryview(arr.reshape(-1)).cast('B') if arr.size else b''      # one copy, into the file image (create_dataset made it contiguous little-endian)
+        addr = self._alloc(raw) if len(raw) else UNDEF
         msgs = [_message(MSG_DATASPACE, _dataspace_message(arr.shape)),
                 _message(MSG_DATATYPE, _dtype_message(arr.dtype), flags=1),                      # constant message, as libhdf5 marks it
                 _message(MSG_FILL, struct.pack('<BBBBI', 2, 2, 2, 1, 0), flags=1),               # v2: late allocation, fill if set, default (size 0) value
@@ -606,7 +610,7 @@ def save_keras_weights(path, layers, backend='tensorflow', keras_version='2.4.0'
         w.set_attr(ln, 'weight_names', np.array(wn, dtype='S') if wn else np.zeros((0,), np.float64))
         for n, arr in ws:
             w.create_dataset(ln + '/' + n, np.asarray(arr, np.float32))
-    data = w.tobytes()
+    data = w.serialise()
     with open(path, 'wb') as f:
         f.write(data)
     return len(data)

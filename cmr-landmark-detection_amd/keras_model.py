@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import math
 import queue
+import sys
 import threading
 import time
 import weakref
@@ -204,35 +205,76 @@ class Model:
             by_layer[ln].append(('%s/%s:0' % (ln, wn), i))
         return list(by_layer.items())
 
-    def save_weights(self, filepath, overwrite=True, save_format=None, sync=True, **_):
+    def save_weights(self, filepath, overwrite=True, save_format=None, sync=True, background=False, **_):
         """Weights-only checkpoint (ModelCheckpoint(save_weights_only=True), KerasCallbacks.py:54-61).  ``*.h5`` / ``*.hdf5`` /
         ``*.keras`` (or save_format='h5') write the Keras-HDF5 layout ``model.load_weights`` of the reference reads
         (predict_model.py:75-76) through the in-tree HDF5 writer (keras_h5.py); ``*.npz`` keeps the NumPy container keyed
         '<layer>/<weight>:0'.  Data-parallel: BN moving statistics are mean-reduced over the replicas first (Keras
         MirroredVariable aggregation MEAN) -- a collective every rank must enter -- and only rank 0 writes; ``sync=False`` skips
-        the collective (a rank-0-only caller) and writes this replica's moving statistics."""
+        the collective (a rank-0-only caller) and writes this replica's moving statistics.
+
+        ``background=True`` (the ModelCheckpoint callback): the weights are downloaded now (8 ms at config 2), serialised and
+        written by a host-only thread (36 ms) while training goes on; the file appears under its name only when complete
+        (written beside it, then os.replace), one writer at a time in call order; `wait_for_checkpoint()` -- called by the next
+        save, load_weights, close() and at the end of fit() -- joins it and re-raises its error."""
         import os
         weights = self.get_weights(sync=sync)                          # collective when data-parallel (replica mean of the BN statistics)
         if self._dist()[0] != 0:
             return
+        self.wait_for_checkpoint()
         if not overwrite and os.path.exists(filepath):
             raise FileExistsError(filepath)
         ext = os.path.splitext(str(filepath))[1].lower()
         if save_format in ('h5', 'hdf5', 'keras') or (save_format is None and ext in ('.h5', '.hdf5', '.keras')):
             from . import keras_h5
             layers = [(ln, [(wn, weights[i]) for wn, i in ws]) for ln, ws in self._layers_with_weights()]
-            keras_h5.save_keras_weights(filepath, layers)
-        elif save_format in (None, 'npz') :
+
+            def write(path):
+                keras_h5.save_keras_weights(path, layers)
+        elif save_format in (None, 'npz'):
             arrs = OrderedDict(zip(self.weight_names(), weights))
-            with open(filepath, 'wb') as f:
-                np.savez(f, **arrs)
+
+            def write(path):
+                with open(path, 'wb') as f:
+                    np.savez(f, **arrs)
         else:
             raise ValueError("save_format=%r: 'h5' (Keras-HDF5) and 'npz' are written; the TensorFlow checkpoint format is not" % (save_format,))
+        if not background:
+            write(filepath)
+            return
+        import threading
+        box = {}
+
+        def run():
+            tmp = '%s.part%d' % (filepath, os.getpid())
+            try:
+                write(tmp)
+                os.replace(tmp, filepath)
+            except BaseException as e:                                 # surfaces in wait_for_checkpoint
+                box['error'] = e
+                try:
+                    os.remove(tmp)
+                except OSError:
+                    pass
+        th = threading.Thread(target=run, name='rvip-checkpoint')
+        th.start()
+        self._checkpoint = (th, box)
+
+    def wait_for_checkpoint(self):
+        """Joins the background checkpoint writer, if any (host-only thread); re-raises what it raised."""
+        ck = getattr(self, '_checkpoint', None)
+        if ck is None:
+            return
+        self._checkpoint = None
+        ck[0].join()
+        if 'error' in ck[1]:
+            raise ck[1]['error']
 
     def load_weights(self, filepath, by_name=False, **_):
         """Keras-HDF5 (weights-only ``model.h5`` or the /model_weights group of a full ``model.save`` file) or ``.npz``.
         HDF5 files load the way Keras does: by topology -- the file's layers that hold weights, in ``layer_names`` order,
         against this model's -- or ``by_name``.  Shapes must match (Keras raises ValueError as well)."""
+        self.wait_for_checkpoint()
         with open(filepath, 'rb') as f:
             magic = f.read(8)
         if magic[:2] == b'PK':                                                     # NumPy .npz (zip)
@@ -652,6 +694,13 @@ class Model:
                         epoch + 1, epochs, dt, 1e3 * dt / max(steps, 1), ' - '.join('%s: %.4f' % kv for kv in logs.items())))
         finally:                                               # also when a callback stopped the training or raised: drop what was prefetched
             staged.close()
+            if sys.exc_info()[0] is None:
+                self.wait_for_checkpoint()                         # the last background checkpoint is on disk when fit() returns
+            else:
+                try:
+                    self.wait_for_checkpoint()
+                except BaseException:
+                    pass                                           # the training error is the one to report
         cbs.on_train_end()
         torch.cuda.synchronize()
         return self.history
@@ -670,6 +719,7 @@ class Model:
         thread, after a device synchronisation -- instead of whenever the last reference happens to go.  The weights stay
         readable (they are downloaded first); the next fit / predict rebuilds the device state from them."""
         import torch
+        self.wait_for_checkpoint()
         if self._params is not None:
             self.get_weights(sync=False)
             torch.cuda.synchronize()

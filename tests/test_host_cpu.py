@@ -438,3 +438,29 @@ def test_generator_batch_slice_is_the_slice_of_the_batch():
     np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), y)
     with pytest.raises(IndexError):
         gen.batch_slice(0, 4, 9)
+
+
+def test_background_checkpoint_is_atomic_ordered_and_joined(tmp_path):
+    """Model.save_weights(background=True) (the ModelCheckpoint callback's form): the file appears under its name only when
+    complete, a second save waits for the first, wait_for_checkpoint() joins and re-raises, load_weights sees the finished file."""
+    import threading
+    rvip = importlib.import_module('cmr-landmark-detection_amd')
+    cfg = dict(DIM=[32, 32], FILTERS=8, DEPTH=2, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2, SEED=5)
+    m = rvip.Unets.create_unet(cfg, metrics=[])
+    p = str(tmp_path / 'model.h5')
+    w0 = m.get_weights()
+    m.save_weights(p, background=True)
+    w1 = [w + 1.0 for w in w0]
+    m.set_weights(w1)
+    m.save_weights(p, background=True)                       # joins the first writer before it starts
+    m.wait_for_checkpoint()
+    assert not [t for t in threading.enumerate() if t.name == 'rvip-checkpoint']
+    assert sorted(os.listdir(tmp_path)) == ['model.h5']      # no .part file left
+    m2 = rvip.Unets.create_unet(cfg, metrics=[])
+    m2.load_weights(p)
+    for a, b in zip(m2.get_weights(), w1):
+        np.testing.assert_array_equal(a, b)
+    m.save_weights(str(tmp_path / 'no_such_dir' / 'x.h5'), background=True)
+    with pytest.raises(OSError):
+        m.wait_for_checkpoint()
+    m.wait_for_checkpoint()                                  # the error is reported once
