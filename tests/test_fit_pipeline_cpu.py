@@ -256,3 +256,32 @@ def test_augmentation_draws_belong_to_the_sample_not_to_the_call_order(tmp_path)
         for g in (whole, r0, r1):
             g.on_epoch_end()
         assert not np.array_equal(whole[0][0], first)      # a new epoch draws new augmentations
+
+
+def test_single_threaded_ring_of_four_slots_never_waits_forever():
+    """evaluate() / predict() drive a ring from ONE thread (engine.EvalRing: stage, feed, next batch) with four slots: staging batch
+    k needs slot k % 4, which feeding batch k - 2 handed back -- also when no upload ever reports completion early, and for inputs
+    without targets (predict)."""
+    assert E.EvalRing.SLOTS == 4
+    ring = _FakeRing((2, 4, 4, 1), (2, 4, 4, 2))
+    ring.alloc_input_ring(E.EvalRing.SLOTS)
+    done = threading.Event()
+    seen = []
+
+    def drive():
+        for k in range(23):
+            x = np.full((2, 4, 4, 1), k, np.float32)
+            y = None if k % 3 == 0 else np.full((2, 4, 4, 2), -k, np.float32)
+            slot = ring.next_slot()
+            assert ring.stage_host_batch(slot, x, y)
+            assert ring.slot_has_y[slot] == (y is not None)
+            ring.feed(slot)
+            seen.append(float(ring.device_x.ravel()[0]))
+        done.set()
+    ring.main_thread = None                                 # (the twin's thread assertions are for fit(): set below)
+    th = threading.Thread(target=lambda: (setattr(ring, 'main_thread', threading.get_ident()), drive()), daemon=True)
+    th.start()
+    assert done.wait(20), 'a slot was never handed back: the single-threaded protocol deadlocked'
+    assert seen == [float(k) for k in range(23)]
+    ring.reset_input_ring()
+    assert all(f.is_set() for f in ring.slot_free)
