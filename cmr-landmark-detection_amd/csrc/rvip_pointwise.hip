@@ -1339,6 +1339,89 @@ __global__ __launch_bounds__(256) void c1_wgrad_tiled(const T* __restrict__ x, c
     block_fold<9, VE>(part, true, ps * cg + cv, cout, pps, lds, ws + (size_t)blockIdx.x * 9 * cout);
 }
 
+// The same reduction on the matrix cores (16-bit types, Cout = 32, 2-D): dw[tap][co] = sum_p x[p + tap] * dy[p][co] is the weight
+// gradient of a 1 x 1 convolution whose input is im2col(x) -- the nine shifted copies of the single channel as a 32-"channel" pixel
+// row (channels 9..31 zero).  Per 8 x 32 tile the workgroup builds that [256][64 B] tile in LDS beside the [256][64 B] dy tile and
+// contracts them over the pixels exactly as wgrad3x3_kernel does for one tap (ds_read_tr16_b64 transposes the pixels into the K
+// run, v_mfma_f32_32x32x16): the products of two 16-bit values are exact in fp32, so against c1_wgrad_tiled only the order of the
+// fp32 additions differs.  c1_wgrad_tiled needed ~125 lane-operations per 16 bytes of dy (VALU-bound, 3.1 TB/s); this form moves
+// the multiply-adds to four MFMAs per wave and tile.  Same rows as c1_wgrad_tiled: ws[blockIdx.x][9][32].
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_pw;
+__device__ __forceinline__ s16x4 tr_read_pw(const unsigned char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_pw*)(p)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void c1_wgrad_mfma(const T* __restrict__ x, const unsigned char* __restrict__ dy,
+                                                     int n, int h, int w, int tiles_x, int tiles_y, float* __restrict__ ws) {
+    static_assert(sizeof(T) == 2, "16-bit storage types");
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * 256 * 64];       // im2col(x) tile, dy tile: [256 pixels][64 B]
+    __shared__ unsigned short xs[10 * 34 + 4];
+    unsigned char* lx = sm;
+    unsigned char* lg = sm + 256 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, hf = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // taps 16..31 of every im2col row stay zero for good; taps 9..15 are rewritten as zeros with every tile's row
+    *reinterpret_cast<uint4*>(lx + tid * 64 + 32) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(lx + tid * 64 + 48) = make_uint4(0, 0, 0, 0);
+    const int py = tid >> 5, px = tid & 31;                                          // this thread's pixel of the 8 x 32 tile
+    const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, grp = lane >> 4;
+    const int kk = 8 * (grp >> 1) + q;
+    const int cb = (16 * (grp & 1) + 4 * p4) * 2;
+    const int ntiles = n * tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int bx = tile;
+        const int tx0 = (bx % tiles_x) * 32; bx /= tiles_x;
+        const int ty0 = (bx % tiles_y) * 8;
+        const long long img = bx / tiles_y;
+        __syncthreads();                                                             // the previous tile has been contracted
+        for (int i = tid; i < 340; i += 256) {
+            const int gy = ty0 - 1 + i / 34, gx = tx0 - 1 + i % 34;
+            xs[i] = ((unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) ? x[(img * h + gy) * w + gx].bits : (unsigned short)0;
+        }
+        {
+            const int gy = ty0 + py, gx = tx0 + px;
+            uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+            if (gy < h && gx < w) {
+                const uint4* src = reinterpret_cast<const uint4*>(dy + ((size_t)(img * h + gy) * w + gx) * 64);
+                r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+            }
+            uint4* dst = reinterpret_cast<uint4*>(lg + tid * 64);
+            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+        }
+        __syncthreads();
+        {
+            unsigned v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = xs[(py + t / 3) * 34 + px + t % 3];
+            uint4* dst = reinterpret_cast<uint4*>(lx + tid * 64);
+            dst[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+            dst[1] = make_uint4(v[8], 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int P0 = wv * 64 + s4 * 16 + kk;
+            const s16x4 g0 = tr_read_pw(lg + P0 * 64 + cb), g1 = tr_read_pw(lg + (P0 + 4) * 64 + cb);
+            const s16x4 x0 = tr_read_pw(lx + P0 * 64 + cb), x1 = tr_read_pw(lx + (P0 + 4) * 64 + cb);
+            const uint4 fb = __builtin_bit_cast(uint4, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+            const uint4 fa = __builtin_bit_cast(uint4, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+            acc = mfma16<T>(fa, fb, acc);
+        }
+    }
+    // the four waves (quarters of every tile's pixels) in a fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sm);                                      // [4][9][32]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int tap = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        if (tap < 9) red[(wv * 9 + tap) * 32 + j] = acc[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 9 * 32; e += 256)
+        ws[(size_t)blockIdx.x * 9 * 32 + e] = ((red[e] + red[9 * 32 + e]) + red[2 * 9 * 32 + e]) + red[3 * 9 * 32 + e];
+}
+
 struct PostC1Wgrad {
     float* dw; int cout; int tstride;                          // tap stride of dw: cout for one input channel, cin * cout for HWIO with cin > 1
     __device__ void run_k(int ch, int k, double t) const { dw[k * tstride + ch] = (float)t; }
@@ -2325,7 +2408,10 @@ extern "C" int rvip_conv3x3_c1_wgrad(const void* x, const void* dy, float* dw, i
         long long nt = (long long)n * tx * ty;
         const int nb = (int)(nt < 1024 ? nt : 1024);
         if (workspace_bytes < (size_t)nb * 9 * cout * sizeof(float)) return RVIP_EWORKSPACE;
-        if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, 1, 0);
+        static const bool mfma = [] { const char* e = getenv("RVIP_C1_WGRAD_MFMA"); return !(e && e[0] == '0'); }();      // 0: the VALU form
+        if (mfma && cout == 32 && dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_mfma<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, tx, ty, ws);
+        else if (mfma && cout == 32 && dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_mfma<f16_t>, dim3(nb), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, tx, ty, ws);
+        else if (dtype == RVIP_BF16) hipLaunchKernelGGL(c1_wgrad_tiled<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, 1, 0);
         else if (dtype == RVIP_F16) hipLaunchKernelGGL(c1_wgrad_tiled<f16_t>, dim3(nb), dim3(256), 0, s, (const f16_t*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, 1, 0);
         else hipLaunchKernelGGL(c1_wgrad_tiled<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const unsigned char*)dy, n, h, w_, cout, tx, ty, ws, 1, 0, 1, 0);
         int rc2 = check_launch();

@@ -229,8 +229,9 @@ int    rvip_conv3x3_wgrad_form(const rvip_wgrad3x3_desc* d);
 typedef struct rvip_fold_entry { const float* src; float* dst; int32_t nrows; int32_t stride; long long width; } rvip_fold_entry;   /* stride (narrow folds): floats between rows, 0 = width */
 int rvip_fold_rows_batch(const void* table, int entries, long long max_width, int wide, void* stream);
 
-/* First layer, Cin = 1 (bandwidth-bound, no MFMA): y = act(conv3x3(x[N,H,W,1]) + bias); weights are
- * the fp32 HWIO master [9][1][Cout].  wgrad: dw[9][Cout] and nothing else (the input has no grad).
+/* First layer, Cin = 1 (bandwidth-bound; the forward pass without MFMA): y = act(conv3x3(x[N,H,W,1]) + bias); weights are
+ * the fp32 HWIO master [9][1][Cout].  wgrad: dw[9][Cout] and nothing else (the input has no grad); with a 16-bit dtype and
+ * Cout = 32 the contraction over the pixels runs on the matrix cores (im2col(x) x dy; exact 16-bit products, fp32 sums).
  * workspace for wgrad: rvip_reduce_workspace(n*h*w, 16*cout) bytes. */
 int rvip_conv3x3_c1_fwd(const void* x, const float* w, const float* bias, void* y,
                         int n, int h, int w_, int cout, int act, int dtype, void* stream);

@@ -1345,3 +1345,39 @@ def test_bce_dice_head_gradients_from_the_forward_pass(dtype, shape):
     assert L.rvip_head_mse_coef(C.byref(hc2), stream()) == -1
     assert L.rvip_bn_bwd_apply_head_lazy(C.byref(b2), P(hwd), None, P(ytd), P(o1['dcoef']), k, stream()) == -1
     assert L.rvip_bn_bwd_apply_head_lazy(C.byref(b2), P(hwd), P(o1['pred']), P(ytd), P(o1['dcoef']), 3, stream()) == -2
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(2, 20, 36), (3, 37, 70), (1, 256, 256), (5, 8, 32), (2, 1, 3)], ids=lambda s: 'x'.join(map(str, s)))
+def test_first_layer_weight_gradient_on_the_matrix_cores(shape, dtype, monkeypatch):
+    """rvip_conv3x3_c1_wgrad with Cout = 32 and a 16-bit type runs c1_wgrad_mfma (im2col(x) x dy over the pixels on v_mfma_f32_32x32x16):
+    against the float64 oracle (the products of two 16-bit values are exact in fp32, so the bound is the fp32 summation's: relative
+    to sum |x| |dy| per element), ragged tiles and tiny maps included; the rows-only form (dw = NULL) leaves exactly the rows whose
+    sum that is.  (The VALU form, RVIP_C1_WGRAD_MFMA=0, is what every other Cout takes: test_first_layer_c1.)"""
+    n, h, w = shape
+    co = 32
+    rng = np.random.default_rng(14)
+    x = rnd(rng.random((n, h, w, 1)) - 0.3, dtype)
+    dy = rnd(rng.standard_normal((n, h, w, co)), dtype)
+    xd, dyd = up(x, dtype), up(dy, dtype)
+    L = N.lib()
+    wsb = L.rvip_reduce_workspace(n * h * w, 16 * co)
+    ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev())
+    dw = torch.full((3, 3, 1, co), 7.0, dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_c1_wgrad', P(xd), P(dyd), P(dw), n, h, w, co, ndt(dtype), P(ws), C.c_size_t(wsb), stream())
+    x64, dy64 = x.astype(np.float64), dy.astype(np.float64)
+    xp = np.pad(x64[..., 0], ((0, 0), (1, 1), (1, 1)))
+    ref = np.zeros((3, 3, 1, co))
+    mag = np.zeros((3, 3, 1, co))
+    for ky in range(3):
+        for kx in range(3):
+            sh = xp[:, ky:ky + h, kx:kx + w]
+            ref[ky, kx, 0] = np.einsum('nhw,nhwc->c', sh, dy64)
+            mag[ky, kx, 0] = np.einsum('nhw,nhwc->c', np.abs(sh), np.abs(dy64))
+    got = down(dw).astype(np.float64)
+    assert np.all(np.abs(got - ref) <= 2e-6 * mag + 1e-30), float(np.max(np.abs(got - ref) / (mag + 1e-30)))
+    nr = L.rvip_conv3x3_c1_wgrad_rows(n, h, w, co, ndt(dtype))
+    rows = torch.full((nr * 9 * co,), 5.0, dtype=torch.float32, device=dev())
+    N.call('rvip_conv3x3_c1_wgrad', P(xd), P(dyd), None, n, h, w, co, ndt(dtype), P(rows), C.c_size_t(rows.numel() * 4), stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(rows.cpu().numpy().reshape(nr, 3, 3, 1, co).astype(np.float64).sum(0), got, rtol=0, atol=2e-6 * mag.max())
