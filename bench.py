@@ -47,6 +47,63 @@ def workload_key(args):
     return 'dim%d_f%d_d%d_b%d_t%d_%s' % (args.dim, args.filters, args.depth, args.batch, args.frames, args.precision)
 
 
+def make_cfg(M, dim, filters, depth, frames, precision, loss):
+    cfg = dict(DIM=[dim, dim], FILTERS=filters, DEPTH=depth, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
+               MASK_CLASSES=2, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-4, RVIP_PRECISION=precision,
+               LOSS_FUNCTION=M.mse if loss == 'mse' else M.bce_dice_loss, SEED=42)
+    if frames > 0:
+        cfg.update(DIM=[frames, dim, dim], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3])
+    return cfg
+
+
+OTHER_CONFIGS = (      # (key, BASELINE.json config, dim, filters, depth, frames, precision, loss, batch per GPU)
+    ('cfg4', 'configs[3]: 5-level U-Net, 64 base filters, 512x512, fp16 MFMA path', 512, 64, 5, 0, 'fp16', 'mse', 8),
+    ('cfg5', 'configs[4] per GPU: 3D cine U-Net, 16x256x256 volumes, Conv3D implicit GEMM, batch 4', 256, 32, 4, 16, 'bf16', 'mse', 4),
+    ('cfg2_bce_dice', "configs[1] with the Train notebook's bce_dice_loss (Train_tests.ipynb:219)", 256, 32, 4, 0, 'bf16', 'bce_dice', 32),
+)
+
+
+def measure_other(rvip, spec, steps, warmup=5):
+    """One more configuration through the same product path (get_model -> Engine.train_step: eager, capture, replay), timed like the
+    headline: inputs resident, `steps` replays between two device synchronisations.  Its engine and parameters are freed afterwards."""
+    import gc
+    import numpy as np
+    import torch
+    key, what, dim, filters, depth, frames, precision, loss, B = spec
+    M = rvip.Loss_and_metrics
+    cfg = make_cfg(M, dim, filters, depth, frames, precision, loss)
+    model = rvip.get_model(cfg, metrics=[])
+    try:
+        gen = rvip.Generators.SyntheticSAXGenerator(B, dict(DIM=cfg['DIM'], BATCHSIZE=B, GAUS=True, SIGMA=2, SHUFFLE=False, SEED=42))
+        x, y = gen[0]
+        eng = model._engine(B)
+        eng.load_input(x, y)
+        for _ in range(3 + warmup):
+            eng.train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.train_step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        lossv = float(eng.loss.item())
+        assert np.isfinite(lossv), 'training diverged in other_configs[%s]' % key
+        step_flops = model.plan.flops_per_slice()[1]
+        value = B * steps / el
+        return {'config': what, 'value': round(value, 2), 'unit': 'volumes/s' if frames > 0 else 'slices/s', 'ms_per_step': round(1e3 * el / steps, 4),
+                'steps': steps, 'warmup': warmup, 'dtype': {'bf16': 'bf16', 'fp16': 'f16', 'fp32': 'f32'}[precision],
+                'workload': '%d-level %s U-Net F=%d, %s, batch %d, fwd+loss(%s)+bwd+Adam' % (
+                    depth, '3D cine (Conv3D 3x3x3, pool 1x2x2)' if frames > 0 else '2D', filters,
+                    ('%dx%dx%d' % (frames, dim, dim)) if frames > 0 else '%dx%d' % (dim, dim), B, 'MSE' if loss == 'mse' else 'BCE-Dice'),
+                'launch': eng.launch_mode, 'gflop_per_unit_fwd_bwd': round(step_flops / 1e9, 3),
+                'mfma_util_whole_step': round(value * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4), 'loss': lossv}
+    finally:
+        model.close()
+        del model
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -67,6 +124,8 @@ def main():
     ap.add_argument('--detail', default=None, help='write a per-launch timing table (conv / wgrad shapes) to this file')
     ap.add_argument('--dump-labels', default=None, help='write the launch labels of one step, in launch order, as JSON (tools/step_timeline.py joins them with a kernel trace)')
     ap.add_argument('--no-roofline-pass', action='store_true', help='skip the eager per-launch and family-graph passes (profiling runs: only the captured step in the trace)')
+    ap.add_argument('--no-other-configs', action='store_true', help="skip the `other_configs` legs (BASELINE.json configs[3], configs[4] per GPU, the Train notebook's BCE-Dice loss)")
+    ap.add_argument('--other-steps', type=int, default=30, help='timed steps of every `other_configs` leg')
     args = ap.parse_args()
 
     import numpy as np
@@ -95,11 +154,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    cfg = dict(DIM=[args.dim, args.dim], FILTERS=args.filters, DEPTH=args.depth, BATCH_NORMALISATION=True, BN_FIRST=False, ACTIVATION='relu',
-               MASK_CLASSES=2, M_POOL=[2, 2], F_SIZE=[3, 3], LEARNING_RATE=1e-4, RVIP_PRECISION=args.precision,
-               LOSS_FUNCTION=M.mse if args.loss == 'mse' else M.bce_dice_loss, SEED=42)
-    if args.frames > 0:
-        cfg.update(DIM=[args.frames, args.dim, args.dim], M_POOL=[1, 2, 2], F_SIZE=[3, 3, 3])
+    cfg = make_cfg(M, args.dim, args.filters, args.depth, args.frames, args.precision, args.loss)
     model = rvip.get_model(cfg, metrics=[])
     plan = model.plan
     B = args.batch
@@ -174,9 +229,32 @@ def main():
         s = torch.cuda.current_stream()
         L = rvip._native.lib()
         conv_fn, conv_stats_fn, conv_sums_fn, wgrad_fn = L.rvip_conv3x3_fwd, L.rvip_conv3x3_fwd_stats, L.rvip_conv3x3_fwd_sums, L.rvip_conv3x3_wgrad
-        reps = 3
+        reps = 5
         agg = {}
         detail = []
+        # What the event pair adds to a launch's reading, calibrated on a trivial kernel in this run: its reading inside a busy
+        # queue minus its back-to-back cost per launch (one event pair around 200 launches).  Subtracted per launch below.
+        scratch = torch.zeros(64, dtype=torch.float32, device='cuda')
+        cs_ = C.c_void_p(s.cuda_stream)
+
+        def _triv():
+            assert L.rvip_scale_f32(C.c_void_p(scratch.data_ptr()), C.c_longlong(1), C.c_float(1.0), cs_) == 0
+        for _ in range(20):
+            _triv()
+        torch.cuda.synchronize()
+        eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        eb0.record(s)
+        for _ in range(200):
+            _triv()
+        eb1.record(s)
+        ovs = []
+        for _ in range(100):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s); _triv(); e1.record(s)
+            ovs.append((e0, e1))
+        torch.cuda.synchronize()
+        triv_ms = eb0.elapsed_time(eb1) / 200
+        ev_ovh_ms = max(sorted(a.elapsed_time(b) for a, b in ovs)[len(ovs) // 2] - triv_ms, 0.0)
         for _ in range(reps):
             eng.stage_input()
             for seq in (eng.fwd_train, eng.bwd, eng.opt):
@@ -235,7 +313,10 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / nrep
         conv_calls = [(th[0], th[1]) for seq in (eng.fwd_train, eng.bwd) for th in seq if th[0] in (conv_fn, conv_stats_fn, conv_sums_fn)]
-        fam_ms = family_ms(conv_calls)
+        fam_alone_ms = family_ms(conv_calls)    # informational: the same launches WITHOUT their producers in front (inputs cache-cold)
+        # THE roofline time: the family's launches inside the step (every launch behind its producer, as in the captured step and in
+        # the rocprofv3 kernel trace): HIP events around each launch of the eager pass above, minus the calibrated event-pair cost
+        fam_ms = max(sum(a.elapsed_time(b) for a, b, _ in cv) / reps - ev_ovh_ms * (len(cv) // reps), 1e-6)
         achieved = (fl / reps) / (fam_ms * 1e-3) / 1e12
         ms = fam_ms * reps                     # (kept for avg_launch_ms below: per-step family time x the eager pass's repetitions)
         # weight-gradient kernels alone: the same descriptors with the fold left out (slabs to the shared workspace)
@@ -305,7 +386,12 @@ def main():
                     algorithmic_bytes_per_launch=round(plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * 2.0 / 3.0 * B / max(len(cv) // reps, 1)),
                     launches_per_step=len(cv) // reps, avg_launch_ms=round(ms / len(cv), 4),
                     flops_per_launch=fl / len(cv), family_ms_per_step=round(fam_ms, 4),
-                    timing='HIP events around 20 replays of a hipGraph holding the family\'s launches of one step', profile=prof)
+                    timing='HIP events around every launch of the family inside %d eager steps (each launch behind its producer, as in the captured step), '
+                           'minus what the event pair adds to a reading (%.2f us, calibrated on a trivial kernel in this run) per launch' % (reps, 1e3 * ev_ovh_ms),
+                    family_alone_ms_per_step=round(fam_alone_ms, 4),
+                    family_alone_note='hipGraph of ONLY the family\'s launches replayed back to back: every input was written a whole family pass earlier '
+                                      '(cold in L2 / Infinity Cache); informational, not the roofline time',
+                    profile=prof)
         peak_ = PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3
         roof_wg = None
         if wg_ms:
@@ -329,6 +415,18 @@ def main():
                     'input': 'host float32 batches (x %.1f MB + y %.1f MB per step) through pinned ring + copy stream' % (
                         eng.x_stage.numel() * 4 / 1e6, eng.y_true.numel() * 4 / 1e6)}
 
+    # ---- the other configurations BASELINE.json names that fit one GPU, and the Train notebook's loss: the same product path, a few
+    # dozen steps each, AFTER everything the headline line reports (its `metric` / `value` / `config` are untouched by these legs)
+    other = None
+    headline = (args.dim, args.filters, args.depth, args.frames, args.precision, args.loss, B) == (256, 32, 4, 0, 'bf16', 'mse', 32)
+    if rank == 0 and world == 1 and headline and not (args.no_other_configs or args.no_aux):
+        other = {}
+        for spec in OTHER_CONFIGS:
+            try:
+                other[spec[0]] = measure_other(rvip, spec, args.other_steps)
+            except Exception as e:                                          # the headline line must survive a failing leg
+                other[spec[0]] = {'config': spec[1], 'error': '%s: %s' % (type(e).__name__, e)}
+
     fwd_flops, step_flops = plan.flops_per_slice()
     slices = B * world * args.steps
     value = slices / elapsed
@@ -351,6 +449,7 @@ def main():
             'wasted_traffic_ratio': round(hbm_step / (plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * B), 3) if hbm_step else None,
             'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),
             'loss': loss, 'steps_executed_total': max(2, min(args.warmup, 3)) + args.warmup + args.steps + (0 if args.no_roofline_pass else 3),
+            'other_configs': other,
             'roofline': roof,
             'roofline_wgrad': roof_wg if roof is not None else None,
             'kernels': per_kernel,

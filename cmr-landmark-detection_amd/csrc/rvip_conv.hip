@@ -287,7 +287,7 @@ struct ConvArgs2 {
     int down2;                               // epilogue_down2 instead of the plain epilogue
     int subpix;                              // TAPS == 4 kernels: blockIdx.z = output phase (a, b); y is [N, 2h, 2w, Cout]
     int nt_in;                               // input pieces with the non-temporal hint
-    int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing
+    int dbg;                                 // ablation only (RVIP_DBG): 1 = no DMA after the first item, 2 = no MFMA section, 4 = DMAs fetch nothing; ws16: 4 = input DMAs fetch nothing, 8 = no weight DMA / 16 = no input DMA after the first item, 32 = no epilogue, 64 = weights requested first
     float* stats;                            // optional [gridDim.x][2][cout] partial (sum, sum of squares) of the STORED output
     const uint32_t* mbits; unsigned mbits_bytes; int mbits_c; float mscale; int lds_mb_off;      // see ConvArgs; STATS == 3 kernels
     uint32_t* sbits; unsigned sbits_bytes;   // STATS == 0 kernels
@@ -934,7 +934,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
 #pragma unroll
             for (int i = 0; i < QI; ++i) {
                 const int gy = ty0 + ihy[i], gx = tx0 + ihx[i];
-                const bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+                const bool ok = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w && !(a.dbg & 4);
                 const bool ok0 = a.zs ? (ok && ((gy & gx) & 1)) : ok;
                 t0[i] = ok0 ? (unsigned)irel0[i] : OOB;
                 t1[i] = ok ? (unsigned)irel1[i] : OOB;
@@ -1018,8 +1018,9 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             if (itile >= a.ntiles) return 0;
             int cnt = nin;
             if constexpr (STATS == 3) cnt += (ikc == 0 && lwv < NCT * NPM) ? 1 : 0;
-            issue_input(ikc, istg);
-            if (!resident) issue_weights(ikc, istg);                          // (rotating weights: two stages only, host-checked)
+            if (!resident && (a.dbg & 64)) issue_weights(ikc, istg);          // (ablation: weights first)
+            if (!(a.dbg & 16)) issue_input(ikc, istg);
+            if (!resident && !(a.dbg & (8 | 64))) issue_weights(ikc, istg);   // (rotating weights: two stages only, host-checked)
             if (++ikc == nchunks) {
                 ikc = 0;
                 itile += gridDim.x;
@@ -1170,8 +1171,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             const u32x4v dta = {s0[0], s1[0], s0[1], s1[1]};
             const int co = cbase + 16 * (kq & 1) + 8 * (kq >> 1);
             const unsigned off = (pix_ok && co < a.cout) ? (pix * cstride + (co - cshift)) * 2u : OOB;
-            if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, 0);
+            if (second) __builtin_amdgcn_raw_buffer_store_b128(dta, ry1, off, 0, RVIP_WT_AUX);
+            else __builtin_amdgcn_raw_buffer_store_b128(dta, ry, off, 0, RVIP_WT_AUX);
         };
         auto block_pixel = [&](int blk, int& gy, int& gx) __attribute__((always_inline)) {
             gy = ty0 + row0 + blk / BPR;
@@ -1317,7 +1318,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
                 }
             }
         };
-        if (a.down2) epilogue_down2_16();
+        if (a.dbg & 32) {}                                                       // (ablation: no epilogue)
+        else if (a.down2) epilogue_down2_16();
         else if constexpr (STATS >= 2) epilogue([](float t) { return t; });      // data gradients carry no activation (host-checked)
         else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
         else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });

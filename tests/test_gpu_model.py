@@ -588,6 +588,69 @@ def test_bn_backward_in_front_of_subpixel_layers_with_trained_like_parameters(mo
         json.dump(report, fh, indent=1)
 
 
+TRAINED_REPORT = {}
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_trained_state_gradients_against_the_storage_emulation(precision):
+    """the 16-bit gradients of the DEFAULT backward schedule (algebraic BN backward, bit-plane gates, sub-pixel
+    consumers: `auto`) against the ORACLE with the same storage rounding, at a TRAINED state -- gamma != 1, beta != 0, logits with
+    real spatial structure -- instead of the initialisation, where the loss gradient is common-mode and the emulation's own rounding
+    noise is as large as the gradient (test_bf16_path_at_the_real_channel_widths_...).  The state comes from 60 Adam steps of the
+    fp32 device path on the batch (any weights are a valid input; that path is held to the float64 oracle elsewhere).  Reference
+    semantics: conv -> activation -> BatchNormalization -> Dropout (KerasLayers.py:684,691), TF's fused batch-norm backward.
+    Every trainable tensor: the device sits within `DEV_OVER_EMU` of the emulation's own distance from the exact float64 oracle
+    (both round the same tensors; the device differs by summation order -- rare one-ulp flips -- and by the algebraic form of
+    the BN backward, which is what this bounds), plus a floor for the tensors whose emulation noise is itself tiny."""
+    DEV_OVER_EMU, FLOOR = 0.6, 0.02
+    cfg = _cfg(FILTERS=32, DEPTH=3, DIM=[64, 64])
+    B = 4
+    x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=12)
+    trainer = rvip.get_model(dict(cfg, RVIP_PRECISION='fp32'), metrics=[])
+    for _ in range(60):
+        trainer.train_on_batch(x, y)
+    w = trainer.get_weights()
+    trainer.close()
+    names = trainer.weight_names()
+    dev_gb = [float(np.abs(a - 1.0).max()) if n_.endswith('/gamma:0') else float(np.abs(a).max()) for n_, a in zip(names, w) if n_.endswith(('/gamma:0', '/beta:0'))]
+    assert max(dev_gb) > 0.02, 'the state is not a trained one (gamma, beta still at their initial values)'
+    model = rvip.get_model(dict(cfg, RVIP_PRECISION=precision), metrics=[])
+    model.set_weights(w)
+    exact, layers = _oracle_from(model, cfg)
+    eng = model._engine(B)
+    assert eng.algebraic and eng.keep_bits, 'the default backward schedule (algebraic BN backward, keep-bit gates) is what this test is about'
+    q = O.bf16_round if precision == 'bf16' else O.f16_round
+    qg = q if precision == 'bf16' else (lambda a_: O.f16_round(a_, eng.loss_scale))      # f16 gradient tensors are stored at the loss scale
+    emu = O.OracleUNet(cfg, exact.params, dtype=np.float64, quant=q, quant_grad=qg)
+    eng.load_input(x, y)
+    eng.forward(training=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert not any(int(f.sum().item()) for f in eng.bn_flags.values())          # no channel block took the in-kernel exact route
+    masks = _masks(layers, B, model.seed, 0)
+    lv, egrads, epred, _ = emu.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', masks)
+    _, xgrads, _, _ = exact.loss_and_grads(x.astype(np.float64), y.astype(np.float64), 'mse', masks)
+    assert abs(float(eng.loss.item()) - lv) < 5e-3 * lv
+    got = model._params.grads_host()
+    table, bad = {}, []
+    for lname, gs in egrads.items():
+        kinds = ('kernel', 'bias') if lname.startswith(('conv', 'unet')) else ('gamma', 'beta')
+        for kind, ge, gx in zip(kinds, gs, xgrads[lname]):
+            gd = got[(lname, kind)].astype(np.float64)
+            nx = np.linalg.norm(gx) + 1e-300
+            dev_emu, emu_x, dev_x = (float(np.linalg.norm(gd - ge) / nx), float(np.linalg.norm(ge - gx) / nx), float(np.linalg.norm(gd - gx) / nx))
+            table['%s/%s' % (lname, kind)] = (round(dev_emu, 4), round(emu_x, 4), round(dev_x, 4))
+            if dev_emu > DEV_OVER_EMU * emu_x + FLOOR:
+                bad.append((lname, kind, dev_emu, emu_x))
+    TRAINED_REPORT[precision] = table
+    print(precision, 'trained state: (device - emulation, emulation - exact, device - exact) / |exact| per tensor:', table)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    import json
+    with open(os.path.join(ROOT, 'gpurun_out', 'r05_trained_state_gradients_%s.json' % precision), 'w') as fh:
+        json.dump(table, fh, indent=1)
+    assert not bad, bad
+
+
 def test_full_size_step_is_deterministic_and_finite():
     """BASELINE.json configs[1] shape (256x256, F=32, depth 4, batch 32, bf16): size-independent properties --
     two identical steps from identical state give bit-identical loss, heat-maps and gradients; a further step
