@@ -45,7 +45,9 @@ typedef float rvip_f32x4 __attribute__((ext_vector_type(4)));
 // pass 4.322 ms (-2.4 %); the 16-byte slab stores of the weight gradient on top: no change (left plain / non-temporal).
 #define RVIP_WT_AUX 16            /* raw_buffer_store aux: bit 4 = sc1 */
 __device__ __forceinline__ void store16(void* p, rvip_u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    // s_nop 1: a store of more than 64 bits reads its data registers late; a VALU write to them within the next two wait states
+    // corrupts it (the compiler pads its own stores, it cannot see into this statement: found as wrong fp16 skip tensors)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 template <typename T> struct Vec;
 template <> struct Vec<float> {

@@ -599,10 +599,13 @@ def test_trained_state_gradients_against_the_storage_emulation(precision):
     noise is as large as the gradient (test_bf16_path_at_the_real_channel_widths_...).  The state comes from 60 Adam steps of the
     fp32 device path on the batch (any weights are a valid input; that path is held to the float64 oracle elsewhere).  Reference
     semantics: conv -> activation -> BatchNormalization -> Dropout (KerasLayers.py:684,691), TF's fused batch-norm backward.
+    Measured: emulation - exact = 0.13 median / 0.38 max of |exact| in bf16 (0.04 / 0.11 in fp16) -- bf16 activations cost that much
+    even at a trained state (profiles/r03_gradient_fidelity.txt), so 'emulation noise < 0.05' is not a state this graph has -- and
+    device - emulation = 0.06 median / 0.20 max (0.02 / 0.05).
     Every trainable tensor: the device sits within `DEV_OVER_EMU` of the emulation's own distance from the exact float64 oracle
     (both round the same tensors; the device differs by summation order -- rare one-ulp flips -- and by the algebraic form of
     the BN backward, which is what this bounds), plus a floor for the tensors whose emulation noise is itself tiny."""
-    DEV_OVER_EMU, FLOOR = 0.6, 0.02
+    DEV_OVER_EMU, FLOOR = 0.75, 0.02          # measured (MI355X, round 5): worst tensor 0.58 (bf16) / 0.48 (fp16) of its emulation noise beyond the floor
     cfg = _cfg(FILTERS=32, DEPTH=3, DIM=[64, 64])
     B = 4
     x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=12)
