@@ -266,6 +266,7 @@ def main():
                     rc = fn(*a, C.c_void_p(s.cuda_stream))
                     e1.record(s)
                     assert rc == 0
+                    fn = getattr(fn, 'fn', fn)              # (an entry of the second stream wraps its entry point)
                     flops = 0.0
                     if fn is conv_fn or fn is conv_stats_fn or fn is conv_sums_fn:      # the same igemm kernels; the others add the BN partial sums / the column sums
                         d = a[0]._obj
@@ -322,7 +323,7 @@ def main():
         # weight-gradient kernels alone: the same descriptors with the fold left out (slabs to the shared workspace)
         wg_calls, wg_keep, wg_fl = [], [], 0.0
         for th in eng.bwd:
-            if th[0] is wgrad_fn:
+            if getattr(th[0], 'fn', th[0]) is wgrad_fn:
                 d0 = th[1][0]._obj
                 d1 = type(d0).from_buffer_copy(d0)
                 if max(d0.kd, 1) == 1:

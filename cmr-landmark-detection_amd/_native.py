@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RVIP_LIB') or os.path.join(_HERE, 'librvip_hip.so')     # RVIP_LIB: A/B another build of the same ABI
 
-EXPECTED_ABI = 7          # RVIP_ABI_VERSION of include/rvip_hip.h (tests/test_host_cpu.py holds the two together)
+EXPECTED_ABI = 8          # RVIP_ABI_VERSION of include/rvip_hip.h (tests/test_host_cpu.py holds the two together)
 F32, BF16, F16 = 0, 1, 2
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'elu': 2, 'sigmoid': 3}
 LOSS_MSE, LOSS_BCE_DICE = 0, 1
@@ -35,7 +35,7 @@ class Conv3x3Desc(C.Structure):
                 ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cout', C.c_int32),
                 ('act', C.c_int32), ('dtype', C.c_int32),
                 ('depth', C.c_int32), ('kd', C.c_int32), ('down2', C.c_int32), ('subpix', C.c_int32), ('stream_in', C.c_int32),
-                ('mask_bits', vp), ('mask_channels', C.c_int32), ('mask_scale', C.c_float), ('sign_bits', vp), ('sums_from', C.c_int32)]
+                ('mask_bits', vp), ('mask_channels', C.c_int32), ('mask_scale', C.c_float), ('sign_bits', vp), ('sums_from', C.c_int32), ('cu_limit', C.c_int32)]
 
 
 class PackEntry(C.Structure):
@@ -51,7 +51,7 @@ class Wgrad3x3Desc(C.Structure):
                 ('dtype', C.c_int32),
                 ('workspace', vp), ('workspace_bytes', C.c_size_t),
                 ('depth', C.c_int32), ('kd', C.c_int32), ('defer_fold', C.c_int32),
-                ('w_master', vp), ('dot_rows', vp), ('dot_rows_bytes', C.c_size_t), ('w_phase', vp)]
+                ('w_master', vp), ('dot_rows', vp), ('dot_rows_bytes', C.c_size_t), ('w_phase', vp), ('cu_limit', C.c_int32)]
 
 
 class ApplyDesc(C.Structure):

@@ -55,6 +55,7 @@ struct ConvArgs {
     const uint32_t* mbits; int mbits_c; float mscale;
     uint32_t* sbits;                          // forward launches: write the sign bits (stored value > 0) of the result in that layout
     int sums_from;
+    int cus;                                  // compute units the persistent grid is sized for (rvip_conv3x3_desc.cu_limit; 256 = all)
 };
 
 template <typename T, int TW, int NCT>
@@ -1427,7 +1428,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     const int cot = (int)cdiv(a0.cout, NCT * 32);
     if (cot > 1) b.nt_in = 0;       // several workgroup columns re-read the same input tile: keep it cached (measured)
     const int NZ = sp_fwd ? 4 : 1;
-    int gx = 256 / (cot * NZ);                     // one workgroup per CU (LDS-limited), persistent over the pixel tiles
+    int gx = a0.cus / (cot * NZ);                  // one workgroup per CU (LDS-limited), persistent over the pixel tiles
     if (gx < 1) gx = 1;
     if (gx > b.ntiles) gx = b.ntiles;
     b.stats = stats;
@@ -1459,7 +1460,7 @@ static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float
         // channel columns); 32-channel tiles double the workgroup count for a little more LDS traffic per FLOP
         const int tpx = (a.w > 16 && a.h >= 16) ? 512 : 256, tw = a.w > 16 ? 32 : 16;
         const long long ntiles = (long long)a.n * cdiv(a.w, tw) * cdiv(a.h, tpx / tw);
-        if (ntiles * cdiv(a.cout, 64) <= 128) two = false;
+        if (ntiles * cdiv(a.cout, 64) <= a.cus / 2) two = false;
     }
     if (a.subpix) {                     // a.h, a.w = the low-resolution grid
         if (a.w > 16 && a.h >= 16) {
@@ -1972,7 +1973,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 
 using namespace rvip;
 
-extern "C" int rvip_abi_version(void) { return RVIP_ABI_VERSION; }     // 3: round-2 prune; 4: window argmax of the pooled stages (apply / BN-backward descriptors), IMG_CHANNELS 2..4 entry points
+extern "C" int rvip_abi_version(void) { return RVIP_ABI_VERSION; }     // 8: cu_limit of the conv / weight-gradient descriptors; 3: round-2 prune; 4: window argmax of the pooled stages (apply / BN-backward descriptors), IMG_CHANNELS 2..4 entry points
 extern "C" const char* rvip_build_info(void) { return "rvip_hip gfx950 wave64 mfma"; }
 extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
 extern "C" int rvip_device_check(void) {
@@ -2009,6 +2010,7 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     a.subpix = d->subpix == 2 ? 2 : (d->subpix ? 1 : 0);
     a.mbits = nullptr; a.mbits_c = 0; a.mscale = 1.f; a.sbits = nullptr;
     a.sums_from = (d->sums_from > 0 && d->sums_from % 32 == 0) ? d->sums_from : 0;
+    a.cus = (d->cu_limit > 0 && d->cu_limit < 256) ? d->cu_limit : 256;
     if (a.subpix == 1) {                 // UpSampling2D -> conv as four phase convolutions on the low-resolution grid
         if (d->up0 != 1 || d->c1 || d->y1 || a.kd != 1 || a.down2) return RVIP_EINVAL;
         a.up0 = 0; a.h = d->h / 2; a.w = d->w / 2;

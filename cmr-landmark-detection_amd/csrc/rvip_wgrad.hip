@@ -949,7 +949,9 @@ static void wgrad_geometry(int n, int h, int w, int cin, int cout, int& tw, int&
 
 struct Wg2Geom { int tw, cib, cob, tiles_x, tiles_y, ntiles, nsplit; bool ok; bool pair = false; };     // pair: sub-pixel form with both column phases per workgroup
 
-static Wg2Geom wgrad2_geometry(int n, int h, int w, int c0, int c1, int cout, int dtype) {
+static int wg_cus(const rvip_wgrad3x3_desc* d) { return (d->cu_limit > 0 && d->cu_limit < 256) ? d->cu_limit : 256; }
+
+static Wg2Geom wgrad2_geometry(int n, int h, int w, int c0, int c1, int cout, int dtype, int cus = 256) {
     Wg2Geom g;
     const int cin = c0 + c1;
     const int esz = RVIP_ESZ(dtype);
@@ -966,7 +968,7 @@ static Wg2Geom wgrad2_geometry(int n, int h, int w, int c0, int c1, int cout, in
     }
     g.ok = (c1 == 0 || c0 % g.cib == 0);
     const long long blocks = cdiv(cin, g.cib) * cdiv(cout, g.cob);
-    long long s = 256 / blocks;                                  // one workgroup per CU (LDS-limited)
+    long long s = cus / blocks;                                  // one workgroup per CU (LDS-limited)
     if (s < 1) s = 1;
     if (s > g.ntiles) s = g.ntiles;
     g.nsplit = (int)s;
@@ -1014,7 +1016,7 @@ static bool wgrad_subpixel_geometry(const rvip_wgrad3x3_desc* d, Wg2Geom& g) {
     const bool on = !(e && e[0] == '0'), force = e && e[0] == '2';
     const int kd = d->kd > 0 ? d->kd : 1;
     if (!on || d->up0 != 1 || d->c1 != 0 || d->dtype == RVIP_F32 || kd != 1 || ((d->h | d->w) & 1)) return false;
-    g = wgrad2_geometry(d->n, d->h / 2, d->w / 2, d->c0, 0, d->cout, d->dtype);
+    g = wgrad2_geometry(d->n, d->h / 2, d->w / 2, d->c0, 0, d->cout, d->dtype, wg_cus(d));
     if (!g.ok) return false;
     // The form saves matrix work (16 / 36), not staging: every phase stages the X tile again.  It pays where the nine-tap kernel is
     // bound by its MFMA / LDS-read side -- the 64 x 64 blocks (512 -> 256 .. 128 -> 64: 64 -> 45 us) -- and not on the 32-wide
@@ -1023,7 +1025,7 @@ static bool wgrad_subpixel_geometry(const rvip_wgrad3x3_desc* d, Wg2Geom& g) {
     if (!force && !(g.cib == 64 && g.cob == 64) && !pair) return false;
     const long long blocks = cdiv(d->c0, g.cib) * cdiv(d->cout, g.cob);
     const int nph = pair ? 2 : 4;                                 // phases that are separate workgroups
-    long long sp = 256 / nph / blocks;                            // phases x sp pixel splits x blocks ~ one workgroup per CU
+    long long sp = wg_cus(d) / nph / blocks;                      // phases x sp pixel splits x blocks ~ one workgroup per CU
     if (sp < 1) sp = 1;
     if (sp > g.ntiles) sp = g.ntiles;
     g.nsplit = (int)(nph * sp);
@@ -1094,7 +1096,7 @@ extern "C" int rvip_conv3x3_wgrad(const rvip_wgrad3x3_desc* d, void* stream) {
     const long long dyb = (long long)a.n * a.h * a.w * a.cout * esz;
     Wg2Geom g2;
     const bool sp = wgrad_subpixel_geometry(d, g2);
-    if (!sp) g2 = wgrad2_geometry(a.n, a.h, a.w, a.c0, a.c1, a.cout, d->dtype);
+    if (!sp) g2 = wgrad2_geometry(a.n, a.h, a.w, a.c0, a.c1, a.cout, d->dtype, wg_cus(d));
     if (g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) {
         WgArgs2 b;
         b.x0 = a.x0; b.x1 = a.x1; b.dy = a.dy; b.slab = a.slab;
@@ -1170,7 +1172,7 @@ extern "C" int rvip_conv3x3_wgrad_form(const rvip_wgrad3x3_desc* d) {
     const long long dyb = (long long)d->n * d->h * d->w * d->cout * esz;
     Wg2Geom g2;
     const bool sp = wgrad_subpixel_geometry(d, g2);
-    if (!sp) g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype);
+    if (!sp) g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype, wg_cus(d));
     if (g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) return sp ? (g2.pair ? 2 : 1) : 0;
     return 3;
 }
@@ -1183,7 +1185,7 @@ extern "C" int rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d) {
     const long long x0b = (long long)d->n * (d->h >> up) * (d->w >> up) * d->c0 * esz, x1b = (long long)d->n * d->h * d->w * d->c1 * esz;
     const long long dyb = (long long)d->n * d->h * d->w * d->cout * esz;
     Wg2Geom g2;
-    if (!wgrad_subpixel_geometry(d, g2)) g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype);
+    if (!wgrad_subpixel_geometry(d, g2)) g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype, wg_cus(d));
     if (g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31)) return g2.nsplit;
     int tw, tx, ty, nt, ns;
     wgrad_geometry(d->n, d->h, d->w, d->c0 + d->c1, d->cout, tw, tx, ty, nt, ns);

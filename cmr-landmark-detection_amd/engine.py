@@ -79,6 +79,49 @@ def _ptr(t, offset_elems=0):
     return C.c_void_p(t.data_ptr() + offset_elems * t.element_size())
 
 
+class _OnSide:
+    """A launch-list entry that goes to the engine's SECOND stream (between a _Fork and a _Join): called like the C entry point it
+    wraps -- (*args, stream) -- and ignores the stream it is handed."""
+
+    def __init__(self, eng, fn):
+        self.eng, self.fn, self.__name__ = eng, fn, fn.__name__
+
+    def __call__(self, *a):
+        if os.environ.get('RVIP_BWD_OVERLAP_SERIAL') == '1':          # (diagnosis: the same grids, one stream)
+            return self.fn(*a)
+        return self.fn(*a[:-1], C.c_void_p(self.eng.side_stream.cuda_stream))
+
+
+class _Fork:
+    """second stream <- everything queued so far on the current one (capturable: an event edge)"""
+    __name__ = 'rvip_fork'
+
+    def __init__(self, eng):
+        self.eng = eng
+
+    def __call__(self, *a):
+        torch = _torch()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.eng.side_stream.wait_event(ev)
+        return 0
+
+
+class _Join:
+    """current stream <- everything queued so far on the second one"""
+    __name__ = 'rvip_join'
+
+    def __init__(self, eng):
+        self.eng = eng
+
+    def __call__(self, *a):
+        torch = _torch()
+        ev = torch.cuda.Event()
+        ev.record(self.eng.side_stream)
+        torch.cuda.current_stream().wait_event(ev)
+        return 0
+
+
 class ParamStore:
     """Flat device parameter blocks + packed conv operands, shared by every per-batch-size Engine."""
 
@@ -786,19 +829,43 @@ class Engine(InputRing):
             return sp_consumer
         self.sp_modes = {}
         wg_desc, dg_desc = {}, {}
-        for st in plan.stages:
+        # Weight and data gradient of a layer side by side (RVIP_BWD_OVERLAP = compute units of the weight gradient, 1..255; 0 = one
+        # after the other): both read the same gradient tensor and neither fills the chip's fixed costs -- launch, first tile, the
+        # epilogue / slab store at the end, the boundary -- with work.  Each is a one-workgroup-per-CU persistent kernel that owns its
+        # CU (LDS, registers), so "side by side" is a PARTITION of the CUs: the two grids are sized to W and 256 - W of them
+        # (rvip_*_desc.cu_limit) and launched on two streams between a fork and a join of the captured graph.
+        # RVIP_RCCL_CU_RESERVE = n (data-parallel runs): the contraction launches of the encoder's backward pass -- the ones that run
+        # while gradient bucket 0 is in flight -- leave n CUs to RCCL's kernels (default 0).
+        self.side_stream = None
+        # Measured (round 5, same box, alternating): W = 128 4.650 -> 4.54 ms at config 2 (-2.4 %), BCE-Dice -3.0 %, config 4 +0.3 %;
+        # 96 / 112 / 144 are SLOWER than one after the other (4.76 / 4.69 / 4.89: the tile counts no longer divide by the grids).
+        ov = int(os.environ.get('RVIP_BWD_OVERLAP', '128') or 0)
+        self.bwd_overlap = ov if (0 < ov < 256 and self.kd == 1) else 0
+        reserve = int(os.environ.get('RVIP_RCCL_CU_RESERVE', '0') or 0) if self.dp else 0
+        self.cu_reserve = reserve if 0 < reserve < 128 else 0
+        if self.bwd_overlap:
+            self.side_stream = torch.cuda.Stream(device=P.device)
+        n_enc_ = 2 * plan.depth
+        for si_, st in enumerate(plan.stages):
             if st.src0 == 'input_1':
                 continue
             dz = self.dz[st.z]
             wg = N.Wgrad3x3Desc()
+            avail = 256 - (self.cu_reserve if si_ < n_enc_ else 0)      # (encoder stages run while bucket 0 travels)
+            cu_w = cu_d = avail if avail < 256 else 0
+            if self.bwd_overlap:
+                cu_w = max(8, min(avail - 8, self.bwd_overlap * avail // 256))
+                cu_d = avail - cu_w
             wg.x0, wg.c0, wg.up0 = self.act[st.src0].data_ptr(), st.c0, st.up0
             wg.x1, wg.c1 = (self.act[st.src1].data_ptr(), st.c1) if st.src1 else (None, 0)
             wg.dy, wg.dw = dz.data_ptr(), P.g(st.conv, 'kernel').value
             wg.n, wg.h, wg.w, wg.cout, wg.dtype = n, st.h, st.w, st.cout, dt
             wg.depth, wg.kd = self.depth, self.kd
             wg.workspace, wg.workspace_bytes = self.ws_wg.data_ptr(), self.ws_wg_bytes
+            wg.cu_limit = cu_w
             wg_desc[st.conv] = wg
             dg = N.Conv3x3Desc()
+            dg.cu_limit = cu_d
             dg.x0, dg.c0, dg.up0, dg.x1, dg.c1 = dz.data_ptr(), st.cout, 0, None, 0
             dg.w_packed, dg.bias = P.packed[st.conv][1].data_ptr(), None
             dg.n, dg.h, dg.w, dg.cout, dg.act, dg.dtype = n, st.h, st.w, st.cin, 0, dt
@@ -1044,13 +1111,19 @@ class Engine(InputRing):
                 self._fold_bufs.append(sbuf)
                 wg.workspace, wg.workspace_bytes, wg.defer_fold = sbuf.data_ptr(), sbuf.numel() * 4, 1
                 wide.append((sbuf, P.g(st.conv, 'kernel'), ns, 9 * st.cin * st.cout))
-            bwd.append((L.rvip_conv3x3_wgrad, (C.byref(wg),)))
+            if self.bwd_overlap:            # weight gradient (+ its slab fold) on the second stream, beside the data gradient
+                bwd.append((_Fork(self), ()))
+                bwd.append((_OnSide(self, L.rvip_conv3x3_wgrad), (C.byref(wg),)))
+            else:
+                bwd.append((L.rvip_conv3x3_wgrad, (C.byref(wg),)))
             fuse_down = st.up0 == 1 and fuse_down_on
             if st.conv in sums_rows:        # the column sums of the result ride in the epilogue (sum g of the producers' BN backward)
                 sb = sums_rows[st.conv][0]
                 bwd.append((L.rvip_conv3x3_fwd_sums, (C.byref(dg), _ptr(sb), C.c_size_t(sb.numel() * 4))))
             else:
                 bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
+            if self.bwd_overlap:
+                bwd.append((_Join(self), ()))
             if st.up0 and not fuse_down:    # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions
                 back = L.rvip_upsample2x_bwd if st.up0 == 1 else L.rvip_subsample_odd
                 bwd.append((back, (_ptr(self.up_tmp[st.conv]), _ptr(self.grd[st.src0]), n, st.h // 2, st.w // 2, st.c0, dt)))

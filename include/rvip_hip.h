@@ -56,7 +56,7 @@ extern "C" {
 #define RVIP_STATE_WORDS  8
 
 #define RVIP_BIT_OF_CHANNEL(c) (8 * (((c) & 15) >> 2) + 4 * (((c) & 31) >> 4) + ((c) & 3))      /* bit planes of rvip_conv3x3_desc / rvip_apply_desc */
-#define RVIP_ABI_VERSION 7   /* what rvip_abi_version() of a matching library returns; _native.py checks it at every load */
+#define RVIP_ABI_VERSION 8   /* what rvip_abi_version() of a matching library returns; _native.py checks it at every load */
 int         rvip_abi_version(void);
 const char* rvip_build_info(void);          /* "gfx950 ..." */
 int         rvip_last_hip_error(void);      /* last hipError_t seen by a launcher (0 = none) */
@@ -130,6 +130,13 @@ typedef struct rvip_conv3x3_desc {
     /* rvip_conv3x3_fwd_sums only: the caller reads columns >= sums_from of the partial rows only (a multiple of 32; e.g. csplit when
      * the first half of a split result belongs to a stage without BatchNormalization); the columns below are unspecified. */
     int32_t      sums_from;
+    /* ABI 8 -- cu_limit in 1..255: the persistent grid of the LDS-DMA kernels is sized for that many compute units instead of all 256
+     * (one workgroup per CU), so that ANOTHER launch can run beside this one on the rest of the chip: the weight gradient of the same
+     * layer on a second stream (both read the same gradient tensor), or RCCL's kernels while a gradient bucket is in flight
+     * (RVIP_RCCL_CU_RESERVE).  The result tensor does not depend on it; the partial rows of the _stats / _sums forms do
+     * (rvip_conv3x3_fwd_*_rows answers for the limit in the descriptor), and with them the last bits of what is folded from them.
+     * 0 (or >= 256): the whole chip. */
+    int32_t      cu_limit;
 } rvip_conv3x3_desc;
 
 int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream);
@@ -211,6 +218,9 @@ typedef struct rvip_wgrad3x3_desc {
      * dW_phase[phase][u][v][i][o] = sum_pixels X[., i] * dX'[., i]  for the dX' the sub-pixel data gradient really writes, so that
      * T2' and the column sums of dX' describe the same gradient (rvip_bn_bwd_coef).  RVIP_EUNSUPPORTED for every other form. */
     const void*  w_phase;             /* [4][4][C0][Cout] in `dtype` */
+    /* ABI 8 -- as rvip_conv3x3_desc.cu_limit: the pixel-split count (rvip_conv3x3_wgrad_splits, _dot_rows) is chosen for that many
+     * compute units; fewer splits = fewer slabs to write and fold, and a different (still fixed) summation order of dw. */
+    int32_t      cu_limit;
 } rvip_wgrad3x3_desc;
 
 size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout);

@@ -602,10 +602,15 @@ def test_trained_state_gradients_against_the_storage_emulation(precision):
     Measured: emulation - exact = 0.13 median / 0.38 max of |exact| in bf16 (0.04 / 0.11 in fp16) -- bf16 activations cost that much
     even at a trained state (profiles/r03_gradient_fidelity.txt), so 'emulation noise < 0.05' is not a state this graph has -- and
     device - emulation = 0.06 median / 0.20 max (0.02 / 0.05).
-    Every trainable tensor: the device sits within `DEV_OVER_EMU` of the emulation's own distance from the exact float64 oracle
-    (both round the same tensors; the device differs by summation order -- rare one-ulp flips -- and by the algebraic form of
-    the BN backward, which is what this bounds), plus a floor for the tensors whose emulation noise is itself tiny."""
-    DEV_OVER_EMU, FLOOR = 0.75, 0.02          # measured (MI355X, round 5): worst tensor 0.58 (bf16) / 0.48 (fp16) of its emulation noise beyond the floor
+    Every trainable tensor: the device sits within `DEV_OVER_EMU` x the emulation's own distance from the exact float64 oracle -- of
+    the emulation AND of the exact gradient (both round the same tensors; the device differs by summation order, i.e. rare one-ulp
+    flips, and by the algebraic form of the BN backward, which is what this bounds) -- plus a floor for the tensors whose emulation
+    noise is itself tiny.  (VERDICT asked for 2 x; a bound relative to the device-emulation distance ALONE is not stable: at a
+    second, equally valid trained state the device is the closer of the two to the exact gradient and 0.9 x the noise away from
+    the emulation.)"""
+    # measured (MI355X, round 5) over two trained states (the second: the same recipe under another split-K partition of the fp32 steps):
+    # device - emulation at most 1.08 x the emulation's noise, device - exact at most 1.0 x (the device is usually the CLOSER of the two)
+    DEV_OVER_EMU, FLOOR = 1.25, 0.02
     cfg = _cfg(FILTERS=32, DEPTH=3, DIM=[64, 64])
     B = 4
     x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=12)
@@ -643,8 +648,8 @@ def test_trained_state_gradients_against_the_storage_emulation(precision):
             nx = np.linalg.norm(gx) + 1e-300
             dev_emu, emu_x, dev_x = (float(np.linalg.norm(gd - ge) / nx), float(np.linalg.norm(ge - gx) / nx), float(np.linalg.norm(gd - gx) / nx))
             table['%s/%s' % (lname, kind)] = (round(dev_emu, 4), round(emu_x, 4), round(dev_x, 4))
-            if dev_emu > DEV_OVER_EMU * emu_x + FLOOR:
-                bad.append((lname, kind, dev_emu, emu_x))
+            if dev_emu > DEV_OVER_EMU * emu_x + FLOOR or dev_x > DEV_OVER_EMU * emu_x + FLOOR:
+                bad.append((lname, kind, dev_emu, emu_x, dev_x))
     TRAINED_REPORT[precision] = table
     print(precision, 'trained state: (device - emulation, emulation - exact, device - exact) / |exact| per tensor:', table)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
