@@ -130,6 +130,8 @@ SIGNATURES = {
     'rvip_conv3x3_wgrad_splits': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
     'rvip_conv3x3_wgrad_dot_rows': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
     'rvip_conv3x3_wgrad_form': (C.c_int, [C.POINTER(Wgrad3x3Desc)]),
+    'rvip_conv3x3_wgrad_dgrad_ok': (C.c_int, [C.POINTER(Wgrad3x3Desc), C.POINTER(Conv3x3Desc)]),
+    'rvip_conv3x3_wgrad_dgrad': (C.c_int, [C.POINTER(Wgrad3x3Desc), C.POINTER(Conv3x3Desc), vp, C.c_size_t, vp]),
     'rvip_fold_rows_batch': (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'rvip_bn_bwd_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'rvip_bn_bwd_apply_head_rows': (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_int]),

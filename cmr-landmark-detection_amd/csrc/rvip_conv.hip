@@ -20,7 +20,9 @@
 
 namespace rvip {
 
+#ifndef RVIP_KERNELS_ONLY
 int g_last_hip_error = 0;
+#endif
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -835,8 +837,10 @@ __device__ __forceinline__ float lane16_channel_sum(const float (&a)[4], int i16
 }
 // STATS: 0 none; 1 BatchNormalization statistics of the stored output (sum, sum of squares: forward launches); 2 column sums only,
 // for data-gradient launches (with the 2x2-sum / channel-split epilogues): rows [gridDim.x][cout]; 3 = 2 + the Dropout backward
+// (the body is a device function of the workgroup's coordinates so that the weight / data gradient pair kernel of rvip_pair.hip can
+//  run it in a part of its grid: bx_ = first pixel tile, by_ = channel column, bz_ = output phase, gdx_ = the grid's tile stride)
 template <typename T, int TW, int NCT, int NPIX, int STATS, int TAPS = 9, int NCW = 4>
-__global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs2 a) {
+__device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx_, const int by_, const int bz_, const int gdx_) {
     static_assert(sizeof(T) == 2, "16-bit storage types");
     static_assert(TAPS == 9 || TAPS == 4, "taps");
     constexpr int TH = NPIX / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
@@ -856,8 +860,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int co0 = blockIdx.y * BN;
-    const int ph = (TAPS == 4) ? (int)blockIdx.z : 0, pa = ph >> 1, pb = ph & 1;      // output phase of the sub-pixel form
+    const int co0 = by_ * BN;
+    const int ph = (TAPS == 4) ? (int)bz_ : 0, pa = ph >> 1, pb = ph & 1;      // output phase of the sub-pixel form
     // subpix == 2 (TAPS = 4, gridDim.z = 1): the DATA GRADIENT of the sub-pixel form.  x0 is the full-resolution gradient [N, 2h, 2w, c0],
     // the result the low-resolution [N, h, w, cout]; the K loop runs over kd = 4 source phases (al, be) x the channel chunks: chunk
     // (al, be, c) reads x0[2y + al][2x + be] (an addressing mode of the loaders) through the 2x2 window at halo origin (1 - al, 1 - be)
@@ -866,7 +870,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     const int nch = (a.cin + KCE - 1) / KCE;         // chunks per depth tap
     const int nchunks = nch * a.kd;
     const bool resident = a.wres > 0;
-    const int first_tile = blockIdx.x;
+    const int first_tile = bx_;
     if (first_tile >= a.ntiles) return;
 
     if (wv >= NCW) {
@@ -1024,7 +1028,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             if (!resident && !(a.dbg & (8 | 64))) issue_weights(ikc, istg);   // (rotating weights: two stages only, host-checked)
             if (++ikc == nchunks) {
                 ikc = 0;
-                itile += gridDim.x;
+                itile += gdx_;
                 if (itile < a.ntiles) prep_tile(itile);                        // its offsets, while the DMAs fly
             }
             istg = istg + 1 == a.nstg ? 0 : istg + 1;
@@ -1033,7 +1037,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
         issue_next();
         if (a.dbg & 1) itile = a.ntiles;                  // (ablation: nothing is requested after the first item)
         int cyoung = a.nstg == 3 ? issue_next() : 0;      // DMAs of the item BEHIND the one the next barrier hands over
-        for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
+        for (int tile = first_tile; tile < a.ntiles; tile += gdx_) {
             for (int kc = 0; kc < nchunks; ++kc) {
                 // my pieces of the item about to be consumed have landed; after the barrier: everybody's have, and the compute waves
                 // are done with the item before it, whose stage the next request may now overwrite
@@ -1104,7 +1108,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
     int mb_par = 0;
 
     int it = 0, stg = 0;
-    for (int tile = first_tile; tile < a.ntiles; tile += gridDim.x, mb_par = (mb_par + 1 == a.nstg ? 0 : mb_par + 1)) {
+    for (int tile = first_tile; tile < a.ntiles; tile += gdx_, mb_par = (mb_par + 1 == a.nstg ? 0 : mb_par + 1)) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
@@ -1345,20 +1349,28 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs
             float t = 0.f;
 #pragma unroll
             for (int w4 = 0; w4 < NCW; ++w4) t += lst[(w4 * KS + k) * BN + c];
-            if (co0 + c < a.cout) a.stats[((size_t)blockIdx.x * KS + k) * a.cout + co0 + c] = t;
+            if (co0 + c < a.cout) a.stats[((size_t)bx_ * KS + k) * a.cout + co0 + c] = t;
         }
     }
+}
+
+template <typename T, int TW, int NCT, int NPIX, int STATS, int TAPS = 9, int NCW = 4>
+__global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws16(ConvArgs2 a) {
+    igemm_ws16_body<T, TW, NCT, NPIX, STATS, TAPS, NCW>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x);
 }
 
 template <typename T, bool V5, int TW, int NCT, int NPIX, int STATS, int TAPS, int NCW>
 static constexpr auto igemm_ws_kernel() {
     // (the four-compute-wave 512-pixel tiling holds 128 accumulators per lane: the wider fragment set of v5 would spill there)
-    if constexpr (V5 && sizeof(T) == 2 && NPIX / (32 * NCW) <= 2) return &conv3x3_igemm_ws16<T, TW, NCT, NPIX, STATS, TAPS, NCW>;
+    if constexpr (V5 && sizeof(T) == 2 && (NPIX / (32 * NCW) <= 2 || (TAPS == 9 && NCW == 4))) return &conv3x3_igemm_ws16<T, TW, NCT, NPIX, STATS, TAPS, NCW>;
     else return &conv3x3_igemm_ws<T, TW, NCT, NPIX, STATS, TAPS, NCW>;
 }
 
-template <typename T, bool V5, int TW, int NCT, int NPIX, int TAPS = 9, int NCW = 4>
-static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry, int smode = 1) {
+// what launch_igemm_ws would launch (PLAN_ONLY: filled instead of launching -- the pair kernel of rvip_pair.hip runs the body itself)
+struct IgemmPlan { ConvArgs2 args; int gx, gy, gz, lds; };
+
+template <typename T, bool V5, int TW, int NCT, int NPIX, int TAPS = 9, int NCW = 4, bool PLAN_ONLY = false>
+static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float* stats, int* rows_out, bool dry, int smode = 1, IgemmPlan* plan = nullptr) {
     constexpr int TH = NPIX / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int IN_BYTES = NHROWS * 64, W_BYTES = TAPS * NCT * 32 * 64;
@@ -1370,7 +1382,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     const long long x1b = (long long)a0.n * a0.h * a0.w * a0.c1 * (long long)sizeof(T);
     const long long wpb = (TAPS == 4 ? 16LL : 9LL * a0.kd) * a0.cin * a0.cout * (long long)sizeof(T);
     if ((TAPS == 4) != (a0.subpix != 0)) return RVIP_OK;
-    constexpr bool WS16 = V5 && sizeof(T) == 2 && NPIX / (32 * NCW) <= 2;      // (igemm_ws_kernel's choice)
+    constexpr bool WS16 = V5 && sizeof(T) == 2 && (NPIX / (32 * NCW) <= 2 || (TAPS == 9 && NCW == 4));      // (igemm_ws_kernel's choice)
     if (a0.subpix == 2 && !WS16) return RVIP_OK;           // the data-gradient form of the sub-pixel up-conv lives in the 16-bit kernel only
     const bool sp_fwd = TAPS == 4 && a0.subpix == 1;        // forward form: four output phases = blockIdx.z, result at twice the grid
     if (x0b >= (1LL << 31) || x1b >= (1LL << 31) || wpb >= (1LL << 31)) return RVIP_OK;
@@ -1407,6 +1419,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     const int lds = b.lds_bias_off + 256 + mb_bytes;
     if (lds > LDS_MAX) return RVIP_OK;
     static std::atomic<int> attr_lds{0};             // idempotent attribute call; atomic so concurrent host threads do not race on the flag
+    if constexpr (!PLAN_ONLY)
     if (!dry && lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ws_kernel<T, V5, TW, NCT, NPIX, 0, TAPS, NCW>()),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
@@ -1436,6 +1449,11 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     if (rows_out) *rows_out = gx;
     if (stats && TAPS == 4 && (!WS16 || a0.subpix != 2 || smode != 2 || gated)) return dry ? RVIP_OK : RVIP_EUNSUPPORTED;
     if (dry) { used = true; return RVIP_OK; }
+    if constexpr (PLAN_ONLY) {
+        plan->args = b; plan->gx = gx; plan->gy = cot; plan->gz = NZ; plan->lds = lds;
+        used = true;
+        return RVIP_OK;
+    } else {
     if (stats) {
         if constexpr (TAPS == 9) {
             if (smode == 2 && gated) hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 3, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
@@ -1449,6 +1467,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     } else hipLaunchKernelGGL((igemm_ws_kernel<T, V5, TW, NCT, NPIX, 0, TAPS, NCW>()), dim3((unsigned)gx, (unsigned)cot, (unsigned)NZ), dim3((NCW + 4) * 64), lds, s, b);
     used = true;
     return check_launch();
+    }
 }
 
 template <typename T, bool V5 = false>
@@ -1472,6 +1491,8 @@ static int dispatch_igemm_ws(const ConvArgs& a, hipStream_t s, bool& used, float
         return two ? launch_igemm_ws<T, V5, 16, 2, 256, 4>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 16, 1, 256, 4>(a, s, used, stats, rows_out, dry, smode);
     }
     if (a.w > 16 && a.h >= 16) {
+        static const bool ncw4 = [] { const char* e = getenv("RVIP_IGEMM_NCW4"); return e && e[0] == '1'; }();      // (A/B: four compute waves of 128 pixels)
+        if (ncw4) wide = false;
         if (wide) return two ? launch_igemm_ws<T, V5, 32, 2, 512, 9, 8>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 32, 1, 512, 9, 8>(a, s, used, stats, rows_out, dry, smode);
         return two ? launch_igemm_ws<T, V5, 32, 2, 512>(a, s, used, stats, rows_out, dry, smode) : launch_igemm_ws<T, V5, 32, 1, 512>(a, s, used, stats, rows_out, dry, smode);
     }
@@ -1969,21 +1990,6 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 // f32 and for the four-compute-wave sub-pixel tiling) serves every shape it is eligible for; the register-staged conv3x3_igemm is
 // the fallback for ragged channel counts (concat halves that are not whole 64-byte chunks, Cout % 8).  The generations measured
 // and retired on the way (igemm v2: every wave stages and computes; two workgroups per CU on the one-chunk layers) are in DESIGN.md.
-}  // namespace rvip
-
-using namespace rvip;
-
-extern "C" int rvip_abi_version(void) { return RVIP_ABI_VERSION; }     // 8: cu_limit of the conv / weight-gradient descriptors; 3: round-2 prune; 4: window argmax of the pooled stages (apply / BN-backward descriptors), IMG_CHANNELS 2..4 entry points
-extern "C" const char* rvip_build_info(void) { return "rvip_hip gfx950 wave64 mfma"; }
-extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
-extern "C" int rvip_device_check(void) {
-    const hipError_t a = hipDeviceSynchronize();
-    const hipError_t b = hipGetLastError();
-    const hipError_t e = a != hipSuccess ? a : b;
-    if (e != hipSuccess) g_last_hip_error = (int)e;
-    return (int)e;
-}
-
 static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
     if (!d || !d->x0 || !d->w_packed || !d->y) return RVIP_EINVAL;
     const int ve = RVIP_VE(d->dtype);
@@ -2019,6 +2025,22 @@ static int conv_args_from_desc(const rvip_conv3x3_desc* d, ConvArgs& a) {
         a.h = d->h / 2; a.w = d->w / 2; a.kd = 4;
     }
     return RVIP_OK;
+}
+
+}  // namespace rvip
+
+#ifndef RVIP_KERNELS_ONLY        /* rvip_pair.hip includes this file for its kernels and launch geometry only */
+using namespace rvip;
+
+extern "C" int rvip_abi_version(void) { return RVIP_ABI_VERSION; }     // 8: cu_limit of the conv / weight-gradient descriptors; 3: round-2 prune; 4: window argmax of the pooled stages (apply / BN-backward descriptors), IMG_CHANNELS 2..4 entry points
+extern "C" const char* rvip_build_info(void) { return "rvip_hip gfx950 wave64 mfma"; }
+extern "C" int rvip_last_hip_error(void) { return g_last_hip_error; }
+extern "C" int rvip_device_check(void) {
+    const hipError_t a = hipDeviceSynchronize();
+    const hipError_t b = hipGetLastError();
+    const hipError_t e = a != hipSuccess ? a : b;
+    if (e != hipSuccess) g_last_hip_error = (int)e;
+    return (int)e;
 }
 
 extern "C" int rvip_conv3x3_fwd(const rvip_conv3x3_desc* d, void* stream) {
@@ -2289,3 +2311,4 @@ extern "C" int rvip_pack_all_conv3x3_weights_tick(const float* theta, const void
     if (!state) return RVIP_EINVAL;
     return pack_all_launch(theta, table, entries, max_elems, dtype, wf_base, wd_base, state, stream);
 }
+#endif  /* RVIP_KERNELS_ONLY */

@@ -421,8 +421,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
 // phase tiles per stage, two accumulator sets, their blocks added before the slab leaves.  A tile's DMA pieces need ~2.2 us to issue
 // and land whatever the MFMA count (one tile in flight), so the form pays where the stage still fits two buffers: 64 x 32 blocks
 // (X 45 KB + 2 x 16 KB), i.e. the full-resolution layer 64 -> 32 at 256^2, which the four-phase form could not speed up.
+// (a device function of the workgroup's coordinates: bx_ = pixel split [x phase], by_ / bz_ = input / output channel block, gdx_ = the
+//  grid's x extent -- rvip_pair.hip runs it in a part of the grid of its weight / data gradient pair kernel)
 template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9, int PB = 0>
-__global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
+__device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigned bx_, const unsigned by_, const unsigned bz_, const unsigned gdx_) {
     static_assert(TAPS == 9 || (TAPS == 4 && sizeof(T) == 2), "taps");
     static_assert(PB == 0 || TAPS == 4, "phase pairs belong to the sub-pixel form");
     constexpr bool SP = TAPS == 4;
@@ -452,10 +454,10 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     // groups of 32 the phases of split s are the workgroups 8 apart -- same XCD, same L2, running side by side; otherwise every line
     // of dY comes from memory twice (64 -> 32 at 256^2: 85 us against 74 for the nine-tap form it replaces).
     constexpr int NPHB = PB ? 1 : 2;                                  // log2 of the phases that are separate workgroups (PB: only pa)
-    const bool xcd_map = SP && gridDim.x % (8 << NPHB) == 0;
-    const int ph = !SP ? 0 : xcd_map ? (int)((blockIdx.x >> 3) & ((1 << NPHB) - 1)) : (int)(blockIdx.x & ((1 << NPHB) - 1));
-    const int split = !SP ? (int)blockIdx.x : xcd_map ? (int)((blockIdx.x & 7) | ((blockIdx.x >> (3 + NPHB)) << 3)) : (int)(blockIdx.x >> NPHB);
-    const int ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
+    const bool xcd_map = SP && gdx_ % (8 << NPHB) == 0;
+    const int ph = !SP ? 0 : xcd_map ? (int)((bx_ >> 3) & ((1 << NPHB) - 1)) : (int)(bx_ & ((1 << NPHB) - 1));
+    const int split = !SP ? (int)bx_ : xcd_map ? (int)((bx_ & 7) | ((bx_ >> (3 + NPHB)) << 3)) : (int)(bx_ >> NPHB);
+    const int ci0 = by_ * CIB, co0 = bz_ * COB;
     const int pa = PB ? ph : ph >> 1, pb = PB ? 0 : ph & 1;                                             // output phase (wave-uniform); PB: pb = 0 and 1
     const int nsplit = SP ? a.nsplit >> NPHB : a.nsplit;                                                // pixel splits
     const int h0 = a.h >> a.up0, w0 = a.w >> a.up0;
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
 
     // results: one 9 x 32 x 32 fp32 block per (ci_t, co_t) pair; waves that split the pixels fold through LDS
     asm volatile("s_barrier" ::: "memory");                           // every stage has been consumed by every compute wave
-    float* out = a.slab + (size_t)blockIdx.x * 9 * a.cin * a.cout;
+    float* out = a.slab + (size_t)bx_ * 9 * a.cin * a.cout;
     // sub-pixel form: which of the phase's two summed taps per axis holds 3x3 tap row kh / column kw
     auto tap_of = [](int phase, int k3) { return phase ? (k3 == 2 ? 1 : 0) : (k3 != 0 ? 1 : 0); };
     if constexpr (PSPLIT == 1) {
@@ -703,6 +705,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
             }
         }
     }
+}
+
+template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9, int PB = 0>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
+    wgrad3x3_ws_body<T, TW, CIB, COB, NST, TAPS, PB>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
 // dw[i] = sum_k slab[k][i] in a fixed order (reproducible).  A thread owns four consecutive elements (one 16-byte load per slab);
@@ -1054,10 +1061,73 @@ static int launch_wgrad(const WgArgs& a, hipStream_t s) {
 
 }  // namespace rvip
 
-using namespace rvip;
-
 extern "C" int rvip_conv3x3_wgrad_dot_rows(const rvip_wgrad3x3_desc* d);
 extern "C" int rvip_conv3x3_wgrad_form(const rvip_wgrad3x3_desc* d);
+
+namespace rvip {
+// The arguments rvip_conv3x3_wgrad hands to wgrad3x3_ws for a 2-D layer of a 16-bit type (the case the pair kernel of rvip_pair.hip
+// serves), without launching; RVIP_EUNSUPPORTED for everything else.  Mirrors the checks of rvip_conv3x3_wgrad.
+struct WgradPlan { WgArgs2 b; Wg2Geom g; };
+static int wgrad_plan(const rvip_wgrad3x3_desc* d, WgradPlan& p) {
+    if (!d || !d->x0 || !d->dy || !d->dw || !d->workspace) return RVIP_EINVAL;
+    if (d->dtype != RVIP_BF16 && d->dtype != RVIP_F16) return RVIP_EUNSUPPORTED;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->c0 <= 0) return RVIP_EINVAL;
+    if (d->c0 % 8 || d->c1 % 8 || d->cout % 8) return RVIP_EINVAL;
+    if ((d->c1 > 0) != (d->x1 != nullptr)) return RVIP_EINVAL;
+    if (d->up0 < 0 || d->up0 > 2 || (d->up0 == 2 && d->c1 > 0)) return RVIP_EINVAL;
+    if (d->up0 && ((d->h | d->w) & 1)) return RVIP_EINVAL;
+    const int depth = d->depth > 0 ? d->depth : 1, kd = d->kd > 0 ? d->kd : 1;
+    if (kd != 1 || depth != 1) return RVIP_EUNSUPPORTED;
+    if (d->w_phase && !d->dot_rows) return RVIP_EINVAL;
+    if (d->w_phase && rvip_conv3x3_wgrad_form(d) != 1) return RVIP_EUNSUPPORTED;
+    const int cin = d->c0 + d->c1;
+    if (d->dot_rows) {
+        if (!d->w_master || d->defer_fold) return RVIP_EINVAL;
+        if (d->dot_rows_bytes < (size_t)rvip_conv3x3_wgrad_dot_rows(d) * cin * sizeof(double) || ((uintptr_t)d->dot_rows & 7)) return RVIP_EWORKSPACE;
+    }
+    const int up = d->up0 ? 1 : 0;
+    const long long x0b = (long long)d->n * (d->h >> up) * (d->w >> up) * d->c0 * 2, x1b = (long long)d->n * d->h * d->w * d->c1 * 2;
+    const long long dyb = (long long)d->n * d->h * d->w * d->cout * 2;
+    Wg2Geom& g2 = p.g;
+    const bool sp = wgrad_subpixel_geometry(d, g2);
+    if (!sp) g2 = wgrad2_geometry(d->n, d->h, d->w, d->c0, d->c1, d->cout, d->dtype, wg_cus(d));
+    if (!(g2.ok && x0b < (1LL << 31) && x1b < (1LL << 31) && dyb < (1LL << 31))) return RVIP_EUNSUPPORTED;
+    WgArgs2& b = p.b;
+    b.x0 = (const unsigned char*)d->x0; b.x1 = (const unsigned char*)d->x1; b.dy = (const unsigned char*)d->dy; b.slab = (float*)d->workspace;
+    b.x0_bytes = (unsigned)x0b; b.x1_bytes = (unsigned)x1b; b.dy_bytes = (unsigned)dyb;
+    b.c0 = d->c0; b.c1 = d->c1; b.up0 = up; b.zs = d->up0 == 2; b.n = d->n; b.h = d->h; b.w = d->w; b.cin = cin; b.cout = d->cout;
+    b.sp = sp ? (g2.pair ? 2 : 1) : 0;
+    if (sp) { b.up0 = 0; b.h = d->h / 2; b.w = d->w / 2; }
+    b.tiles_x = g2.tiles_x; b.tiles_y = g2.tiles_y; b.ntiles = g2.ntiles; b.nsplit = g2.nsplit;
+    { static const int dbg = [] { const char* e = getenv("RVIP_DBG"); return e ? atoi(e) : 0; }(); b.dbg = dbg; }
+    { static const bool ntx = [] { const char* e = getenv("RVIP_NT_WGRAD"); return !(e && e[0] == '0'); }(); b.nt_x = ntx ? 1 : 0; }
+    b.nt_slab = d->defer_fold ? 1 : 0;
+    b.depth = 1; b.dshift = 0;
+    if (d->workspace_bytes < (size_t)b.nsplit * 9 * cin * d->cout * sizeof(float)) return RVIP_EWORKSPACE;
+    return RVIP_OK;
+}
+// what follows the kernel: the slab fold (with the dot rows), or nothing when the fold is deferred (defined once, in rvip_wgrad.hip's
+// own translation unit: it launches the fold kernels)
+int wgrad_finish(const rvip_wgrad3x3_desc* d, int nsplit, int sp, hipStream_t s);
+}  // namespace rvip
+
+#ifndef RVIP_KERNELS_ONLY        /* rvip_pair.hip includes this file for its kernels and launch geometry only */
+namespace rvip {
+int wgrad_finish(const rvip_wgrad3x3_desc* d, int nsplit, int sp, hipStream_t s) {
+    if (d->defer_fold) return RVIP_OK;
+    const int cin = d->c0 + d->c1;
+    const long long count2 = 9LL * cin * d->cout;
+    if (d->dot_rows) {
+        return by_dtype(d->dtype, [&](auto t) {
+            return launch_wgrad_fold_dot<decltype(t)>((const float*)d->workspace, nsplit, cin, d->cout, d->dw, d->w_master, d->dot_rows, s,
+                                                      d->w_phase, (sp == 1 && nsplit % 32 == 0) ? 1 : 0);
+        });
+    }
+    return launch_wgrad_fold((const float*)d->workspace, nsplit, count2, d->dw, s);
+}
+}  // namespace rvip
+using namespace rvip;
+
 extern "C" size_t rvip_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout) {
     int tw, tx, ty, nt, ns;
     wgrad_geometry(n, h, w, cin, cout, tw, tx, ty, nt, ns);
@@ -1191,3 +1261,4 @@ extern "C" int rvip_conv3x3_wgrad_splits(const rvip_wgrad3x3_desc* d) {
     wgrad_geometry(d->n, d->h, d->w, d->c0 + d->c1, d->cout, tw, tx, ty, nt, ns);
     return ns;
 }
+#endif  /* RVIP_KERNELS_ONLY */

@@ -837,6 +837,12 @@ class Engine(InputRing):
         # RVIP_RCCL_CU_RESERVE = n (data-parallel runs): the contraction launches of the encoder's backward pass -- the ones that run
         # while gradient bucket 0 is in flight -- leave n CUs to RCCL's kernels (default 0).
         self.side_stream = None
+        self.paired = []                                  # layers whose two gradients run as one launch (rvip_conv3x3_wgrad_dgrad)
+        # RVIP_BWD_PAIR=1: the two gradients of a layer as ONE launch (rvip_conv3x3_wgrad_dgrad) instead of a fork / join.  Built and
+        # measured (round 5): it removes the ~18 us of cross-queue synchronisation per layer, but both halves must be 512-thread /
+        # 256-VGPR workgroups, i.e. the data gradient runs in its four-compute-wave form, which is ~16 % slower on the MFMA-bound
+        # layers than the eight-wave form: 4.66 ms against 4.50 (two launches) and 4.58 (one after the other), same box.  Opt-in.
+        self.bwd_pair = os.environ.get('RVIP_BWD_PAIR', '0') == '1'
         # Measured (round 5, same box, alternating): W = 128 4.650 -> 4.54 ms at config 2 (-2.4 %), BCE-Dice -3.0 %, config 4 +0.3 %;
         # 96 / 112 / 144 are SLOWER than one after the other (4.76 / 4.69 / 4.89: the tile counts no longer divide by the grids).
         ov = int(os.environ.get('RVIP_BWD_OVERLAP', '128') or 0)
@@ -1111,19 +1117,29 @@ class Engine(InputRing):
                 self._fold_bufs.append(sbuf)
                 wg.workspace, wg.workspace_bytes, wg.defer_fold = sbuf.data_ptr(), sbuf.numel() * 4, 1
                 wide.append((sbuf, P.g(st.conv, 'kernel'), ns, 9 * st.cin * st.cout))
-            if self.bwd_overlap:            # weight gradient (+ its slab fold) on the second stream, beside the data gradient
-                bwd.append((_Fork(self), ()))
-                bwd.append((_OnSide(self, L.rvip_conv3x3_wgrad), (C.byref(wg),)))
-            else:
-                bwd.append((L.rvip_conv3x3_wgrad, (C.byref(wg),)))
             fuse_down = st.up0 == 1 and fuse_down_on
-            if st.conv in sums_rows:        # the column sums of the result ride in the epilogue (sum g of the producers' BN backward)
-                sb = sums_rows[st.conv][0]
-                bwd.append((L.rvip_conv3x3_fwd_sums, (C.byref(dg), _ptr(sb), C.c_size_t(sb.numel() * 4))))
+            if self.bwd_overlap and self.bwd_pair and L.rvip_conv3x3_wgrad_dgrad_ok(C.byref(wg), C.byref(dg)):
+                # both kernels as the two parts of ONE grid (rvip_pair.hip): no fork / join of the graph, ~18 us per layer
+                if st.conv in sums_rows:
+                    sb = sums_rows[st.conv][0]
+                else:                           # (nobody reads this layer's column sums: a scratch row set)
+                    sb = torch.zeros(max(L.rvip_conv3x3_fwd_sums_rows(C.byref(dg)), 1) * st.cin, dtype=torch.float32, device=self.ws.device)
+                    self._fold_bufs.append(sb)
+                bwd.append((L.rvip_conv3x3_wgrad_dgrad, (C.byref(wg), C.byref(dg), _ptr(sb), C.c_size_t(sb.numel() * 4))))
+                self.paired.append(st.conv)
             else:
-                bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
-            if self.bwd_overlap:
-                bwd.append((_Join(self), ()))
+                if self.bwd_overlap:        # weight gradient (+ its slab fold) on the second stream, beside the data gradient
+                    bwd.append((_Fork(self), ()))
+                    bwd.append((_OnSide(self, L.rvip_conv3x3_wgrad), (C.byref(wg),)))
+                else:
+                    bwd.append((L.rvip_conv3x3_wgrad, (C.byref(wg),)))
+                if st.conv in sums_rows:    # the column sums of the result ride in the epilogue (sum g of the producers' BN backward)
+                    sb = sums_rows[st.conv][0]
+                    bwd.append((L.rvip_conv3x3_fwd_sums, (C.byref(dg), _ptr(sb), C.c_size_t(sb.numel() * 4))))
+                else:
+                    bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
+                if self.bwd_overlap:
+                    bwd.append((_Join(self), ()))
             if st.up0 and not fuse_down:    # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions
                 back = L.rvip_upsample2x_bwd if st.up0 == 1 else L.rvip_subsample_odd
                 bwd.append((back, (_ptr(self.up_tmp[st.conv]), _ptr(self.grd[st.src0]), n, st.h // 2, st.w // 2, st.c0, dt)))
