@@ -1408,7 +1408,7 @@ static int launch_igemm_ws(const ConvArgs& a0, hipStream_t s, bool& used, float*
     b.ntiles = a0.n * b.tiles_x * b.tiles_y;
     const int mb_tile = gated ? NCT * TH * TW * 4 : 0;           // one tile of mask words per input stage, behind the bias table
     // a third input stage (two items in flight per CU) where the 16-bit kernel keeps every weight chunk resident beside it
-    static const bool stg3_on = [] { const char* e = getenv("RVIP_IGEMM_STAGES"); return !(e && e[0] == '2'); }();
+    const bool stg3_on = [] { const char* e = getenv("RVIP_IGEMM_STAGES"); return !(e && e[0] == '2'); }();      // (read per call: the host side of a launch; a test flips it)
     const bool res3 = WS16 && stg3_on && 3 * IN_BYTES + nchunks * W_BYTES + 256 + 3 * mb_tile <= LDS_MAX;
     b.nstg = res3 ? 3 : 2;
     const int mb_bytes = b.nstg * mb_tile;

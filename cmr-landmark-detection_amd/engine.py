@@ -33,6 +33,13 @@ ALIGN = 64                                 # floats: every parameter tensor star
 
 
 _CAPTURE_LOCK = threading.RLock()            # one stream capture at a time per process; graph release never overlaps one
+_GRAVEYARD = []                              # captured graphs of engines that died without release(): see Engine.__del__
+
+
+def _bury_dead_graphs():
+    """(under _CAPTURE_LOCK, device idle, no capture running on this thread) destroys the graphs dead engines left behind"""
+    while _GRAVEYARD:
+        _GRAVEYARD.pop()
 
 
 def _torch():
@@ -50,6 +57,7 @@ def capture_guard():
     with _CAPTURE_LOCK:
         torch.cuda.synchronize()
         gc.collect()
+        _bury_dead_graphs()
         was_on = gc.isenabled()
         gc.disable()
         try:
@@ -1271,11 +1279,22 @@ class Engine(InputRing):
         self._graphs, self.launch_mode = graphs, 'hipGraph' if len(graphs) == 1 else 'hipGraph x%d + %s between' % (len(graphs), coll)
         return True
 
+    def __del__(self):
+        # an engine whose last reference goes on ANOTHER thread (or in an explicit gc.collect() of a callback / pool /
+        # checkpoint thread) must not run ~CUDAGraph there -- it synchronises the device, which throws from the destructor while
+        # any stream captures (SIGABRT).  The graphs are handed to a module-level list instead and destroyed by
+        # whoever next holds _CAPTURE_LOCK outside a capture (capture_guard's entry, release()).
+        g = getattr(self, '_graphs', None)
+        if g:
+            _GRAVEYARD.append(g)
+            self._graphs = None
+
     def release(self):
         """Drops the captured graphs and the pinned ring now (training thread, outside any capture, device idle)."""
         torch = _torch()
         with _CAPTURE_LOCK:
             torch.cuda.synchronize()
+            _bury_dead_graphs()
             self._graphs, self.launch_mode = None, 'eager'
             self._eager_steps = 0
             self.reset_input_ring()

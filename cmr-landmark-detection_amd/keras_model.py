@@ -653,6 +653,7 @@ class Model:
                     order = np.random.default_rng([self.seed, ep]).permutation(len(gen))
                 yield order[:steps]
         staged = self._staged_batches(gen, epoch_orders(), max_queue_size, workers)
+        ok = False                                             # set by the last statement of the loop: did THIS fit() finish cleanly
         try:
             for epoch in range(initial_epoch, epochs):
                 if self.stop_training:
@@ -692,10 +693,11 @@ class Model:
                     dt = time.time() - t0
                     print('Epoch %d/%d - %.1fs - %.0fms/step - %s' % (
                         epoch + 1, epochs, dt, 1e3 * dt / max(steps, 1), ' - '.join('%s: %.4f' % kv for kv in logs.items())))
+            ok = True
         finally:                                               # also when a callback stopped the training or raised: drop what was prefetched
             staged.close()
-            if sys.exc_info()[0] is None:
-                self.wait_for_checkpoint()                         # the last background checkpoint is on disk when fit() returns
+            if ok:                                                 # (not sys.exc_info(): fit() may itself run inside a caller's except block)
+                self.wait_for_checkpoint()                         # the last background checkpoint is on disk when fit() returns -- or its error is raised
             else:
                 try:
                     self.wait_for_checkpoint()

@@ -1120,6 +1120,58 @@ def test_rccl_one_rank_data_parallel_schedule_equals_the_single_graph_step():
         np.testing.assert_array_equal(a_, b_)
 
 
+def _rccl_reserve_worker(port, reserve, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      RVIP_FORCE_DP_SCHEDULE='1', RVIP_OVERLAP_ALLREDUCE='1', RVIP_RCCL_CU_RESERVE=str(reserve))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        cfg = _cfg(RVIP_PRECISION='fp32', DIM=[128, 128], FILTERS=32, DEPTH=3)
+        model = rvip.get_model(cfg, metrics=[])
+        x, y = O.synthetic_batch(8, cfg['DIM'], 2, seed=5)
+        eng = model._engine(8)
+        eng.load_input(x, y)
+        eng.forward(training=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        grads = {k: v.copy() for k, v in model._params.grads_host().items()}
+        losses = [model.train_on_batch(x, y)[0] for _ in range(3)]
+        n_enc = 2 * model.plan.depth
+        limits = [(int(th[1][0]._obj.cu_limit), i < eng.bwd_split) for i, th in enumerate(eng.bwd)
+                  if getattr(th[0], '__name__', '') in ('rvip_conv3x3_wgrad', 'rvip_conv3x3_fwd', 'rvip_conv3x3_fwd_sums')]
+        q.put((losses, grads, eng.cu_reserve, limits, eng.launch_mode, n_enc))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_cu_reserve_leaves_compute_units_to_the_collective():
+    """RVIP_RCCL_CU_RESERVE = n sizes the grids of the contraction launches that run while gradient bucket 0 is in
+    flight (the encoder's backward pass) for 256 - n compute units, so that the first multi-GPU run can A/B whether RCCL's kernels --
+    which cannot co-reside with the persistent one-workgroup-per-CU kernels -- profit from CUs of their own.  One rank against RCCL:
+    the launches of bucket 1 carry the reduced limits and those of bucket 0 do not, and a step's gradients and three training steps'
+    losses agree up to the fp32 summation order of the partial rows / split-K slabs, whose partition follows the grid (the tensors
+    themselves do not depend on it: rvip_hip.h, cu_limit).  Reference: MirroredStrategy's all-reduce, Unets.py:70-75."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    res = {}
+    for reserve in (0, 8):
+        q = ctx.Queue()
+        p = ctx.Process(target=_rccl_reserve_worker, args=(30100 + os.getpid() % 1500 + reserve, reserve, q))
+        p.start()
+        res[reserve] = q.get(timeout=300)
+        p.join(60)
+    l0, w0, r0, lim0, mode0, _ = res[0]
+    l8, w8, r8, lim8, mode8, _ = res[8]
+    assert r0 == 0 and r8 == 8 and mode8 == 'hipGraph x3 + RCCL between', (r0, r8, mode8)
+    assert all(lim in (128, 0) for lim, _ in lim0), lim0                       # (128: the side-by-side halves of the backward pass)
+    assert all(lim == 124 for lim, head in lim8 if not head) and all(lim == 128 for lim, head in lim8 if head), lim8
+    assert any(not head for _, head in lim8)
+    np.testing.assert_allclose(l8, l0, rtol=2e-5)
+    for k, g0 in w0.items():        # the gradients of one step (not weights after Adam: where a gradient element is ~0 its last bits decide a step of the learning rate)
+        np.testing.assert_allclose(w8[k], g0, atol=2e-5 * float(np.abs(g0).max()) + 1e-12, rtol=0, err_msg=str(k))
+
+
 def _dp_fit_worker(rank, world, port, path, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')

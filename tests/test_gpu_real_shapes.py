@@ -622,3 +622,47 @@ def test_real_shape_conv3d(idx, dtype):
     t2 = rows_t.cpu().numpy().sum(0)
     s2 = (np.abs(k['wt'].astype(np.float64)) * np.abs(k['dw'])).sum((0, 1, 2, 4)).max()
     assert np.abs(t2 - ident).max() <= 2e-5 * s2 * max(1.0, np.sqrt(n * h * h / 4096.0)), (name, np.abs(t2 - ident).max() / s2)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', ['one chunk', 'concat halves', 'partial chunk', 'gated sums', 'streamed input'])
+def test_three_input_stages_equal_two(case, dtype, monkeypatch):
+    """the loaders of the 16-bit igemm run TWO items ahead where every weight chunk stays resident in LDS and wait with a
+    COUNTED s_waitcnt vmcnt(n) -- n = the wave's DMA instructions of the younger item.  A miscount would be a silent race (compute
+    waves reading a stage before it has landed), so the three-stage launch must equal the two-stage one (RVIP_IGEMM_STAGES=2) bit
+    for bit on the shapes whose instruction counts differ: one K chunk, a K loop over both concat halves, a partial last chunk, the
+    gated data gradient (its mask words ride as one more DMA per tile) and the non-temporal input path."""
+    rng = np.random.default_rng(7)
+    n, h, w_ = 2, 64, 96                                   # ragged against the 16 x 32 tiles
+    c0, c1, co = {'one chunk': (32, 0, 32), 'concat halves': (32, 32, 32), 'partial chunk': (40, 0, 32), 'gated sums': (32, 0, 32),
+                  'streamed input': (32, 0, 32)}[case]
+    ci = c0 + c1
+    x0 = up(_grid(rng.standard_normal((n, h, w_, c0))), dtype)
+    x1 = up(_grid(rng.standard_normal((n, h, w_, c1))), dtype) if c1 else None
+    wf, _ = pack(_grid(rng.standard_normal((3, 3, ci, co)) * 0.1), dtype)
+    bits = torch.from_numpy(rng.integers(0, 2 ** 32, size=(1, n * h * w_), dtype=np.uint32).view(np.int32)).to(dev())
+    outs = []
+    for stages in ('3', '2'):
+        if stages == '2':
+            monkeypatch.setenv('RVIP_IGEMM_STAGES', '2')
+        else:
+            monkeypatch.delenv('RVIP_IGEMM_STAGES', raising=False)
+        y = torch.zeros((n, h, w_, co), dtype=tdt(dtype), device=dev())
+        if case == 'gated sums':
+            d = conv_desc(x0, c0, 0, None, 0, wf, None, y, None, 0, n, h, w_, co, 0, dtype)
+            d.mask_bits, d.mask_channels, d.mask_scale = bits.data_ptr(), co, 2.0
+            rows = N.lib().rvip_conv3x3_fwd_sums_rows(C.byref(d))
+            assert rows > 0
+            sums = torch.zeros(rows * co, dtype=torch.float32, device=dev())
+            N.call('rvip_conv3x3_fwd_sums', C.byref(d), P(sums), C.c_size_t(sums.numel() * 4), stream())
+            outs.append((y.clone(), sums.clone()))
+        else:
+            d = conv_desc(x0, c0, 0, x1, c1, wf, None, y, None, 0, n, h, w_, co, N.ACT['relu'], dtype)
+            if case == 'streamed input':
+                d.stream_in = 1
+            N.call('rvip_conv3x3_fwd', C.byref(d), stream())
+            outs.append((y.clone(),))
+    torch.cuda.synchronize()
+    assert float(outs[0][0].float().abs().max()) > 0
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b), case
