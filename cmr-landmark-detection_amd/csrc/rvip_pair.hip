@@ -6,13 +6,15 @@
 // Side by side on a PARTITION of the CUs (rvip_*_desc.cu_limit) the fixed costs of one hide behind the other's matrix work -- but as
 // two launches on two streams every layer pays a fork and a join of the captured graph, ~18 us of cross-queue synchronisation
 // (profiles/r05_bwd_pair.txt).  Here the two run as the two halves of one grid: workgroups [0, nw) execute the body of wgrad3x3_ws,
-// workgroups [nw, nw + nd) the body of conv3x3_igemm_ws16 in its four-compute-wave form (both 512 threads, <= 256 VGPRs; the
-// eight-compute-wave form is 768 threads at 168).  Workgroups are dealt to the 8 XCDs round-robin by their linear id, so with nw a
+// workgroups [nw, nw + nd) the body of conv3x3_igemm_ws16.  Both halves must be workgroups of one shape: 768 threads at <= 168 VGPRs
+// for the 512-pixel tiles (the igemm's eight-compute-wave form; the weight gradient then splits its nine taps over two waves, TS = 2:
+// 80 / 64 accumulator registers instead of 144), 512 threads for the 256-pixel tiles of the 16-wide maps.  Workgroups are dealt to the 8 XCDs round-robin by their linear id, so with nw a
 // multiple of 8 both halves keep the placement their own launches have.  The arithmetic of either half is untouched (the tensors are
-// bit-identical to the two launches with the same cu_limit; the column sums are added over four compute waves instead of eight).
-// MEASURED (round 5, same box): the pair kernels take 91 / 133 us where the two launches take max(56, 72) / max(89, 100) -- the
-// four-compute-wave data gradient is the slower half by ~16 % on the MFMA-bound layers -- and the step 4.66 ms against 4.50 for the
-// fork / join schedule: the engine keeps this entry point opt-in (RVIP_BWD_PAIR=1) until that form is as fast as the eight-wave one.
+// and partial rows are bit-identical to the two launches with the same cu_limit).
+// MEASURED (round 5, same box, captured step): one after the other 4.62 ms, two launches between a fork and a join 4.60, this 4.52.
+// What the pair hides is the fixed cost of the two launches (~10 us per layer on the MFMA-bound layers); on the HBM-bound 256^2
+// layers the two halves share the bandwidth and the pair takes as long as the two launches did.  (A first form with 512-thread
+// halves -- the igemm's four-compute-wave tiling -- measured 4.66: that tiling is ~16 % slower on the MFMA-bound layers.)
 #define RVIP_KERNELS_ONLY
 #include "rvip_conv.hip"
 #include "rvip_wgrad.hip"
@@ -20,18 +22,21 @@
 
 namespace rvip {
 
-template <typename T, int TW, int CIB, int COB, int NSTW, int NCT, int NPIX, int STATS>
-__global__ __launch_bounds__(512, 1) void wgrad_dgrad_pair(WgArgs2 wa, ConvArgs2 ca, int nw, int wgx, int wgy, int dgx) {
+// NCW = compute waves of BOTH halves' workgroups: 8 (768 threads, <= 168 VGPRs: the igemm's eight-compute-wave form of the 512-pixel
+// tiles + the weight gradient with its taps split over two waves, TS = 2) or 4 (512 threads: the forms the 256-pixel tiles of the
+// 16-wide maps use anyway)
+template <typename T, int TW, int CIB, int COB, int NSTW, int NCT, int NPIX, int STATS, int NCW>
+__global__ __launch_bounds__((NCW + 4) * 64, 1) void wgrad_dgrad_pair(WgArgs2 wa, ConvArgs2 ca, int nw, int wgx, int wgy, int dgx) {
     if ((int)blockIdx.x < nw) {
         const unsigned id = blockIdx.x, r = id / (unsigned)wgx;
-        wgrad3x3_ws_body<T, TW, CIB, COB, NSTW, 9, 0>(wa, id % (unsigned)wgx, r % (unsigned)wgy, r / (unsigned)wgy, (unsigned)wgx);
+        wgrad3x3_ws_body<T, TW, CIB, COB, NSTW, 9, 0, NCW / 4>(wa, id % (unsigned)wgx, r % (unsigned)wgy, r / (unsigned)wgy, (unsigned)wgx);
     } else {
         const int id = (int)blockIdx.x - nw;
-        igemm_ws16_body<T, TW, NCT, NPIX, STATS, 9, 4>(ca, id % dgx, id / dgx, 0, dgx);
+        igemm_ws16_body<T, TW, NCT, NPIX, STATS, 9, NCW>(ca, id % dgx, id / dgx, 0, dgx);
     }
 }
 
-template <typename T, int TW, int CIB, int COB, int NCT, int NPIX, int STATS>
+template <typename T, int TW, int CIB, int COB, int NCT, int NPIX, int STATS, int NCW>
 static int launch_pair(const WgArgs2& wa, const IgemmPlan& dp, hipStream_t s, bool dry) {
     // LDS of the weight-gradient half: launch_wgrad2x's arithmetic (the stage count is a template parameter of the body)
     constexpr int TH = 256 / TW;
@@ -44,7 +49,7 @@ static int launch_pair(const WgArgs2& wa, const IgemmPlan& dp, hipStream_t s, bo
     if (dp.gz != 1 || dp.lds > 160 * 1024) return RVIP_EUNSUPPORTED;
     if (dry) return RVIP_OK;
     const int lds = lds_w > dp.lds ? lds_w : dp.lds;
-    auto kern = &wgrad_dgrad_pair<T, TW, CIB, COB, NSTW, NCT, NPIX, STATS>;
+    auto kern = &wgrad_dgrad_pair<T, TW, CIB, COB, NSTW, NCT, NPIX, STATS, NCW>;
     static std::atomic<bool> attr_done{false};
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -53,15 +58,15 @@ static int launch_pair(const WgArgs2& wa, const IgemmPlan& dp, hipStream_t s, bo
     }
     const int wgx = wa.nsplit, wgy = (int)cdiv(wa.cin, CIB), wgz = (int)cdiv(wa.cout, COB);
     const int nw = wgx * wgy * wgz, nd = dp.gx * dp.gy;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nw + nd)), dim3(512), lds, s, wa, dp.args, nw, wgx, wgy, dp.gx);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nw + nd)), dim3((NCW + 4) * 64), lds, s, wa, dp.args, nw, wgx, wgy, dp.gx);
     return check_launch();
 }
 
 // the data-gradient half: the tiling dispatch_igemm_ws takes for this shape, in its four-compute-wave (512-thread) instantiation
-template <typename T, int TW, int NCT, int NPIX>
+template <typename T, int TW, int NCT, int NPIX, int NCW>
 static int plan_dgrad(const ConvArgs& a, float* sums, IgemmPlan& p) {
     bool used = false;
-    const int rc = launch_igemm_ws<T, true, TW, NCT, NPIX, 9, 4, true>(a, nullptr, used, sums, nullptr, false, 2, &p);
+    const int rc = launch_igemm_ws<T, true, TW, NCT, NPIX, 9, NCW, true>(a, nullptr, used, sums, nullptr, false, 2, &p);
     if (rc) return rc;
     return used ? RVIP_OK : RVIP_EUNSUPPORTED;
 }
@@ -97,11 +102,11 @@ static int pair_dispatch(const rvip_wgrad3x3_desc* wd, const rvip_conv3x3_desc* 
     IgemmPlan dp;
 #define RVIP_PAIR(TWv, CIBv, COBv, NCTv, NPIXv)                                                                                   \
     if (tw == TWv && cib == CIBv && cob == COBv && two == (NCTv == 2)) {                                                            \
-        rc = plan_dgrad<T, TWv, NCTv, NPIXv>(a, sums_ws, dp);                                                                      \
+        rc = plan_dgrad<T, TWv, NCTv, NPIXv, (NPIXv == 512 ? 8 : 4)>(a, sums_ws, dp);                                              \
         if (rc) return rc;                                                                                                         \
         if (sums_ws_bytes < (size_t)dp.gx * a.cout * sizeof(float)) return RVIP_EWORKSPACE;                                        \
-        return gated ? launch_pair<T, TWv, CIBv, COBv, NCTv, NPIXv, 3>(wp.b, dp, s, dry)                                           \
-                     : launch_pair<T, TWv, CIBv, COBv, NCTv, NPIXv, 2>(wp.b, dp, s, dry);                                          \
+        return gated ? launch_pair<T, TWv, CIBv, COBv, NCTv, NPIXv, 3, (NPIXv == 512 ? 8 : 4)>(wp.b, dp, s, dry)                   \
+                     : launch_pair<T, TWv, CIBv, COBv, NCTv, NPIXv, 2, (NPIXv == 512 ? 8 : 4)>(wp.b, dp, s, dry);                  \
     }
     // the (tile width, weight-gradient block, channel-column) combinations of the benchmark graphs (configs 2 and 4)
     RVIP_PAIR(32, 32, 32, 1, 512)

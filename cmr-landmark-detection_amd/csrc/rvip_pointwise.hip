@@ -1690,7 +1690,6 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(CoefArgs a) {
     constexpr int VE = Vec<T>::VE, NV = 32 / VE, NS = 1024 / NV;
     __shared__ double sh[2][32][32];
     __shared__ float part_lds[NS][32];
-    __shared__ int bad[32];
     __shared__ int sbad;
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int ch = blockIdx.x * 32 + c;
@@ -1722,22 +1721,16 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(CoefArgs a) {
     __syncthreads();
     double t1 = 0.0, t2 = 0.0;
     float gm = 1.f, bt = 0.f;
-    if (g == 0) {
+    if (threadIdx.x < 64) {                                  // wave 0: its first 32 lanes own the block's channels (g == 0)
         int isbad = 0;
-        if (ch < a.c) {
+        if (g == 0 && ch < a.c) {
 #pragma unroll
             for (int gg = 0; gg < 32; ++gg) { t1 += sh[0][gg][c]; t2 += sh[1][gg][c]; }
             gm = a.gamma[ch]; bt = a.beta ? a.beta[ch] : 0.f;
             isbad = !(fabsf(gm) >= a.min_gamma && fabsf(bt) <= a.max_beta_ratio * fabsf(gm));
         }
-        bad[c] = isbad;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int any = 0;
-        for (int i = 0; i < 32; ++i) any |= bad[i];
-        a.flags[blockIdx.x] = any;
-        sbad = any;
+        const int any = __ballot(isbad) != 0ull;               // one wave vote instead of 32 words through LDS, a serial OR and a barrier
+        if (threadIdx.x == 0) { a.flags[blockIdx.x] = any; sbad = any; }
     }
     __syncthreads();
     if (!sbad) {

@@ -13,6 +13,7 @@
 // slab [9][Cin][Cout], and a second kernel sums the slabs in split order: bitwise reproducible.
 #include "rvip_common.h"
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 namespace rvip {
@@ -423,10 +424,16 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
 // (X 45 KB + 2 x 16 KB), i.e. the full-resolution layer 64 -> 32 at 256^2, which the four-phase form could not speed up.
 // (a device function of the workgroup's coordinates: bx_ = pixel split [x phase], by_ / bz_ = input / output channel block, gdx_ = the
 //  grid's x extent -- rvip_pair.hip runs it in a part of the grid of its weight / data gradient pair kernel)
-template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9, int PB = 0>
+// TS = 2 (nine taps, 16-bit types): EIGHT compute waves -- every (pair, pixel part) of the four-wave form twice, once for taps 0..4 and
+// once for taps 5..8 (80 / 64 accumulator registers instead of 144) -- so that the workgroup is 12 waves at <= 168 VGPRs, the shape of
+// the eight-compute-wave igemm: the two can then be the two parts of one grid (rvip_pair.hip).  Both tap halves read the same dY
+// fragments; the X fragments, the MFMA count and the slab are those of the four-wave form.
+template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9, int PB = 0, int TS = 1>
 __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigned bx_, const unsigned by_, const unsigned bz_, const unsigned gdx_) {
     static_assert(TAPS == 9 || (TAPS == 4 && sizeof(T) == 2), "taps");
     static_assert(PB == 0 || TAPS == 4, "phase pairs belong to the sub-pixel form");
+    static_assert(TS == 1 || (TS == 2 && TAPS == 9 && sizeof(T) == 2), "tap halves: the nine-tap form of the 16-bit types");
+    constexpr int NCWV = 4 * TS;                                      // compute waves
     constexpr bool SP = TAPS == 4;
     constexpr int NG = PB ? 2 : 1;                                    // dY phase tiles per stage
     constexpr int TH = 256 / TW, HWD = TW + 2, HHT = TH + 2, NHALO = HWD * HHT;
@@ -447,8 +454,9 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
     const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wv8 >= 4;
-    const int wv = wv8 & 3;                                           // compute wave id / loader wave id
+    const bool loader = wv8 >= NCWV;
+    const int wv = wv8 & 3;                                           // compute wave id within its tap half / loader wave id
+    const int th = TS == 2 ? wv8 >> 2 : 0;                            // tap half of a compute wave (TS = 2: 0 -> taps 0..4, 1 -> taps 5..8)
     // Sub-pixel form: the four phases of a pixel split read the same X tiles and the four interleaved quarters of the same dY lines
     // (a pixel of a 32-channel dY is half a 128-byte line).  Workgroups go to the 8 XCDs round-robin, so with a grid of whole
     // groups of 32 the phases of split s are the workgroups 8 apart -- same XCD, same L2, running side by side; otherwise every line
@@ -564,11 +572,15 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
         return;
     }
 
-    f32x16 acc[NG * TAPS];
+    // (T0, T1): this wave's taps.  acc[lt] belongs to tap T0 + lt (TS = 1: all of them, lt = gph * TAPS + t)
+    constexpr int MYT = TS == 2 ? 5 : NG * TAPS;
+    f32x16 acc[MYT];
 #pragma unroll
-    for (int t = 0; t < NG * TAPS; ++t)
+    for (int t = 0; t < MYT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    auto tile_loop = [&](auto T0c, auto T1c) __attribute__((always_inline)) {
+    constexpr int T0 = decltype(T0c)::value, T1 = decltype(T1c)::value;
 
     int it = 0;
     for (int tile = split; tile < a.ntiles; tile += nsplit, ++it) {
@@ -621,12 +633,12 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
                 const s16x4 g1 = tr_read(gp[1] + gph * G_BYTES + s * 16 * RBG);
                 const uint4 fb = __builtin_bit_cast(uint4, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
+                for (int t = T0; t < T1; ++t) {
                     const int off = ((srow + (SP ? t >> 1 : t / 3)) * HWD + scol) * RBX;
                     const s16x4 x0 = tr_read((SP ? xq[SP ? gph : 0][t & 1][0] : xp[t % 3][0]) + off);
                     const s16x4 x1 = tr_read((SP ? xq[SP ? gph : 0][t & 1][1] : xp[t % 3][1]) + off);
                     const uint4 fa = __builtin_bit_cast(uint4, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    acc[gph * TAPS + t] = mfma16<T>(fa, fb, acc[gph * TAPS + t]);
+                    acc[gph * TAPS + t - T0] = mfma16<T>(fa, fb, acc[gph * TAPS + t - T0]);
                 }
             }
         } else {
@@ -648,6 +660,9 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
             }
         }
     }
+    };
+    if (TS == 2 && th == 1) tile_loop(std::integral_constant<int, 5>{}, std::integral_constant<int, 9>{});
+    else tile_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, TS == 2 ? 5 : TAPS>{});
 
     // results: one 9 x 32 x 32 fp32 block per (ci_t, co_t) pair; waves that split the pixels fold through LDS
     asm volatile("s_barrier" ::: "memory");                           // every stage has been consumed by every compute wave
@@ -661,14 +676,16 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
             if (SP ? (2 * tap_of(pa, t9 / 3) + tap_of(pb, t9 % 3) != t) : (t != t9)) continue;           // wave-uniform
+            if (TS == 2 && (t < 5) != (th == 0)) continue;                                               // the other tap half's
+            const int lt = TS == 2 ? (t < 5 ? t : t - 5) : t;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + ci_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf, co = co0 + co_t * 32 + j;
                 // the slab is read back by the batched fold at the end of the gradient bucket, milliseconds later: non-temporal
                 // stores keep its 37.7 MB per layer from displacing the activations (measured: -0.07 ms per step)
                 if (ci < a.cin && co < a.cout) {
-                    if (a.nt_slab) __builtin_nontemporal_store(acc[t][r], &out[((size_t)t9 * a.cin + ci) * a.cout + co]);
-                    else out[((size_t)t9 * a.cin + ci) * a.cout + co] = acc[t][r];      // folded by the next launch: keep it cached
+                    if (a.nt_slab) __builtin_nontemporal_store(acc[lt][r], &out[((size_t)t9 * a.cin + ci) * a.cout + co]);
+                    else out[((size_t)t9 * a.cin + ci) * a.cout + co] = acc[lt][r];      // folded by the next launch: keep it cached
                 }
             }
           }
@@ -679,12 +696,16 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
         constexpr int BLK = NG * TAPS * 32 * 32, N4 = PAIRS * BLK / 4, BLK9 = 9 * 32 * 32;
         float* red = reinterpret_cast<float*>(smem) + (part * PAIRS + pair) * BLK;   // [PSPLIT][PAIRS][9][32][32]
 #pragma unroll
-        for (int t = 0; t < NG * TAPS; ++t)
+        for (int lt = 0; lt < MYT; ++lt) {
+            const int t = TS == 2 ? lt + 5 * th : lt;
+            if (t < NG * TAPS) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j] = acc[t][r];
+                for (int r = 0; r < 16; ++r) red[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j] = acc[lt][r];
+            }
+        }
         __syncthreads();
         const f32x4* r4 = reinterpret_cast<const f32x4*>(smem);
-        for (int o4 = tid; o4 < PAIRS * BLK9 / 4; o4 += 256) {
+        for (int o4 = tid; o4 < PAIRS * BLK9 / 4; o4 += 256 * TS) {
             const int e = 4 * o4, pr = e / BLK9, rem = e % BLK9;
             const int t = rem >> 10;                                             // 3x3 tap of the slab element
             const int e4 = SP ? (pr * BLK + (2 * tap_of(pa, t / 3) + tap_of(pb, t % 3)) * 1024 + (rem & 1023)) / 4 : o4;
@@ -710,6 +731,11 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
 template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9, int PB = 0>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     wgrad3x3_ws_body<T, TW, CIB, COB, NST, TAPS, PB>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+template <typename T, int TW, int CIB, int COB, int NST = 2>
+__global__ __launch_bounds__(768, 1) void wgrad3x3_ws12(WgArgs2 a) {
+    wgrad3x3_ws_body<T, TW, CIB, COB, NST, 9, 0, 2>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
 // dw[i] = sum_k slab[k][i] in a fixed order (reproducible).  A thread owns four consecutive elements (one 16-byte load per slab);
@@ -1002,6 +1028,20 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid((unsigned)a.nsplit, (unsigned)cdiv(a.cin, CIB), (unsigned)cdiv(a.cout, COB));
+    if constexpr (WS && TAPS == 9 && PB == 0 && sizeof(T) == 2) {
+        // (A/B: the eight-compute-wave form -- the taps split between two waves -- as a launch of its own)
+        static const bool ws12 = [] { const char* e = getenv("RVIP_WGRAD_WS12"); return e && e[0] == '1'; }();
+        if (ws12) {
+            static std::atomic<bool> attr12{false};
+            if (!attr12) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws12<T, TW, CIB, COB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
+                attr12 = true;
+            }
+            hipLaunchKernelGGL((wgrad3x3_ws12<T, TW, CIB, COB, NST>), grid, dim3(768), lds, s, a);
+            return check_launch();
+        }
+    }
     if constexpr (WS) hipLaunchKernelGGL((wgrad3x3_ws<T, TW, CIB, COB, NST, TAPS, PB>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((wgrad3x3_dma<T, TW, CIB, COB>), grid, dim3(256), lds, s, a);
     return check_launch();

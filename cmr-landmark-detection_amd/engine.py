@@ -846,11 +846,11 @@ class Engine(InputRing):
         # while gradient bucket 0 is in flight -- leave n CUs to RCCL's kernels (default 0).
         self.side_stream = None
         self.paired = []                                  # layers whose two gradients run as one launch (rvip_conv3x3_wgrad_dgrad)
-        # RVIP_BWD_PAIR=1: the two gradients of a layer as ONE launch (rvip_conv3x3_wgrad_dgrad) instead of a fork / join.  Built and
-        # measured (round 5): it removes the ~18 us of cross-queue synchronisation per layer, but both halves must be 512-thread /
-        # 256-VGPR workgroups, i.e. the data gradient runs in its four-compute-wave form, which is ~16 % slower on the MFMA-bound
-        # layers than the eight-wave form: 4.66 ms against 4.50 (two launches) and 4.58 (one after the other), same box.  Opt-in.
-        self.bwd_pair = os.environ.get('RVIP_BWD_PAIR', '0') == '1'
+        # RVIP_BWD_PAIR (default 1): where rvip_conv3x3_wgrad_dgrad serves the layer (nine-tap forms, 16-bit types: 17 of the 21 layers of
+        # config 2) the two gradients are the two parts of ONE grid instead of two launches between a fork and a join of the graph --
+        # the cross-queue synchronisation of that schedule costs ~18 us per layer, most of what running side by side hides.
+        # Same box (round 5): one after the other 4.62, fork / join 4.60, pair kernel 4.52 ms; bit-identical gradients (tools/ab_pair.py).
+        self.bwd_pair = os.environ.get('RVIP_BWD_PAIR', '1') != '0'
         # Measured (round 5, same box, alternating): W = 128 4.650 -> 4.54 ms at config 2 (-2.4 %), BCE-Dice -3.0 %, config 4 +0.3 %;
         # 96 / 112 / 144 are SLOWER than one after the other (4.76 / 4.69 / 4.89: the tile counts no longer divide by the grids).
         ov = int(os.environ.get('RVIP_BWD_OVERLAP', '128') or 0)

@@ -235,12 +235,9 @@ int    rvip_conv3x3_wgrad_form(const rvip_wgrad3x3_desc* d);
 /* ABI 8 -- the weight gradient and the data gradient of one layer as ONE launch: rvip_conv3x3_wgrad(wd) and rvip_conv3x3_fwd_sums(dd,
  * sums_ws, ...) on the two parts of one grid, wd->cu_limit and dd->cu_limit compute units each (both set, their sum <= 256), followed by
  * the weight gradient's slab fold.  dd must be the data gradient of the same layer (dd->x0 == wd->dy, no bias / activation / sign_bits;
- * mask_bits, y1 / csplit and down2 as rvip_conv3x3_fwd_sums takes them).  The weight gradient and the data-gradient TENSOR are
- * bit-identical to the two calls with the same cu_limit values; the column-sum rows are summed over four compute waves instead of
- * eight (another fp32 order).  16-bit types, 2-D, nine-tap forms of both kernels; rvip_conv3x3_wgrad_dgrad_ok tells whether a pair is
- * served (0: launch the two entry points instead).  Measured slower than the two launches side by side on two streams (the data
- * gradient's 512-thread form, DESIGN section 4 "Round 5"): the engine uses it only on request (RVIP_BWD_PAIR=1).
- * Autodiff of Conv2D, KerasLayers.py:683,689. */
+ * mask_bits, y1 / csplit and down2 as rvip_conv3x3_fwd_sums takes them).  Every result is bit-identical to the two calls with the
+ * same cu_limit values.  16-bit types, 2-D, nine-tap forms of both kernels; rvip_conv3x3_wgrad_dgrad_ok tells whether a pair is
+ * served (0: launch the two entry points instead).  Autodiff of Conv2D, KerasLayers.py:683,689. */
 int    rvip_conv3x3_wgrad_dgrad_ok(const rvip_wgrad3x3_desc* wd, const rvip_conv3x3_desc* dd);
 int    rvip_conv3x3_wgrad_dgrad(const rvip_wgrad3x3_desc* wd, const rvip_conv3x3_desc* dd, float* sums_ws, size_t sums_ws_bytes, void* stream);
 
