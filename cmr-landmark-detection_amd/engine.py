@@ -846,6 +846,7 @@ class Engine(InputRing):
         # while gradient bucket 0 is in flight -- leave n CUs to RCCL's kernels (default 0).
         self.side_stream = None
         self.paired = []                                  # layers whose two gradients run as one launch (rvip_conv3x3_wgrad_dgrad)
+        self.bwd_mode = {}                                # conv name -> 'pair' | 'forkjoin' | 'serial'
         # RVIP_BWD_PAIR (default 1): where rvip_conv3x3_wgrad_dgrad serves the layer (nine-tap forms, 16-bit types: 17 of the 21 layers of
         # config 2) the two gradients are the two parts of ONE grid instead of two launches between a fork and a join of the graph --
         # the cross-queue synchronisation of that schedule costs ~18 us per layer, most of what running side by side hides.
@@ -904,6 +905,16 @@ class Engine(InputRing):
                 dg.y = self.up_tmp[st.conv].data_ptr()
             else:
                 dg.y = self.grd[st.src0].data_ptr()
+            # which schedule the layer's two gradients take (decided HERE: the partial-row / slab counts queried below follow cu_limit)
+            mode = 'serial'
+            if self.bwd_overlap:
+                if self.bwd_pair and L.rvip_conv3x3_wgrad_dgrad_ok(C.byref(wg), C.byref(dg)):
+                    mode = 'pair'
+                elif os.environ.get('RVIP_BWD_UNPAIRED', 'serial') == 'forkjoin':
+                    mode = 'forkjoin'
+                else:                           # (the sub-pixel forms of the up-conv layers: measured no faster between a fork and a join,
+                    wg.cu_limit = dg.cu_limit = avail if avail < 256 else 0      #  160 against 137 us for the 64 -> 32 layer at 256^2)
+            self.bwd_mode[st.conv] = mode
             self._keep += [wg, dg]
             wg_desc[st.conv], dg_desc[st.conv] = wg, dg
 
@@ -1126,7 +1137,8 @@ class Engine(InputRing):
                 wg.workspace, wg.workspace_bytes, wg.defer_fold = sbuf.data_ptr(), sbuf.numel() * 4, 1
                 wide.append((sbuf, P.g(st.conv, 'kernel'), ns, 9 * st.cin * st.cout))
             fuse_down = st.up0 == 1 and fuse_down_on
-            if self.bwd_overlap and self.bwd_pair and L.rvip_conv3x3_wgrad_dgrad_ok(C.byref(wg), C.byref(dg)):
+            mode = self.bwd_mode[st.conv]
+            if mode == 'pair':
                 # both kernels as the two parts of ONE grid (rvip_pair.hip): no fork / join of the graph, ~18 us per layer
                 if st.conv in sums_rows:
                     sb = sums_rows[st.conv][0]
@@ -1136,7 +1148,7 @@ class Engine(InputRing):
                 bwd.append((L.rvip_conv3x3_wgrad_dgrad, (C.byref(wg), C.byref(dg), _ptr(sb), C.c_size_t(sb.numel() * 4))))
                 self.paired.append(st.conv)
             else:
-                if self.bwd_overlap:        # weight gradient (+ its slab fold) on the second stream, beside the data gradient
+                if mode == 'forkjoin':      # weight gradient (+ its slab fold) on the second stream, beside the data gradient
                     bwd.append((_Fork(self), ()))
                     bwd.append((_OnSide(self, L.rvip_conv3x3_wgrad), (C.byref(wg),)))
                 else:
@@ -1146,7 +1158,7 @@ class Engine(InputRing):
                     bwd.append((L.rvip_conv3x3_fwd_sums, (C.byref(dg), _ptr(sb), C.c_size_t(sb.numel() * 4))))
                 else:
                     bwd.append((L.rvip_conv3x3_fwd, (C.byref(dg),)))
-                if self.bwd_overlap:
+                if mode == 'forkjoin':
                     bwd.append((_Join(self), ()))
             if st.up0 and not fuse_down:    # 1: UpSampling2D -> 2x2 sum; 2: zero-stuffed (Conv2DTranspose) -> odd positions
                 back = L.rvip_upsample2x_bwd if st.up0 == 1 else L.rvip_subsample_odd

@@ -11,8 +11,8 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 cfg = dict(DIM=[dim, dim], FILTERS=32, DEPTH=4, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2, LEARNING_RATE=1e-3, RVIP_PRECISION=prec, LOSS_FUNCTION=M.mse, SEED=11)
 x, y = O.synthetic_batch(B, cfg['DIM'], 2, seed=12)
 res = {}
-for tag, env in (('two', {'RVIP_BWD_PAIR': '0'}), ('one', {'RVIP_BWD_PAIR': '1'}), ('serial', {'RVIP_BWD_OVERLAP': '0'})):
-    for k in ('RVIP_BWD_PAIR', 'RVIP_BWD_OVERLAP'):
+for tag, env in (('two', {'RVIP_BWD_PAIR': '0', 'RVIP_BWD_UNPAIRED': 'forkjoin'}), ('one', {'RVIP_BWD_PAIR': '1', 'RVIP_BWD_UNPAIRED': 'forkjoin'}), ('serial', {'RVIP_BWD_OVERLAP': '0'})):
+    for k in ('RVIP_BWD_PAIR', 'RVIP_BWD_OVERLAP', 'RVIP_BWD_UNPAIRED'):
         os.environ.pop(k, None)
     os.environ.update(env)
     model = rvip.get_model(cfg, metrics=[])
