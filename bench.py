@@ -7,13 +7,17 @@ the 256x256 4-level U-Net with 2 heat-maps, bf16 activations / fp32 accumulate, 
            bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  ``value`` = slices all ranks processed / max-over-ranks wall time of exactly K steps
-with the synthetic batch already resident in HBM.  ``roofline`` is for the dominant kernel family (the MFMA
-implicit-GEMM conv, forward + data-gradient launches): achieved = algorithmic conv FLOPs of those launches /
-the duration of those launches, measured live with HIP events around replays of a hipGraph that holds exactly the
-family's launches of one step (back to back, as in the captured step; a per-launch eager pass would add the launch gaps) after the
-timed region; ``roofline.profile`` holds the same figure from the committed rocprofv3 kernel trace when it was taken on these
-kernel sources, ``roofline_wgrad`` the weight-gradient kernels the same way, ``kernels`` the per-entry-point eager table.  ``cpu_baseline`` (rank 0, N=1 only) times the same training step on the host cores with the PyTorch-CPU
-port in oracle/ (the reference's own TF2-CPU path cannot run here: no TensorFlow) on a bounded sample.
+with the synthetic batch already resident in HBM.  ``roofline`` is for the dominant kernel family -- every MFMA contraction launch
+of the step: the implicit-GEMM conv (forward with the fused BN statistics, data gradient), the weight gradient (with its slab fold)
+and the pair launches that run a layer's weight and data gradient as the two parts of one grid: achieved = the algorithmic conv
+FLOPs of those launches / their duration INSIDE the step, measured live with HIP events around every launch of eager steps after the
+timed region (each launch behind its producer, as in the captured step), minus the event pair's own cost calibrated on a trivial
+kernel in the same run; ``roofline.parts`` splits it by entry point, ``roofline.profile`` holds the same figure from the committed
+rocprofv3 kernel trace when it was taken on these kernel sources, ``kernels`` the per-entry-point eager table.  ``other_configs``:
+BASELINE.json configs[3] (fp16, 512^2, F = 64, depth 5), configs[4] per GPU (Conv3D cine volumes) and the Train notebook's BCE-Dice
+loss through the same product path, a few dozen steps each after everything the headline reports.  ``cpu_baseline`` (rank 0, N=1
+only) times the same training step on the host cores with the PyTorch-CPU port in oracle/ (the reference's own TF2-CPU path cannot
+run here: no TensorFlow) on a bounded sample.
 """
 import argparse
 import importlib
@@ -28,8 +32,8 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0       # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = 'r04_pmc_summary.json'
-KERNEL_STATS = 'r04_bench_kernel_stats.csv'          # rocprofv3 --kernel-trace --stats of this command (tools/profile_round.sh), + .meta.json
+PMC_SUMMARY = 'r05_pmc_summary.json'
+KERNEL_STATS = 'r05_bench_kernel_stats.csv'          # rocprofv3 --kernel-trace --stats of this command (tools/profile_round.sh), + .meta.json
 
 
 def csrc_sha16():
@@ -131,7 +135,6 @@ def main():
     import numpy as np
     import torch
     rvip = importlib.import_module('cmr-landmark-detection_amd')
-    capture_guard = importlib.import_module('cmr-landmark-detection_amd.engine').capture_guard
     M = rvip.Loss_and_metrics
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -229,6 +232,7 @@ def main():
         s = torch.cuda.current_stream()
         L = rvip._native.lib()
         conv_fn, conv_stats_fn, conv_sums_fn, wgrad_fn = L.rvip_conv3x3_fwd, L.rvip_conv3x3_fwd_stats, L.rvip_conv3x3_fwd_sums, L.rvip_conv3x3_wgrad
+        pair_fn = L.rvip_conv3x3_wgrad_dgrad           # weight + data gradient of a layer as the two parts of one grid
         reps = 5
         agg = {}
         detail = []
@@ -274,6 +278,9 @@ def main():
                     elif fn is wgrad_fn:
                         d = a[0]._obj
                         flops = 2.0 * d.n * d.h * d.w * 9 * max(d.kd, 1) * (d.c0 + d.c1) * d.cout
+                    elif fn is pair_fn:                 # both gradients of the layer: twice the layer's forward FLOPs
+                        d = a[0]._obj
+                        flops = 2.0 * 2.0 * d.n * d.h * d.w * 9 * (d.c0 + d.c1) * d.cout
                     agg.setdefault(fn.__name__, []).append((e0, e1, flops))
                     if flops > 0:
                         detail.append((fn.__name__, (d.n, d.h, d.w, d.c0 + d.c1, d.cout, d.up0, 1 if d.c1 else 0), e0, e1, flops))
@@ -294,45 +301,28 @@ def main():
             fl = sum(f for _, _, f in evs)
             per_kernel[name] = dict(launches_per_step=len(evs) // reps, ms_per_step=round(ms / reps, 4),
                                     tflops=round(fl / (ms * 1e-3) / 1e12, 2) if (fl > 0 and ms > 0) else None)
-        cv = agg['rvip_conv3x3_fwd'] + agg.get('rvip_conv3x3_fwd_stats', []) + agg.get('rvip_conv3x3_fwd_sums', [])
-        fl = sum(f for _, _, f in cv)
+        # THE family of the roofline: every MFMA contraction launch of the step -- the implicit-GEMM conv (forward, with the fused BN
+        # statistics; data gradient), the weight gradient, and the pair launches that hold a layer's weight AND data gradient as the two
+        # parts of one grid (a weight-gradient entry point includes its slab fold: the event pair brackets the C call).  Time = the
+        # launches INSIDE the step (every launch behind its producer, as in the captured step and in the rocprofv3 kernel trace): HIP
+        # events around each launch of the eager pass above, minus the calibrated event-pair cost.
+        FAMILY = ('rvip_conv3x3_fwd', 'rvip_conv3x3_fwd_stats', 'rvip_conv3x3_fwd_sums', 'rvip_conv3x3_wgrad', 'rvip_conv3x3_wgrad_dgrad')
+        TRACE_NAMES = ('conv3x3_igemm', 'wgrad3x3_', 'wgrad_dgrad_pair', 'wgrad_fold')       # the same launches in a kernel trace
 
-        def family_ms(calls, nrep=20):
-            """ms per step of `calls` launched back to back: a hipGraph of exactly these launches, replayed nrep times between two events"""
-            g = torch.cuda.CUDAGraph()
-            with capture_guard(), torch.cuda.graph(g):
-                cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-                for fn, a in calls:
-                    assert fn(*a, cs) == 0
-            g.replay()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s)
-            for _ in range(nrep):
-                g.replay()
-            e1.record(s)
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / nrep
-        conv_calls = [(th[0], th[1]) for seq in (eng.fwd_train, eng.bwd) for th in seq if th[0] in (conv_fn, conv_stats_fn, conv_sums_fn)]
-        fam_alone_ms = family_ms(conv_calls)    # informational: the same launches WITHOUT their producers in front (inputs cache-cold)
-        # THE roofline time: the family's launches inside the step (every launch behind its producer, as in the captured step and in
-        # the rocprofv3 kernel trace): HIP events around each launch of the eager pass above, minus the calibrated event-pair cost
-        fam_ms = max(sum(a.elapsed_time(b) for a, b, _ in cv) / reps - ev_ovh_ms * (len(cv) // reps), 1e-6)
+        def part(names):
+            evs = [e for nm in names for e in agg.get(nm, [])]
+            if not evs:
+                return None
+            ms_ = max(sum(x.elapsed_time(y) for x, y, _ in evs) / reps - ev_ovh_ms * (len(evs) // reps), 1e-6)
+            fl_ = sum(f for _, _, f in evs) / reps
+            return {'launches_per_step': len(evs) // reps, 'ms_per_step': round(ms_, 4), 'gflop_per_step': round(fl_ / 1e9, 2),
+                    'achieved': round(fl_ / (ms_ * 1e-3) / 1e12, 2), 'frac': round(fl_ / (ms_ * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3), 4)}
+        cv = [e for nm in FAMILY for e in agg.get(nm, [])]
+        fl = sum(f for _, _, f in cv)
+        fam_ms = max(sum(x.elapsed_time(y) for x, y, _ in cv) / reps - ev_ovh_ms * (len(cv) // reps), 1e-6)
         achieved = (fl / reps) / (fam_ms * 1e-3) / 1e12
-        ms = fam_ms * reps                     # (kept for avg_launch_ms below: per-step family time x the eager pass's repetitions)
-        # weight-gradient kernels alone: the same descriptors with the fold left out (slabs to the shared workspace)
-        wg_calls, wg_keep, wg_fl = [], [], 0.0
-        for th in eng.bwd:
-            if getattr(th[0], 'fn', th[0]) is wgrad_fn:
-                d0 = th[1][0]._obj
-                d1 = type(d0).from_buffer_copy(d0)
-                if max(d0.kd, 1) == 1:
-                    d1.defer_fold, d1.dot_rows, d1.w_master, d1.w_phase = 1, None, None, None
-                    d1.workspace, d1.workspace_bytes = eng.ws_wg.data_ptr(), eng.ws_wg_bytes
-                wg_keep.append(d1)
-                wg_calls.append((wgrad_fn, (C.byref(d1),)))
-                wg_fl += 2.0 * d0.n * d0.h * d0.w * 9 * max(d0.kd, 1) * (d0.c0 + d0.c1) * d0.cout
-        wg_ms = family_ms(wg_calls) if wg_calls else None
+        parts = {nm: part((nm,)) for nm in FAMILY if agg.get(nm)}          # per entry point: forward with fused BN statistics / forward without
+        #                                                                       (up-convs) / data gradient alone / weight gradient alone + fold / pair
         traffic, traffic_src, hbm_step, pmc_note = None, None, None, None
         try:                                   # HBM bytes per launch of this kernel family from the committed PMC passes of THESE kernels
             pm = json.load(open(os.path.join(ROOT, 'profiles', PMC_SUMMARY)))
@@ -341,12 +331,12 @@ def main():
             elif pm.get('workload') != workload_key(args):
                 pmc_note = '%s is for workload %s' % (PMC_SUMMARY, pm.get('workload'))
             else:
-                fam = [v for k, v in pm['kernels'].items() if k.startswith('conv3x3_igemm')]
+                fam = [v for k, v in pm['kernels'].items() if any(k.startswith(t) for t in TRACE_NAMES)]
                 if not fam:
-                    pmc_note = '%s holds no conv3x3_igemm kernel' % PMC_SUMMARY
+                    pmc_note = '%s holds no kernel of the family' % PMC_SUMMARY
                 else:
-                    traffic = round(sum(f['hbm_bytes_per_launch'] * f['launches_per_step'] for f in fam) / sum(f['launches_per_step'] for f in fam))
-                    traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2, KiB units)' % PMC_SUMMARY
+                    traffic = round(sum(f['hbm_bytes_per_launch'] * f['launches_per_step'] for f in fam) / max(len(cv) // reps, 1))
+                    traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2, KiB units; bytes of the family per step / its entry-point launches)' % PMC_SUMMARY
                     hbm_step = pm.get('hbm_bytes_per_step')
         except FileNotFoundError:
             pmc_note = 'profiles/%s missing' % PMC_SUMMARY
@@ -354,7 +344,7 @@ def main():
             traffic, traffic_src, hbm_step = None, None, None
             pmc_note = 'profiles/%s unusable (%s: %s)' % (PMC_SUMMARY, type(e).__name__, e)
         # the same family in the committed rocprofv3 kernel trace of this command (captured step), when taken on THESE sources
-        prof, prof_wg = None, None
+        prof = None
         try:
             import csv
             meta = json.load(open(os.path.join(ROOT, 'profiles', KERNEL_STATS + '.meta.json')))
@@ -363,8 +353,7 @@ def main():
             else:
                 rows_ = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', KERNEL_STATS))))
                 steps_p = max(int(r['Calls']) for r in rows_ if 'adam_kernel' in r['Name'])
-                fam_ns = sum(float(r['TotalDurationNs']) for r in rows_ if 'conv3x3_igemm' in r['Name'])
-                wg_ns = sum(float(r['TotalDurationNs']) for r in rows_ if 'wgrad3x3_' in r['Name'])
+                fam_ns = sum(float(r['TotalDurationNs']) for r in rows_ if any(t in r['Name'] for t in TRACE_NAMES))
                 pa = (fl / reps) / (fam_ns / steps_p * 1e-9) / 1e12
                 all_ns = sum(float(r['TotalDurationNs']) for r in rows_ if 'at::native' not in r['Name'] and 'rocclr' not in r['Name'])
                 # boxes differ by several per cent in clock: besides the absolute rate, compare the family's SHARE of the step
@@ -372,33 +361,22 @@ def main():
                         'achieved': round(pa, 2), 'live_over_profile': round(achieved / pa, 4),
                         'step_ms_kernel_sum': round(all_ns / steps_p * 1e-6, 4), 'family_share_of_step': round(fam_ns / all_ns, 4),
                         'live_family_share_of_step': round(fam_ms / (1e3 * elapsed / args.steps), 4)}
-                if wg_ns > 0 and wg_ms:
-                    pw = wg_fl / (wg_ns / steps_p * 1e-9) / 1e12
-                    prof_wg = {'file': 'profiles/' + KERNEL_STATS, 'family_ms_per_step': round(wg_ns / steps_p * 1e-6, 4), 'achieved': round(pw, 2),
-                               'live_over_profile': round(wg_fl / (wg_ms * 1e-3) / 1e12 / pw, 4)}
         except FileNotFoundError:
             prof = {'file': 'profiles/' + KERNEL_STATS, 'note': 'missing'}
         except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError) as e:
             prof = {'file': 'profiles/' + KERNEL_STATS, 'note': 'unusable (%s: %s)' % (type(e).__name__, e)}
-        roof = dict(bound='mfma', kernel='conv3x3_igemm (forward incl. fused BN statistics + data-gradient launches)', achieved=round(achieved, 2),
-                    peak=PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3, unit='TFLOP/s',
-                    frac=round(achieved / (PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3), 4),
+        peak_ = PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3
+        esz_ = 2 if args.precision != 'fp32' else 4
+        roof = dict(bound='mfma', kernel='MFMA contraction launches of the step: conv3x3_igemm_ws16 (forward incl. fused BN statistics, data gradient), wgrad3x3_ws '
+                                         '(+ slab fold) and wgrad_dgrad_pair (a layer\'s weight and data gradient as the two parts of one grid)',
+                    achieved=round(achieved, 2), peak=peak_, unit='TFLOP/s', frac=round(achieved / peak_, 4),
                     traffic=traffic, traffic_source=traffic_src, traffic_note=pmc_note,
-                    algorithmic_bytes_per_launch=round(plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * 2.0 / 3.0 * B / max(len(cv) // reps, 1)),
-                    launches_per_step=len(cv) // reps, avg_launch_ms=round(ms / len(cv), 4),
-                    flops_per_launch=fl / len(cv), family_ms_per_step=round(fam_ms, 4),
+                    algorithmic_bytes_per_launch=round(plan.ideal_bytes_per_slice(esz_) * B / max(len(cv) // reps, 1)),
+                    launches_per_step=len(cv) // reps, avg_launch_ms=round(fam_ms / max(len(cv) // reps, 1), 4),
+                    flops_per_launch=fl / max(len(cv), 1), family_ms_per_step=round(fam_ms, 4), gflop_per_step=round(fl / reps / 1e9, 2),
                     timing='HIP events around every launch of the family inside %d eager steps (each launch behind its producer, as in the captured step), '
                            'minus what the event pair adds to a reading (%.2f us, calibrated on a trivial kernel in this run) per launch' % (reps, 1e3 * ev_ovh_ms),
-                    family_alone_ms_per_step=round(fam_alone_ms, 4),
-                    family_alone_note='hipGraph of ONLY the family\'s launches replayed back to back: every input was written a whole family pass earlier '
-                                      '(cold in L2 / Infinity Cache); informational, not the roofline time',
-                    profile=prof)
-        peak_ = PEAK_BF16_TFLOPS if args.precision != 'fp32' else 157.3
-        roof_wg = None
-        if wg_ms:
-            wa = wg_fl / (wg_ms * 1e-3) / 1e12
-            roof_wg = dict(bound='mfma', kernel='wgrad3x3 (weight-gradient kernels without their slab fold)', achieved=round(wa, 2), peak=peak_, unit='TFLOP/s',
-                           frac=round(wa / peak_, 4), launches_per_step=len(wg_calls), family_ms_per_step=round(wg_ms, 4), profile=prof_wg)
+                    parts=parts, profile=prof)
 
     # ---- the product's own loop: Model.fit on a SyntheticSAXGenerator held in memory (the reference trains with in_memory=True,
     # train_model.py:199-203): generator -> rank shard -> pinned ring -> copy stream -> replayed step, per-epoch logs.  Reported
@@ -452,7 +430,6 @@ def main():
             'loss': loss, 'steps_executed_total': max(2, min(args.warmup, 3)) + args.warmup + args.steps + (0 if args.no_roofline_pass else 3),
             'other_configs': other,
             'roofline': roof,
-            'roofline_wgrad': roof_wg if roof is not None else None,
             'kernels': per_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:

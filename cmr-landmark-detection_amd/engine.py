@@ -908,7 +908,10 @@ class Engine(InputRing):
             # which schedule the layer's two gradients take (decided HERE: the partial-row / slab counts queried below follow cu_limit)
             mode = 'serial'
             if self.bwd_overlap:
-                if self.bwd_pair and L.rvip_conv3x3_wgrad_dgrad_ok(C.byref(wg), C.byref(dg)):
+                # (what the pair hides is the launches' fixed cost: nothing on layers that run for hundreds of microseconds -- config 4,
+                #  same box: 516.6 slices/s paired against 524.9 one after the other -- so only layers below a FLOP count take it)
+                small = 2.0 * n * st.h * st.w * 9 * st.cin * st.cout <= float(os.environ.get('RVIP_BWD_PAIR_MAX_GFLOP', '100')) * 1e9
+                if self.bwd_pair and small and L.rvip_conv3x3_wgrad_dgrad_ok(C.byref(wg), C.byref(dg)):
                     mode = 'pair'
                 elif os.environ.get('RVIP_BWD_UNPAIRED', 'serial') == 'forkjoin':
                     mode = 'forkjoin'

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round profile on the GPU box (one MI355X): kernel-trace statistics of the benchmark command, the two HBM-traffic PMC passes
 # (FETCH_SIZE / WRITE_SIZE in runs of their own, --kernel-trace only), an MFMA-busy pass, and the summaries bench.py / DESIGN.md cite.
-#   gpurun -- 'bash tools/profile_round.sh r04'
+#   gpurun -- 'bash tools/profile_round.sh r05'
 set -e -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-fit --no-aux --no-roofline-pass"      # only training steps in the traces
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-fit --no-aux --no-other-configs --no-roofline-pass"      # only training steps in the traces
 # 1. the benchmarked command itself (captured step), per-kernel durations
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- $BENCH --steps 50 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 # 2./3. HBM traffic: eager launches (one dispatch per kernel), few steps; the step count comes from the bench line itself
@@ -30,7 +30,7 @@ python3 - <<PY > $OUT/${TAG}_bench_kernel_stats.csv.meta.json
 import json, sys
 sys.path.insert(0, "$ROOT/tools")
 import pmc_summary
-print(json.dumps({"csrc_sha16": pmc_summary.csrc_sha16(), "workload": "dim256_f32_d4_b32_t0_bf16", "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-fit --no-aux --no-roofline-pass --steps 50 --warmup 5"}))
+print(json.dumps({"csrc_sha16": pmc_summary.csrc_sha16(), "workload": "dim256_f32_d4_b32_t0_bf16", "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-fit --no-aux --no-other-configs --no-roofline-pass --steps 50 --warmup 5"}))
 PY
 # keep the merge-back small: the raw traces stay on the box
 rm -rf $OUT/stats $OUT/pmc_f/*/*kernel_trace* 2>/dev/null || true
