@@ -25,31 +25,32 @@ namespace rvip {
 // NCW = compute waves of BOTH halves' workgroups: 8 (768 threads, <= 168 VGPRs: the igemm's eight-compute-wave form of the 512-pixel
 // tiles + the weight gradient with its taps split over two waves, TS = 2) or 4 (512 threads: the forms the 256-pixel tiles of the
 // 16-wide maps use anyway)
-template <typename T, int TW, int CIB, int COB, int NSTW, int NCT, int NPIX, int STATS, int NCW>
+// TAPS = 4: the sub-pixel forms of an UpSampling2D -> conv layer (four-phase weight gradient, data gradient with subpix = 2)
+template <typename T, int TW, int CIB, int COB, int NSTW, int NCT, int NPIX, int STATS, int NCW, int TAPS>
 __global__ __launch_bounds__((NCW + 4) * 64, 1) void wgrad_dgrad_pair(WgArgs2 wa, ConvArgs2 ca, int nw, int wgx, int wgy, int dgx) {
     if ((int)blockIdx.x < nw) {
         const unsigned id = blockIdx.x, r = id / (unsigned)wgx;
-        wgrad3x3_ws_body<T, TW, CIB, COB, NSTW, 9, 0, NCW / 4>(wa, id % (unsigned)wgx, r % (unsigned)wgy, r / (unsigned)wgy, (unsigned)wgx);
+        wgrad3x3_ws_body<T, TW, CIB, COB, NSTW, TAPS, 0, NCW / 4>(wa, id % (unsigned)wgx, r % (unsigned)wgy, r / (unsigned)wgy, (unsigned)wgx);
     } else {
         const int id = (int)blockIdx.x - nw;
-        igemm_ws16_body<T, TW, NCT, NPIX, STATS, 9, NCW>(ca, id % dgx, id / dgx, 0, dgx);
+        igemm_ws16_body<T, TW, NCT, NPIX, STATS, TAPS, NCW>(ca, id % dgx, id / dgx, 0, dgx);
     }
 }
 
-template <typename T, int TW, int CIB, int COB, int NCT, int NPIX, int STATS, int NCW>
+template <typename T, int TW, int CIB, int COB, int NCT, int NPIX, int STATS, int NCW, int TAPS = 9>
 static int launch_pair(const WgArgs2& wa, const IgemmPlan& dp, hipStream_t s, bool dry) {
     // LDS of the weight-gradient half: launch_wgrad2x's arithmetic (the stage count is a template parameter of the body)
     constexpr int TH = 256 / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
     constexpr int ST = NHROWS * CIB * 2 + 256 * COB * 2;
     constexpr int NSTW = 3 * ST <= 160 * 1024 ? 3 : 2;
-    constexpr int FOLD = (CIB / 32) * (COB / 32) < 4 ? 4 * 9 * 32 * 32 * 4 : 0;
+    constexpr int FOLD = (CIB / 32) * (COB / 32) < 4 ? 4 * TAPS * 32 * 32 * 4 : 0;
     constexpr int lds_w = NSTW * ST > FOLD ? NSTW * ST : FOLD;
     static_assert(lds_w <= 160 * 1024, "LDS");
     if (dp.gz != 1 || dp.lds > 160 * 1024) return RVIP_EUNSUPPORTED;
     if (dry) return RVIP_OK;
     const int lds = lds_w > dp.lds ? lds_w : dp.lds;
-    auto kern = &wgrad_dgrad_pair<T, TW, CIB, COB, NSTW, NCT, NPIX, STATS, NCW>;
+    auto kern = &wgrad_dgrad_pair<T, TW, CIB, COB, NSTW, NCT, NPIX, STATS, NCW, TAPS>;
     static std::atomic<bool> attr_done{false};
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -63,10 +64,10 @@ static int launch_pair(const WgArgs2& wa, const IgemmPlan& dp, hipStream_t s, bo
 }
 
 // the data-gradient half: the tiling dispatch_igemm_ws takes for this shape, in its four-compute-wave (512-thread) instantiation
-template <typename T, int TW, int NCT, int NPIX, int NCW>
+template <typename T, int TW, int NCT, int NPIX, int NCW, int TAPS = 9>
 static int plan_dgrad(const ConvArgs& a, float* sums, IgemmPlan& p) {
     bool used = false;
-    const int rc = launch_igemm_ws<T, true, TW, NCT, NPIX, 9, NCW, true>(a, nullptr, used, sums, nullptr, false, 2, &p);
+    const int rc = launch_igemm_ws<T, true, TW, NCT, NPIX, TAPS, NCW, true>(a, nullptr, used, sums, nullptr, false, 2, &p);
     if (rc) return rc;
     return used ? RVIP_OK : RVIP_EUNSUPPORTED;
 }
@@ -76,12 +77,14 @@ static int pair_dispatch(const rvip_wgrad3x3_desc* wd, const rvip_conv3x3_desc* 
     WgradPlan wp;
     int rc = wgrad_plan(wd, wp);
     if (rc) return rc;
-    if (wp.b.sp) return RVIP_EUNSUPPORTED;                  // (the sub-pixel forms of the up-conv layers keep their own launches)
+    if (wp.b.sp == 2) return RVIP_EUNSUPPORTED;             // (the phase-pair form, two dY tiles per stage, keeps its own launch)
     ConvArgs a;
     rc = conv_args_from_desc(dd, a);
     if (rc) return rc;
-    if (a.kd != 1 || a.subpix || a.c1 || a.up0 || dd->dtype != wd->dtype || !sums_ws) return RVIP_EUNSUPPORTED;
-    if (a.n != wp.b.n || a.h != wd->h || a.w != wd->w || a.cin != wd->cout || dd->x0 != wd->dy) return RVIP_EINVAL;      // the same layer, the same dz
+    const bool sub = wp.b.sp == 1;                          // four-phase weight gradient <-> data gradient in sub-pixel form (subpix = 2)
+    if (sub != (a.subpix == 2) || a.subpix == 1) return RVIP_EUNSUPPORTED;
+    if ((!sub && a.kd != 1) || a.c1 || a.up0 || dd->dtype != wd->dtype || !sums_ws) return RVIP_EUNSUPPORTED;
+    if (dd->n != wd->n || dd->h != wd->h || dd->w != wd->w || a.cin != wd->cout || dd->x0 != wd->dy) return RVIP_EINVAL;      // the same layer, the same dz
     if (dd->bias || dd->act != RVIP_ACT_NONE) return RVIP_EINVAL;
     const bool gated = dd->mask_bits != nullptr;
     if (dd->sign_bits) return RVIP_EINVAL;
@@ -96,12 +99,14 @@ static int pair_dispatch(const rvip_wgrad3x3_desc* wd, const rvip_conv3x3_desc* 
         const long long ntiles = (long long)a.n * cdiv(a.w, tw) * cdiv(a.h, tpx / tw);
         if (ntiles * cdiv(a.cout, 64) <= a.cus / 2) two = false;
     }
+    if (sub) two = a.cout > 32;                            // (dispatch_igemm_ws: the sub-pixel forms keep 64-channel columns)
+    if (sub && gated) return RVIP_EUNSUPPORTED;
     const int tw = wp.g.tw, cib = wp.g.cib, cob = wp.g.cob;
     if (a.w > 16 && a.h < 16) return RVIP_EUNSUPPORTED;    // (32-wide, 256-pixel tiles: no layer of the benchmark graphs)
     if ((a.w > 16 ? 32 : 16) != tw) return RVIP_EUNSUPPORTED;
     IgemmPlan dp;
 #define RVIP_PAIR(TWv, CIBv, COBv, NCTv, NPIXv)                                                                                   \
-    if (tw == TWv && cib == CIBv && cob == COBv && two == (NCTv == 2)) {                                                            \
+    if (!sub && tw == TWv && cib == CIBv && cob == COBv && two == (NCTv == 2)) {                                                            \
         rc = plan_dgrad<T, TWv, NCTv, NPIXv, (NPIXv == 512 ? 8 : 4)>(a, sums_ws, dp);                                              \
         if (rc) return rc;                                                                                                         \
         if (sums_ws_bytes < (size_t)dp.gx * a.cout * sizeof(float)) return RVIP_EWORKSPACE;                                        \
@@ -117,6 +122,16 @@ static int pair_dispatch(const rvip_wgrad3x3_desc* wd, const rvip_conv3x3_desc* 
     RVIP_PAIR(16, 64, 64, 1, 256)
     RVIP_PAIR(16, 64, 64, 2, 256)
 #undef RVIP_PAIR
+#define RVIP_PAIR4(TWv, NCTv, NPIXv)                                                                                                \
+    if (sub && tw == TWv && cib == 64 && cob == 64 && two == (NCTv == 2)) {                                                         \
+        rc = plan_dgrad<T, TWv, NCTv, NPIXv, (NPIXv == 512 ? 8 : 4), 4>(a, sums_ws, dp);                                           \
+        if (rc) return rc;                                                                                                         \
+        if (sums_ws_bytes < (size_t)dp.gx * a.cout * sizeof(float)) return RVIP_EWORKSPACE;                                        \
+        return launch_pair<T, TWv, 64, 64, NCTv, NPIXv, 2, (NPIXv == 512 ? 8 : 4), 4>(wp.b, dp, s, dry);                           \
+    }
+    RVIP_PAIR4(32, 2, 512)
+    RVIP_PAIR4(16, 2, 256)
+#undef RVIP_PAIR4
     return RVIP_EUNSUPPORTED;
 }
 
@@ -145,5 +160,5 @@ extern "C" int rvip_conv3x3_wgrad_dgrad(const rvip_wgrad3x3_desc* wd, const rvip
     hipStream_t s = (hipStream_t)stream;
     const int rc = pair_entry(wd, dd, sums_ws, sums_ws_bytes, s, false);
     if (rc) return rc;
-    return wgrad_finish(wd, rvip_conv3x3_wgrad_splits(wd), 0, s);
+    return wgrad_finish(wd, rvip_conv3x3_wgrad_splits(wd), rvip_conv3x3_wgrad_form(wd) == 1 ? 1 : 0, s);
 }

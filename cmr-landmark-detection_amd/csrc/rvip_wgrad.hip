@@ -424,15 +424,16 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
 // (X 45 KB + 2 x 16 KB), i.e. the full-resolution layer 64 -> 32 at 256^2, which the four-phase form could not speed up.
 // (a device function of the workgroup's coordinates: bx_ = pixel split [x phase], by_ / bz_ = input / output channel block, gdx_ = the
 //  grid's x extent -- rvip_pair.hip runs it in a part of the grid of its weight / data gradient pair kernel)
-// TS = 2 (nine taps, 16-bit types): EIGHT compute waves -- every (pair, pixel part) of the four-wave form twice, once for taps 0..4 and
-// once for taps 5..8 (80 / 64 accumulator registers instead of 144) -- so that the workgroup is 12 waves at <= 168 VGPRs, the shape of
+// TS = 2 (16-bit types, one dY tile per stage): EIGHT compute waves -- every (pair, pixel part) of the four-wave form twice, once for
+// taps 0..4 and once for taps 5..8 of the nine (80 / 64 accumulator registers instead of 144), 0..1 and 2..3 of the sub-pixel form's four -- so that the workgroup is 12 waves at <= 168 VGPRs, the shape of
 // the eight-compute-wave igemm: the two can then be the two parts of one grid (rvip_pair.hip).  Both tap halves read the same dY
 // fragments; the X fragments, the MFMA count and the slab are those of the four-wave form.
 template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9, int PB = 0, int TS = 1>
 __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigned bx_, const unsigned by_, const unsigned bz_, const unsigned gdx_) {
     static_assert(TAPS == 9 || (TAPS == 4 && sizeof(T) == 2), "taps");
     static_assert(PB == 0 || TAPS == 4, "phase pairs belong to the sub-pixel form");
-    static_assert(TS == 1 || (TS == 2 && TAPS == 9 && sizeof(T) == 2), "tap halves: the nine-tap form of the 16-bit types");
+    static_assert(TS == 1 || (TS == 2 && PB == 0 && sizeof(T) == 2), "tap halves: the forms with one dY tile per stage, 16-bit types");
+    constexpr int HT = (TAPS + 1) / 2;                                // taps of the first half (TS = 2): 5 of 9, 2 of 4
     constexpr int NCWV = 4 * TS;                                      // compute waves
     constexpr bool SP = TAPS == 4;
     constexpr int NG = PB ? 2 : 1;                                    // dY phase tiles per stage
@@ -456,7 +457,7 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
     const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wv8 >= NCWV;
     const int wv = wv8 & 3;                                           // compute wave id within its tap half / loader wave id
-    const int th = TS == 2 ? wv8 >> 2 : 0;                            // tap half of a compute wave (TS = 2: 0 -> taps 0..4, 1 -> taps 5..8)
+    const int th = TS == 2 ? wv8 >> 2 : 0;                            // tap half of a compute wave (TS = 2: 0 -> taps 0..HT-1, 1 -> the rest)
     // Sub-pixel form: the four phases of a pixel split read the same X tiles and the four interleaved quarters of the same dY lines
     // (a pixel of a 32-channel dY is half a 128-byte line).  Workgroups go to the 8 XCDs round-robin, so with a grid of whole
     // groups of 32 the phases of split s are the workgroups 8 apart -- same XCD, same L2, running side by side; otherwise every line
@@ -573,7 +574,7 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
     }
 
     // (T0, T1): this wave's taps.  acc[lt] belongs to tap T0 + lt (TS = 1: all of them, lt = gph * TAPS + t)
-    constexpr int MYT = TS == 2 ? 5 : NG * TAPS;
+    constexpr int MYT = TS == 2 ? HT : NG * TAPS;
     f32x16 acc[MYT];
 #pragma unroll
     for (int t = 0; t < MYT; ++t)
@@ -661,8 +662,8 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
         }
     }
     };
-    if (TS == 2 && th == 1) tile_loop(std::integral_constant<int, 5>{}, std::integral_constant<int, 9>{});
-    else tile_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, TS == 2 ? 5 : TAPS>{});
+    if (TS == 2 && th == 1) tile_loop(std::integral_constant<int, HT>{}, std::integral_constant<int, TAPS>{});
+    else tile_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, TS == 2 ? HT : TAPS>{});
 
     // results: one 9 x 32 x 32 fp32 block per (ci_t, co_t) pair; waves that split the pixels fold through LDS
     asm volatile("s_barrier" ::: "memory");                           // every stage has been consumed by every compute wave
@@ -676,8 +677,8 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
             if (SP ? (2 * tap_of(pa, t9 / 3) + tap_of(pb, t9 % 3) != t) : (t != t9)) continue;           // wave-uniform
-            if (TS == 2 && (t < 5) != (th == 0)) continue;                                               // the other tap half's
-            const int lt = TS == 2 ? (t < 5 ? t : t - 5) : t;
+            if (TS == 2 && (t < HT) != (th == 0)) continue;                                              // the other tap half's
+            const int lt = TS == 2 ? (t < HT ? t : t - HT) : t;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + ci_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf, co = co0 + co_t * 32 + j;
@@ -697,7 +698,7 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
         float* red = reinterpret_cast<float*>(smem) + (part * PAIRS + pair) * BLK;   // [PSPLIT][PAIRS][9][32][32]
 #pragma unroll
         for (int lt = 0; lt < MYT; ++lt) {
-            const int t = TS == 2 ? lt + 5 * th : lt;
+            const int t = TS == 2 ? lt + HT * th : lt;
             if (t < NG * TAPS) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) red[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j] = acc[lt][r];
@@ -733,9 +734,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     wgrad3x3_ws_body<T, TW, CIB, COB, NST, TAPS, PB>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
-template <typename T, int TW, int CIB, int COB, int NST = 2>
+template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9>
 __global__ __launch_bounds__(768, 1) void wgrad3x3_ws12(WgArgs2 a) {
-    wgrad3x3_ws_body<T, TW, CIB, COB, NST, 9, 0, 2>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+    wgrad3x3_ws_body<T, TW, CIB, COB, NST, TAPS, 0, 2>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
 // dw[i] = sum_k slab[k][i] in a fixed order (reproducible).  A thread owns four consecutive elements (one 16-byte load per slab);
@@ -1028,17 +1029,17 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid((unsigned)a.nsplit, (unsigned)cdiv(a.cin, CIB), (unsigned)cdiv(a.cout, COB));
-    if constexpr (WS && TAPS == 9 && PB == 0 && sizeof(T) == 2) {
+    if constexpr (WS && PB == 0 && sizeof(T) == 2) {
         // (A/B: the eight-compute-wave form -- the taps split between two waves -- as a launch of its own)
         static const bool ws12 = [] { const char* e = getenv("RVIP_WGRAD_WS12"); return e && e[0] == '1'; }();
         if (ws12) {
             static std::atomic<bool> attr12{false};
             if (!attr12) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws12<T, TW, CIB, COB, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws12<T, TW, CIB, COB, NST, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
                 attr12 = true;
             }
-            hipLaunchKernelGGL((wgrad3x3_ws12<T, TW, CIB, COB, NST>), grid, dim3(768), lds, s, a);
+            hipLaunchKernelGGL((wgrad3x3_ws12<T, TW, CIB, COB, NST, TAPS>), grid, dim3(768), lds, s, a);
             return check_launch();
         }
     }
