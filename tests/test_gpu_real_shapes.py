@@ -666,3 +666,83 @@ def test_three_input_stages_equal_two(case, dtype, monkeypatch):
     assert float(outs[0][0].float().abs().max()) > 0
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b), case
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('idx', range(len(CFG2)), ids=[s_[0].replace(' ', '_') for s_ in CFG2])
+def test_weight_and_data_gradient_as_one_launch_equal_the_two_calls(idx, dtype):
+    """rvip_conv3x3_wgrad_dgrad (round 5, include/rvip_hip.h): a layer's weight gradient and data gradient as the two parts of one
+    grid, cu_limit compute units each, against rvip_conv3x3_wgrad + rvip_conv3x3_fwd_sums with the same limits -- the data-gradient
+    tensor(s), the column-sum rows, dw and the sum W*dW rows bit for bit -- at every layer shape of config 2, in the mode the engine
+    launches the layer's data gradient in (plain / gated by Dropout keep bits / split into the concat halves / sub-pixel form of an
+    up-conv).  The two calls themselves are held to the float64 oracle by the tests above.  Autodiff of Conv2D, KerasLayers.py:683,689."""
+    name, n, h, c0, up0, c1, co, bn = ALL[idx]
+    w_ = h
+    ci = c0 + c1
+    k = _case(idx)
+    L = N.lib()
+    T = tdt(dtype)
+    x0d = up(k['x0'], dtype)
+    x1d = up(k['x1'], dtype) if c1 else None
+    dyd = up(k['dy'], dtype)
+    _, wd_packed = pack(k['wt'], dtype)
+    wmaster = f32(np.ascontiguousarray(k['wt']))
+
+    def run(paired):
+        wsb = L.rvip_conv3x3_wgrad_workspace(n, h, w_, ci, co)
+        ws = torch.zeros(wsb // 4 + 16, dtype=torch.float32, device=dev())
+        dw = torch.full((3, 3, ci, co), 7.0, dtype=torch.float32, device=dev())
+        g = N.Wgrad3x3Desc()
+        g.x0, g.c0, g.up0 = x0d.data_ptr(), c0, up0
+        g.x1, g.c1 = (x1d.data_ptr(), c1) if c1 else (None, 0)
+        g.dy, g.dw = dyd.data_ptr(), dw.data_ptr()
+        g.n, g.h, g.w, g.cout, g.dtype = n, h, w_, co, ndt(dtype)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), wsb
+        g.cu_limit = 128
+        nd = L.rvip_conv3x3_wgrad_dot_rows(C.byref(g))
+        dots = torch.zeros(nd * ci, dtype=torch.float64, device=dev())
+        g.w_master, g.dot_rows, g.dot_rows_bytes = wmaster.data_ptr(), dots.data_ptr(), dots.numel() * 8
+        keep = []
+        if c1:                                     # the concat layer's data gradient: two outputs, the up-conv half gated by its sign bits
+            g0, g1 = torch.zeros((n, h, w_, c0), dtype=T, device=dev()), torch.zeros((n, h, w_, c1), dtype=T, device=dev())
+            d2 = conv_desc(dyd, co, 0, None, 0, wd_packed, None, g0, g1, c0, n, h, w_, ci, 0, dtype)
+            gate = np.random.default_rng(77 + idx).random((n, h, w_, c0)) < 0.6
+            gbits = torch.from_numpy(bit_planes(gate).view(np.int32)).to(dev())
+            d2.mask_bits, d2.mask_channels, d2.mask_scale = gbits.data_ptr(), c0, 1.0
+            keep.append(gbits)
+        elif up0:                                  # an up-conv layer: both gradients in their sub-pixel forms
+            g0, g1 = torch.zeros((n, h // 2, w_ // 2, c0), dtype=T, device=dev()), None
+            wsub = torch.zeros(16 * ci * co, dtype=T, device=dev())
+            N.call('rvip_pack_subpixel_dgrad_weights', P(wmaster), ci, co, ndt(dtype), P(wsub), stream())
+            d2 = conv_desc(dyd, co, 0, None, 0, wsub, None, g0, None, 0, n, h, w_, ci, 0, dtype)
+            d2.subpix = 2
+            keep.append(wsub)
+        else:                                      # a plain layer behind a Dropout: the result gated by the keep bits
+            g0, g1 = torch.zeros((n, h, w_, ci), dtype=T, device=dev()), None
+            d2 = conv_desc(dyd, co, 0, None, 0, wd_packed, None, g0, None, 0, n, h, w_, ci, 0, dtype)
+            kb = np.random.default_rng(31 + idx).random((n, h, w_, ci)) < 0.7       # (the same mask in both runs)
+            kbits = torch.from_numpy(bit_planes(kb).view(np.int32)).to(dev())
+            d2.mask_bits, d2.mask_channels, d2.mask_scale = kbits.data_ptr(), ci, 1.0 / 0.7
+            keep.append(kbits)
+        d2.cu_limit = 128
+        rows = L.rvip_conv3x3_fwd_sums_rows(C.byref(d2))
+        if rows <= 0:
+            return None
+        sums = torch.zeros(rows * ci, dtype=torch.float32, device=dev())
+        if paired:
+            if not L.rvip_conv3x3_wgrad_dgrad_ok(C.byref(g), C.byref(d2)):
+                return None
+            N.call('rvip_conv3x3_wgrad_dgrad', C.byref(g), C.byref(d2), P(sums), C.c_size_t(sums.numel() * 4), stream())
+        else:
+            N.call('rvip_conv3x3_wgrad', C.byref(g), stream())
+            N.call('rvip_conv3x3_fwd_sums', C.byref(d2), P(sums), C.c_size_t(sums.numel() * 4), stream())
+        torch.cuda.synchronize()
+        return [t_ for t_ in (dw, dots, g0, g1, sums) if t_ is not None]
+    one = run(True)
+    if one is None:
+        assert 'dec3.up' in name, name + ': only the 64 -> 32 up-conv at 256^2 (phase-pair weight gradient) has no pair kernel'
+        pytest.skip('no pair kernel for this layer form')
+    two = run(False)
+    assert float(one[0].abs().max()) > 0 and float(one[2].float().abs().max()) > 0
+    for a_, b_ in zip(one, two):
+        assert torch.equal(a_, b_), name
