@@ -854,7 +854,13 @@ class Engine(InputRing):
         self.bwd_pair = os.environ.get('RVIP_BWD_PAIR', '1') != '0'
         # Measured (round 5, same box, alternating): W = 128 4.650 -> 4.54 ms at config 2 (-2.4 %), BCE-Dice -3.0 %, config 4 +0.3 %;
         # 96 / 112 / 144 are SLOWER than one after the other (4.76 / 4.69 / 4.89: the tile counts no longer divide by the grids).
-        ov = int(os.environ.get('RVIP_BWD_OVERLAP', '128') or 0)
+        # RVIP_BWD_OVERLAP unset ('auto'): 128 / 128, except at the two full-resolution levels, where the data gradient is the longer half
+        # by 10-30 % (tools/tune_pair_split.py, the pair launch back to back, us at W = 104 / 112 / 128: 64 -> 64 at 128^2 76 / 83 / 81,
+        # (64 + 64) -> 64 at 128^2 137 / 144 / 156, (32 + 32) -> 32 at 256^2 188 / 174 / 186, 32 -> 32 at 256^2 121 / 114 / 118): the
+        # weight gradient gets 104 (128^2 level, >= 64 input channels, nine-tap forms) or 112 (256^2 level) compute units there.
+        ove = os.environ.get('RVIP_BWD_OVERLAP', 'auto')
+        self.bwd_split_auto = ove == 'auto'
+        ov = 128 if self.bwd_split_auto else int(ove or 0)
         self.bwd_overlap = ov if (0 < ov < 256 and self.kd == 1) else 0
         reserve = int(os.environ.get('RVIP_RCCL_CU_RESERVE', '0') or 0) if self.dp else 0
         self.cu_reserve = reserve if 0 < reserve < 128 else 0
@@ -869,7 +875,13 @@ class Engine(InputRing):
             avail = 256 - (self.cu_reserve if si_ < n_enc_ else 0)      # (encoder stages run while bucket 0 travels)
             cu_w = cu_d = avail if avail < 256 else 0
             if self.bwd_overlap:
-                cu_w = max(8, min(avail - 8, self.bwd_overlap * avail // 256))
+                w_of_256 = self.bwd_overlap
+                if self.bwd_split_auto and not st.up0:
+                    if st.h >= 256:
+                        w_of_256 = 112
+                    elif st.h >= 128 and st.cin >= 64:
+                        w_of_256 = 104
+                cu_w = max(8, min(avail - 8, w_of_256 * avail // 256))
                 cu_d = avail - cu_w
             wg.x0, wg.c0, wg.up0 = self.act[st.src0].data_ptr(), st.c0, st.up0
             wg.x1, wg.c1 = (self.act[st.src1].data_ptr(), st.c1) if st.src1 else (None, 0)
