@@ -298,10 +298,11 @@ class InputRing:
     def _ring_alloc(self, slots):
         torch = _torch()
         self.pin_x = [torch.empty(self.x_stage.shape, dtype=torch.float32).pin_memory() for _ in range(slots)]
-        self.pin_y = [torch.empty(self.y_true.shape, dtype=torch.float32).pin_memory() for _ in range(slots)]
+        with_y = getattr(self, 'with_y', True)              # (EvalRing of predict(): inputs only -- no pinned / device target buffers)
+        self.pin_y = [torch.empty(self.y_true.shape, dtype=torch.float32).pin_memory() if with_y else None for _ in range(slots)]
         self.pin_x_np = [t.numpy() for t in self.pin_x]    # host views, created here so that the generator thread never enters torch
-        self.pin_y_np = [t.numpy() for t in self.pin_y]
-        self.dev_in = [(torch.empty_like(self.x_stage), torch.empty_like(self.y_true)) for _ in range(2)]
+        self.pin_y_np = [t.numpy() if t is not None else None for t in self.pin_y]
+        self.dev_in = [(torch.empty_like(self.x_stage), torch.empty_like(self.y_true) if with_y else None) for _ in range(2)]
         self.copy_stream = torch.cuda.Stream(device=self.P.device)
         self.ev_free = [None, None]                        # device staging pair -> event after which it may be refilled
 
@@ -399,10 +400,29 @@ class EvalRing(InputRing):
 
     SLOTS = 4
 
-    def __init__(self, eng):
+    def __init__(self, eng, with_y=True):
         self.x_stage, self.y_true, self.P = eng.x_stage, eng.y_true, eng.P
+        self.with_y = with_y
         self.alloc_input_ring(self.SLOTS)
         self.out = None
+
+    def ensure_targets(self):
+        """(training thread, nothing staged) a ring made for predict() gets its target buffers when evaluate() comes to use it"""
+        if not self.with_y:
+            self.reset_input_ring()
+            self.with_y = True
+            self.pin_x = None
+            self.alloc_input_ring(self.SLOTS)
+
+    def drop(self):
+        """(training thread) waits for what is in flight and lets the pinned / device buffers go (rings of batch sizes a
+        model no longer predicts with kept several hundred MB pinned)"""
+        self.reset_input_ring()
+        if self.out is not None:
+            for ev in self.out['done']:
+                if ev is not None:
+                    ev.synchronize()
+        self.pin_x = self.pin_y = self.pin_x_np = self.pin_y_np = self.dev_in = self.out = None
 
     def download(self, src):
         """(predict) queue the device-to-host copy of `src` (the engine's heat-maps of the batch just launched) and return a handle

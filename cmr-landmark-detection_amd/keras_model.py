@@ -449,13 +449,25 @@ class Model:
         vals = self._batch_logs(eng, kind, w_bce, w_dice).cpu().numpy().tolist()
         return dict(zip(self.metrics_names, vals)) if return_dict else vals
 
-    def _eval_ring(self, eng, batch, used):
+    MAX_EVAL_RINGS = 2                       # batch sizes whose pinned ring stays allocated (a generator's full and ragged last batch)
+
+    def _eval_ring(self, eng, batch, used, need_y=True):
         """evaluate() / predict(): the pinned ring of this batch size, reset at its first use in a call (a call that ended in an
-        exception may have left staged slots behind)"""
+        exception may have left staged slots behind).  predict() rings hold inputs only; at most MAX_EVAL_RINGS batch sizes keep
+        theirs (least recently used goes first)."""
         from .engine import EvalRing
-        ring = self._eval_rings.get(batch)
-        if ring is None or ring.x_stage is not eng.x_stage:
-            ring = self._eval_rings[batch] = EvalRing(eng)
+        ring = self._eval_rings.pop(batch, None)
+        if ring is not None and ring.x_stage is not eng.x_stage:
+            ring.drop()
+            ring = None
+        if ring is None:
+            idle = [b for b in self._eval_rings if b not in used]          # (a ring this call has used may still hold a download)
+            while len(self._eval_rings) >= self.MAX_EVAL_RINGS and idle:
+                self._eval_rings.pop(idle.pop(0)).drop()
+            ring = EvalRing(eng, with_y=need_y)
+        elif need_y:
+            ring.ensure_targets()
+        self._eval_rings[batch] = ring           # (re-inserted last: most recently used)
         if batch not in used:
             ring.reset_input_ring()
             used.add(batch)
@@ -496,7 +508,7 @@ class Model:
         for xb in batches:
             xb = np.asarray(xb, np.float32)
             eng = self._engine(xb.shape[0])
-            ring = self._eval_ring(eng, xb.shape[0], used)
+            ring = self._eval_ring(eng, xb.shape[0], used, need_y=False)
             if total is not None and result is None:
                 result = np.empty((total,) + tuple(eng.out_shape[1:]), np.float32)
             slot = ring.next_slot()
