@@ -1332,8 +1332,9 @@ class Engine(InputRing):
         # any stream captures (SIGABRT).  The graphs are handed to a module-level list instead and destroyed by
         # whoever next holds _CAPTURE_LOCK outside a capture (capture_guard's entry, release()).
         g = getattr(self, '_graphs', None)
-        if g:
-            _GRAVEYARD.append(g)
+        gy = _GRAVEYARD                      # (None while the interpreter tears the module down: nothing captures any more)
+        if g and gy is not None:
+            gy.append(g)
             self._graphs = None
 
     def release(self):
