@@ -25,32 +25,33 @@ namespace rvip {
 // NCW = compute waves of BOTH halves' workgroups: 8 (768 threads, <= 168 VGPRs: the igemm's eight-compute-wave form of the 512-pixel
 // tiles + the weight gradient with its taps split over two waves, TS = 2) or 4 (512 threads: the forms the 256-pixel tiles of the
 // 16-wide maps use anyway)
-// TAPS = 4: the sub-pixel forms of an UpSampling2D -> conv layer (four-phase weight gradient, data gradient with subpix = 2)
-template <typename T, int TW, int CIB, int COB, int NSTW, int NCT, int NPIX, int STATS, int NCW, int TAPS>
+// TAPS = 4: the sub-pixel forms of an UpSampling2D -> conv layer (four-phase weight gradient, data gradient with subpix = 2);
+// PBW = 1: the weight gradient's phase-PAIR form (both column phases per workgroup) beside the nine-tap data gradient with its 2x2 sums
+template <typename T, int TW, int CIB, int COB, int NSTW, int NCT, int NPIX, int STATS, int NCW, int TAPS, int PBW = 0>
 __global__ __launch_bounds__((NCW + 4) * 64, 1) void wgrad_dgrad_pair(WgArgs2 wa, ConvArgs2 ca, int nw, int wgx, int wgy, int dgx) {
     if ((int)blockIdx.x < nw) {
         const unsigned id = blockIdx.x, r = id / (unsigned)wgx;
-        wgrad3x3_ws_body<T, TW, CIB, COB, NSTW, TAPS, 0, NCW / 4>(wa, id % (unsigned)wgx, r % (unsigned)wgy, r / (unsigned)wgy, (unsigned)wgx);
+        wgrad3x3_ws_body<T, TW, CIB, COB, NSTW, PBW ? 4 : TAPS, PBW, NCW / 4>(wa, id % (unsigned)wgx, r % (unsigned)wgy, r / (unsigned)wgy, (unsigned)wgx);
     } else {
         const int id = (int)blockIdx.x - nw;
         igemm_ws16_body<T, TW, NCT, NPIX, STATS, TAPS, NCW>(ca, id % dgx, id / dgx, 0, dgx);
     }
 }
 
-template <typename T, int TW, int CIB, int COB, int NCT, int NPIX, int STATS, int NCW, int TAPS = 9>
+template <typename T, int TW, int CIB, int COB, int NCT, int NPIX, int STATS, int NCW, int TAPS = 9, int PBW = 0>
 static int launch_pair(const WgArgs2& wa, const IgemmPlan& dp, hipStream_t s, bool dry) {
     // LDS of the weight-gradient half: launch_wgrad2x's arithmetic (the stage count is a template parameter of the body)
     constexpr int TH = 256 / TW;
     constexpr int NHROWS = ((TW + 2) * (TH + 2) + 15) / 16 * 16;
-    constexpr int ST = NHROWS * CIB * 2 + 256 * COB * 2;
+    constexpr int ST = NHROWS * CIB * 2 + (PBW ? 2 : 1) * 256 * COB * 2;
     constexpr int NSTW = 3 * ST <= 160 * 1024 ? 3 : 2;
-    constexpr int FOLD = (CIB / 32) * (COB / 32) < 4 ? 4 * TAPS * 32 * 32 * 4 : 0;
+    constexpr int FOLD = (CIB / 32) * (COB / 32) < 4 ? 4 * (PBW ? 2 * 4 : TAPS) * 32 * 32 * 4 : 0;
     constexpr int lds_w = NSTW * ST > FOLD ? NSTW * ST : FOLD;
     static_assert(lds_w <= 160 * 1024, "LDS");
     if (dp.gz != 1 || dp.lds > 160 * 1024) return RVIP_EUNSUPPORTED;
     if (dry) return RVIP_OK;
     const int lds = lds_w > dp.lds ? lds_w : dp.lds;
-    auto kern = &wgrad_dgrad_pair<T, TW, CIB, COB, NSTW, NCT, NPIX, STATS, NCW, TAPS>;
+    auto kern = &wgrad_dgrad_pair<T, TW, CIB, COB, NSTW, NCT, NPIX, STATS, NCW, TAPS, PBW>;
     static std::atomic<bool> attr_done{false};
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -77,12 +78,12 @@ static int pair_dispatch(const rvip_wgrad3x3_desc* wd, const rvip_conv3x3_desc* 
     WgradPlan wp;
     int rc = wgrad_plan(wd, wp);
     if (rc) return rc;
-    if (wp.b.sp == 2) return RVIP_EUNSUPPORTED;             // (the phase-pair form, two dY tiles per stage, keeps its own launch)
     ConvArgs a;
     rc = conv_args_from_desc(dd, a);
     if (rc) return rc;
     const bool sub = wp.b.sp == 1;                          // four-phase weight gradient <-> data gradient in sub-pixel form (subpix = 2)
-    if (sub != (a.subpix == 2) || a.subpix == 1) return RVIP_EUNSUPPORTED;
+    const bool pbw = wp.b.sp == 2;                          // phase-pair weight gradient <-> nine-tap data gradient with the 2x2 sums (down2)
+    if (sub != (a.subpix == 2) || a.subpix == 1 || (pbw && !a.down2)) return RVIP_EUNSUPPORTED;
     if ((!sub && a.kd != 1) || a.c1 || a.up0 || dd->dtype != wd->dtype || !sums_ws) return RVIP_EUNSUPPORTED;
     if (dd->n != wd->n || dd->h != wd->h || dd->w != wd->w || a.cin != wd->cout || dd->x0 != wd->dy) return RVIP_EINVAL;      // the same layer, the same dz
     if (dd->bias || dd->act != RVIP_ACT_NONE) return RVIP_EINVAL;
@@ -106,7 +107,7 @@ static int pair_dispatch(const rvip_wgrad3x3_desc* wd, const rvip_conv3x3_desc* 
     if ((a.w > 16 ? 32 : 16) != tw) return RVIP_EUNSUPPORTED;
     IgemmPlan dp;
 #define RVIP_PAIR(TWv, CIBv, COBv, NCTv, NPIXv)                                                                                   \
-    if (!sub && tw == TWv && cib == CIBv && cob == COBv && two == (NCTv == 2)) {                                                            \
+    if (!sub && !pbw && tw == TWv && cib == CIBv && cob == COBv && two == (NCTv == 2)) {                                                            \
         rc = plan_dgrad<T, TWv, NCTv, NPIXv, (NPIXv == 512 ? 8 : 4)>(a, sums_ws, dp);                                              \
         if (rc) return rc;                                                                                                         \
         if (sums_ws_bytes < (size_t)dp.gx * a.cout * sizeof(float)) return RVIP_EWORKSPACE;                                        \
@@ -132,6 +133,12 @@ static int pair_dispatch(const rvip_wgrad3x3_desc* wd, const rvip_conv3x3_desc* 
     RVIP_PAIR4(32, 2, 512)
     RVIP_PAIR4(16, 2, 256)
 #undef RVIP_PAIR4
+    if (pbw && !gated && tw == 32 && cib == 64 && cob == 32 && two) {           // the 64 -> 32 up-conv at the full resolution
+        rc = plan_dgrad<T, 32, 2, 512, 8>(a, sums_ws, dp);
+        if (rc) return rc;
+        if (sums_ws_bytes < (size_t)dp.gx * a.cout * sizeof(float)) return RVIP_EWORKSPACE;
+        return launch_pair<T, 32, 64, 32, 2, 512, 2, 8, 9, 1>(wp.b, dp, s, dry);
+    }
     return RVIP_EUNSUPPORTED;
 }
 
@@ -160,5 +167,5 @@ extern "C" int rvip_conv3x3_wgrad_dgrad(const rvip_wgrad3x3_desc* wd, const rvip
     hipStream_t s = (hipStream_t)stream;
     const int rc = pair_entry(wd, dd, sums_ws, sums_ws_bytes, s, false);
     if (rc) return rc;
-    return wgrad_finish(wd, rvip_conv3x3_wgrad_splits(wd), rvip_conv3x3_wgrad_form(wd) == 1 ? 1 : 0, s);
+    return wgrad_finish(wd, rvip_conv3x3_wgrad_splits(wd), rvip_conv3x3_wgrad_form(wd), s);
 }

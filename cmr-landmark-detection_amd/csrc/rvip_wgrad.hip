@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_dma(WgArgs2 a) {
 // (X 45 KB + 2 x 16 KB), i.e. the full-resolution layer 64 -> 32 at 256^2, which the four-phase form could not speed up.
 // (a device function of the workgroup's coordinates: bx_ = pixel split [x phase], by_ / bz_ = input / output channel block, gdx_ = the
 //  grid's x extent -- rvip_pair.hip runs it in a part of the grid of its weight / data gradient pair kernel)
-// TS = 2 (16-bit types, one dY tile per stage): EIGHT compute waves -- every (pair, pixel part) of the four-wave form twice, once for
+// TS = 2 (16-bit types): EIGHT compute waves -- every (pair, pixel part) of the four-wave form twice, once for
 // taps 0..4 and once for taps 5..8 of the nine (80 / 64 accumulator registers instead of 144), 0..1 and 2..3 of the sub-pixel form's four -- so that the workgroup is 12 waves at <= 168 VGPRs, the shape of
 // the eight-compute-wave igemm: the two can then be the two parts of one grid (rvip_pair.hip).  Both tap halves read the same dY
 // fragments; the X fragments, the MFMA count and the slab are those of the four-wave form.
@@ -432,7 +432,7 @@ template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9, int P
 __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigned bx_, const unsigned by_, const unsigned bz_, const unsigned gdx_) {
     static_assert(TAPS == 9 || (TAPS == 4 && sizeof(T) == 2), "taps");
     static_assert(PB == 0 || TAPS == 4, "phase pairs belong to the sub-pixel form");
-    static_assert(TS == 1 || (TS == 2 && PB == 0 && sizeof(T) == 2), "tap halves: the forms with one dY tile per stage, 16-bit types");
+    static_assert(TS == 1 || (TS == 2 && sizeof(T) == 2), "tap halves: 16-bit types");
     constexpr int HT = (TAPS + 1) / 2;                                // taps of the first half (TS = 2): 5 of 9, 2 of 4
     constexpr int NCWV = 4 * TS;                                      // compute waves
     constexpr bool SP = TAPS == 4;
@@ -574,7 +574,7 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
     }
 
     // (T0, T1): this wave's taps.  acc[lt] belongs to tap T0 + lt (TS = 1: all of them, lt = gph * TAPS + t)
-    constexpr int MYT = TS == 2 ? HT : NG * TAPS;
+    constexpr int MYT = TS == 2 ? NG * HT : NG * TAPS;          // TS = 2: acc[gph * HT + (tap - T0)]
     f32x16 acc[MYT];
 #pragma unroll
     for (int t = 0; t < MYT; ++t)
@@ -639,7 +639,8 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
                     const s16x4 x0 = tr_read((SP ? xq[SP ? gph : 0][t & 1][0] : xp[t % 3][0]) + off);
                     const s16x4 x1 = tr_read((SP ? xq[SP ? gph : 0][t & 1][1] : xp[t % 3][1]) + off);
                     const uint4 fa = __builtin_bit_cast(uint4, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    acc[gph * TAPS + t - T0] = mfma16<T>(fa, fb, acc[gph * TAPS + t - T0]);
+                    const int ai = TS == 2 ? gph * HT + (t - T0) : gph * TAPS + t;      // compile-time after unrolling
+                    acc[ai] = mfma16<T>(fa, fb, acc[ai]);
                 }
             }
         } else {
@@ -698,8 +699,9 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
         float* red = reinterpret_cast<float*>(smem) + (part * PAIRS + pair) * BLK;   // [PSPLIT][PAIRS][9][32][32]
 #pragma unroll
         for (int lt = 0; lt < MYT; ++lt) {
-            const int t = TS == 2 ? lt + HT * th : lt;
-            if (t < NG * TAPS) {
+            const int tl = TS == 2 ? lt % HT + HT * th : lt;                  // tap of this accumulator (TS = 2: within its phase tile)
+            const int t = TS == 2 ? (lt / HT) * TAPS + tl : lt;               // its index in the four-wave form's accumulator order
+            if (TS == 2 ? tl < TAPS : t < NG * TAPS) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) red[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j] = acc[lt][r];
             }
@@ -734,9 +736,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws(WgArgs2 a) {
     wgrad3x3_ws_body<T, TW, CIB, COB, NST, TAPS, PB>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
-template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9>
+template <typename T, int TW, int CIB, int COB, int NST = 2, int TAPS = 9, int PB = 0>
 __global__ __launch_bounds__(768, 1) void wgrad3x3_ws12(WgArgs2 a) {
-    wgrad3x3_ws_body<T, TW, CIB, COB, NST, TAPS, 0, 2>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+    wgrad3x3_ws_body<T, TW, CIB, COB, NST, TAPS, PB, 2>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
 // dw[i] = sum_k slab[k][i] in a fixed order (reproducible).  A thread owns four consecutive elements (one 16-byte load per slab);
@@ -1029,17 +1031,17 @@ static int launch_wgrad2x(const WgArgs2& a, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid((unsigned)a.nsplit, (unsigned)cdiv(a.cin, CIB), (unsigned)cdiv(a.cout, COB));
-    if constexpr (WS && PB == 0 && sizeof(T) == 2) {
+    if constexpr (WS && sizeof(T) == 2) {
         // (A/B: the eight-compute-wave form -- the taps split between two waves -- as a launch of its own)
         static const bool ws12 = [] { const char* e = getenv("RVIP_WGRAD_WS12"); return e && e[0] == '1'; }();
         if (ws12) {
             static std::atomic<bool> attr12{false};
             if (!attr12) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws12<T, TW, CIB, COB, NST, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws12<T, TW, CIB, COB, NST, TAPS, PB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e != hipSuccess) { g_last_hip_error = (int)e; return RVIP_ELAUNCH; }
                 attr12 = true;
             }
-            hipLaunchKernelGGL((wgrad3x3_ws12<T, TW, CIB, COB, NST, TAPS>), grid, dim3(768), lds, s, a);
+            hipLaunchKernelGGL((wgrad3x3_ws12<T, TW, CIB, COB, NST, TAPS, PB>), grid, dim3(768), lds, s, a);
             return check_launch();
         }
     }

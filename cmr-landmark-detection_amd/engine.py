@@ -867,8 +867,7 @@ class Engine(InputRing):
         self.side_stream = None
         self.paired = []                                  # layers whose two gradients run as one launch (rvip_conv3x3_wgrad_dgrad)
         self.bwd_mode = {}                                # conv name -> 'pair' | 'forkjoin' | 'serial'
-        # RVIP_BWD_PAIR (default 1): where rvip_conv3x3_wgrad_dgrad serves the layer (nine-tap forms, 16-bit types: 17 of the 21 layers of
-        # config 2) the two gradients are the two parts of ONE grid instead of two launches between a fork and a join of the graph --
+        # RVIP_BWD_PAIR (default 1): where rvip_conv3x3_wgrad_dgrad serves the layer (16-bit types, 2-D: all 21 layers of config 2) the two gradients are the two parts of ONE grid instead of two launches between a fork and a join of the graph --
         # the cross-queue synchronisation of that schedule costs ~18 us per layer, most of what running side by side hides.
         # Same box (round 5): one after the other 4.62, fork / join 4.60, pair kernel 4.52 ms; bit-identical gradients (tools/ab_pair.py).
         self.bwd_pair = os.environ.get('RVIP_BWD_PAIR', '1') != '0'

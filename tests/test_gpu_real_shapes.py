@@ -710,6 +710,12 @@ def test_weight_and_data_gradient_as_one_launch_equal_the_two_calls(idx, dtype):
             gbits = torch.from_numpy(bit_planes(gate).view(np.int32)).to(dev())
             d2.mask_bits, d2.mask_channels, d2.mask_scale = gbits.data_ptr(), c0, 1.0
             keep.append(gbits)
+        elif up0 and L.rvip_conv3x3_wgrad_form(C.byref(g)) == 2:
+            # the 64 -> 32 up-conv at 256^2: phase-PAIR weight gradient beside the nine-tap data gradient with its 2x2 sums (what the
+            # engine launches there: RVIP_BNBWD_SUBPIX_CONSUMER 'ninetap')
+            g0, g1 = torch.zeros((n, h // 2, w_ // 2, c0), dtype=T, device=dev()), None
+            d2 = conv_desc(dyd, co, 0, None, 0, wd_packed, None, g0, None, 0, n, h, w_, ci, 0, dtype)
+            d2.down2 = 1
         elif up0:                                  # an up-conv layer: both gradients in their sub-pixel forms
             g0, g1 = torch.zeros((n, h // 2, w_ // 2, c0), dtype=T, device=dev()), None
             wsub = torch.zeros(16 * ci * co, dtype=T, device=dev())
@@ -739,9 +745,7 @@ def test_weight_and_data_gradient_as_one_launch_equal_the_two_calls(idx, dtype):
         torch.cuda.synchronize()
         return [t_ for t_ in (dw, dots, g0, g1, sums) if t_ is not None]
     one = run(True)
-    if one is None:
-        assert 'dec3.up' in name, name + ': only the 64 -> 32 up-conv at 256^2 (phase-pair weight gradient) has no pair kernel'
-        pytest.skip('no pair kernel for this layer form')
+    assert one is not None, name + ': every layer form of config 2 has a pair kernel'
     two = run(False)
     assert float(one[0].abs().max()) > 0 and float(one[2].float().abs().max()) > 0
     for a_, b_ in zip(one, two):
