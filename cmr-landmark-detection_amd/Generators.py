@@ -65,14 +65,15 @@ class BaseGenerator:
         self._epochs_seen = 0
         self.samples_generated = 0          # samples this process has produced (data-parallel tests: B / world per step and rank)
         self._count_lock = threading.Lock() # __getitem__ may run on several pool threads (fit(workers=))
+        self._tls = threading.local()       # the reshuffle count a fetch started under (augmentation seed), per fetching thread
         self.on_epoch_end()
 
     def __len__(self):
         return int(np.floor(len(self.INDICES) / self.BATCHSIZE))
 
     def __getitem__(self, index):
-        idxs = self.INDICES[index * self.BATCHSIZE:(index + 1) * self.BATCHSIZE]
-        return self.__data_generation__(idxs)
+        epoch, order = self._order          # ONE read: a fetch that overlaps on_epoch_end() (stager thread) keeps its epoch's order and seed
+        return self.__data_generation__(order[index * self.BATCHSIZE:(index + 1) * self.BATCHSIZE], epoch)
 
     def batch_slice(self, index, lo, hi):
         """Samples lo..hi-1 of batch `index` only.  The reference is ONE process under MirroredStrategy (Unets.py:70-75): every
@@ -82,7 +83,8 @@ class BaseGenerator:
         if not (0 <= lo <= hi <= self.BATCHSIZE):
             raise IndexError('slice %d:%d of a batch of %d' % (lo, hi, self.BATCHSIZE))
         base = index * self.BATCHSIZE
-        return self.__data_generation__(self.INDICES[base + lo:base + hi])
+        epoch, order = self._order
+        return self.__data_generation__(order[base + lo:base + hi], epoch)
 
     def __iter__(self):
         for i in range(len(self)):
@@ -96,8 +98,10 @@ class BaseGenerator:
             # one-process MirroredStrategy -- must see the same order to slice the same global batch.
             self.INDICES = np.random.default_rng([int(self.SEED), self._epochs_seen]).permutation(len(self.INDICES))
         self._epochs_seen += 1
+        self._order = (self._epochs_seen, self.INDICES)      # published together (tuple assignment is atomic)
 
-    def __data_generation__(self, idxs):
+    def __data_generation__(self, idxs, epoch=None):
+        self._tls.epoch = self._epochs_seen if epoch is None else epoch
         x = np.empty((len(idxs), *self.DIM, 1), dtype=np.float32)
         y = np.empty((len(idxs), *self.DIM, self.N_CLASSES), dtype=np.float32)
         for i, ID in enumerate(idxs):
@@ -226,7 +230,7 @@ class DataGenerator(BaseGenerator):
             # the draws of a sample come from (SEED, reshuffles so far, sample ID): the same sample gets the same augmentation whichever
             # rank, pool thread or batch slice produces it (a shared sequential stream would hand every data-parallel rank the SAME
             # parameter sequence for DIFFERENT samples, and is not safe under fit(workers > 1)).
-            rng = np.random.default_rng([int(self.SEED), int(self._epochs_seen), int(ID)])
+            rng = np.random.default_rng([int(self.SEED), int(getattr(self._tls, 'epoch', self._epochs_seen)), int(ID)])
             img, msk = pp.augment(img, msk, self.config, rng, self.AUGMENT_PROB)
         img = normalise_image(pp.pad_and_crop(img, self.DIM), self.SCALER)
         msk = pp.pad_and_crop(msk, self.DIM)

@@ -966,7 +966,8 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
             }
         };
         // stages chunk kc of the PREPARED tile
-        auto issue_input = [&](int kc, int stage) __attribute__((always_inline)) {
+        auto issue_input = [&](int kc, int stage) __attribute__((always_inline)) -> int {   // returns the VMEM instructions this wave issued
+            int nvm = 0;
             const int kdi = a.kd > 1 ? kc / nch : 0;
             const int dsh = s2d ? 0 : kdi - (a.kd >> 1);     // depth tap: the image dsh slices away, zeros outside the volume
             const bool dok = (unsigned)(p_nmod + dsh) < (unsigned)a.depth;
@@ -979,7 +980,7 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
             const unsigned base = (unsigned)((from0 ? p_tb0 + dsh * img0_bytes : p_tb1 + dsh * img1_bytes) + cb * (int)sizeof(T) + phoff);
             if constexpr (STATS == 3) {
                 if (kc == 0) {                               // first chunk of a tile: its mask words ride along (wave-uniform)
-                    if (lwv < NCT * NPM) dma16(rsm, p_mb, lds_base + a.lds_mb_off + mb_par * MB_TILE + lwv * 1024);
+                    if (lwv < NCT * NPM) { dma16(rsm, p_mb, lds_base + a.lds_mb_off + mb_par * MB_TILE + lwv * 1024); ++nvm; }
                     mb_par = mb_par + 1 == a.nstg ? 0 : mb_par + 1;      // one buffer of mask words per input stage
                 }
             }
@@ -987,12 +988,12 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
                 if (from0) {
 #pragma unroll
                     for (int i = 0; i < QI; ++i) {
-                        if (i < QI - 1 || lwv + 4 * i < NQI) dma16(rs0, t0[i] + base, li0 + i * 4096);   // OOB + base stays >= 2^31
+                        if (i < QI - 1 || lwv + 4 * i < NQI) { dma16(rs0, t0[i] + base, li0 + i * 4096); ++nvm; }   // OOB + base stays >= 2^31
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < QI; ++i) {
-                        if (i < QI - 1 || lwv + 4 * i < NQI) dma16(rs1, t1[i] + base, li0 + i * 4096);
+                        if (i < QI - 1 || lwv + 4 * i < NQI) { dma16(rs1, t1[i] + base, li0 + i * 4096); ++nvm; }
                     }
                 }
             } else {                                         // partial chunk / depth tap outside the volume / streaming hint
@@ -1004,9 +1005,11 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
                         const unsigned off = (t != OOB && ich[i] < crem) ? t + base : OOB;
                         if (a.nt_in) dma16_nt(rs, off, li0 + i * 4096);
                         else dma16(rs, off, li0 + i * 4096);
+                        ++nvm;
                     }
                 }
             }
+            return nvm;
         };
         if (resident) for (int kc = 0; kc < nchunks; ++kc) issue_weights(kc, kc);
         else issue_weights(0, 0);
@@ -1015,16 +1018,16 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
         // per CU and its compute waves wait for the DMA at every barrier.  Three stages (weights resident, LDS permitting): the item
         // requested here is consumed TWO barriers later, and the wait in front of a barrier is a COUNTED one -- s_waitcnt vmcnt(n) with
         // n = this wave's DMA instructions of the younger item, which may stay in flight (loads return in order).
-        constexpr int NIN_FULL = QI, NIN_LAST = QI - 1;      // input pieces of a wave per item: QI, or QI - 1 for the waves past the last piece
-        const int nin = (lwv + 4 * (QI - 1) < NQI) ? NIN_FULL : NIN_LAST;
         int itile = first_tile, ikc = 0, istg = 0;
         prep_tile(itile);
         auto issue_next = [&]() __attribute__((always_inline)) -> int {     // requests the cursor's item; returns this wave's DMA count for it (0: none)
             if (itile >= a.ntiles) return 0;
-            int cnt = nin;
-            if constexpr (STATS == 3) cnt += (ikc == 0 && lwv < NCT * NPM) ? 1 : 0;
+            // The count IS what was issued (every VMEM instruction of an item is counted where it is issued): the counted wait below
+            // cannot drift from the request code.  Three stages imply resident weights (host), so the rotating-weight DMAs -- issued
+            // only with two stages, where every wait is vmcnt(0) -- are not part of it.
+            int cnt = 0;
             if (!resident && (a.dbg & 64)) issue_weights(ikc, istg);          // (ablation: weights first)
-            if (!(a.dbg & 16)) issue_input(ikc, istg);
+            if (!(a.dbg & 16)) cnt = issue_input(ikc, istg);
             if (!resident && !(a.dbg & (8 | 64))) issue_weights(ikc, istg);   // (rotating weights: two stages only, host-checked)
             if (++ikc == nchunks) {
                 ikc = 0;
@@ -1041,10 +1044,11 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
             for (int kc = 0; kc < nchunks; ++kc) {
                 // my pieces of the item about to be consumed have landed; after the barrier: everybody's have, and the compute waves
                 // are done with the item before it, whose stage the next request may now overwrite
-                if (cyoung == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (cyoung == QI + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QI + 1) : "memory");
+                // cyoung = VMEM instructions of the YOUNGER item that may stay in flight; any count the cases below do not name waits for all
+                if (cyoung == QI + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QI + 1) : "memory");
                 else if (cyoung == QI) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QI) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QI > 1 ? QI - 1 : 0) : "memory");
+                else if (QI > 1 && cyoung == QI - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QI > 1 ? QI - 1 : 0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
                 const int c = issue_next();
                 if (a.nstg == 3) cyoung = c;

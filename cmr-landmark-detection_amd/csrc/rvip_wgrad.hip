@@ -507,7 +507,8 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
         gpx[i] = P % TW;
         grel[i] = SP ? ((2 * (P / TW) * 2 * a.w + 2 * (P % TW)) * a.cout + c) * ESZ : (((P / TW) * a.w + (P % TW)) * a.cout + c) * ESZ;
     }
-    auto issue = [&](int tile, int stage) __attribute__((always_inline)) {
+    auto issue = [&](int tile, int stage) __attribute__((always_inline)) -> int {     // returns the VMEM instructions this wave issued
+        int nvm = 0;
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
@@ -527,6 +528,7 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
                 const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(xbase + xrel[i]) : OOB;
                 if (a.nt_x) dma16w_nt(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
                 else dma16w(rsx, off, lds_base + stage * ST_BYTES + q * 1024);
+                ++nvm;
             }
         }
 #pragma unroll
@@ -539,30 +541,32 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
                 const bool ok = (unsigned)gy < (unsigned)a.h && gx < a.w;
                 const unsigned off = (ok && !(a.dbg & 4)) ? (unsigned)(gbase + gph * gstep + grel[i]) : OOB;
                 dma16w(rsg, off, lds_base + stage * ST_BYTES + X_BYTES + gph * G_BYTES + q * 1024);
+                ++nvm;
             }
         }
+        return nvm;
     };
 
     if (loader) {
         __builtin_amdgcn_s_setprio(3);                       // the loaders' few instructions go ahead of the compute waves' streams
         if (split < a.ntiles) issue(split, 0);
-        if constexpr (NST == 3) { if (split + nsplit < a.ntiles) issue(split + nsplit, 1); }
-        // DMA instructions this wave issues per tile (the pieces are dealt round-robin to the four loader waves)
-        const int mine = ((NQX - wv + 3) >> 2) + NG * ((NQG - wv + 3) >> 2);
+        // VMEM instructions of the tile BEHIND the one the next barrier hands over, as its request counted them (the pieces are dealt
+        // round-robin to the four loader waves): they may stay in flight, loads return in order
+        int young = 0;
+        if constexpr (NST == 3) { if (split + nsplit < a.ntiles) young = issue(split + nsplit, 1); }
         int it = 0;
         for (int tile = split; tile < a.ntiles; tile += nsplit, ++it) {
             // my pieces of this tile have landed; after the barrier everybody's have, and the compute waves are done
             // with the previous tile, whose stage the next one may overwrite
             if constexpr (NST == 3) {
-                // the tile after this one may stay in flight: wait until at most its `mine` instructions are outstanding
-                if (tile + nsplit < a.ntiles && !(a.dbg & 1)) {
-                    static_assert(NG == 1 || NST == 2, "the counted wait below knows one dY tile per stage");
-                    if (mine == QX + QG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG) : "memory");
-                    else if (mine == QX + QG - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG - 1) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG >= 2 ? QX + QG - 2 : 0) : "memory");
-                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                static_assert(NG == 1 || NST == 2, "the counted wait below knows one dY tile per stage");
+                // any count the cases below do not name (none in flight included) waits for everything
+                if (young == QX + QG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG) : "memory");
+                else if (young == QX + QG - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG - 1) : "memory");
+                else if (QX + QG >= 3 && young == QX + QG - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QX + QG >= 2 ? QX + QG - 2 : 0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
-                if (tile + 2 * nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + 2 * nsplit, (it + 2) % 3);
+                young = (tile + 2 * nsplit < a.ntiles && !(a.dbg & 1)) ? issue(tile + 2 * nsplit, (it + 2) % 3) : 0;
             } else {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 if (tile + nsplit < a.ntiles && !(a.dbg & 1)) issue(tile + nsplit, (it + 1) & 1);

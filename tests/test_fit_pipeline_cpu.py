@@ -258,6 +258,37 @@ def test_augmentation_draws_belong_to_the_sample_not_to_the_call_order(tmp_path)
         assert not np.array_equal(whole[0][0], first)      # a new epoch draws new augmentations
 
 
+def test_a_fetch_keeps_the_epoch_it_started_under(tmp_path):
+    """the stager thread calls on_epoch_end() as soon as an epoch's last batch is produced; a fetch from another thread that
+    overlaps it (evaluate / predict on the same generator, gen[i] in user code) must see ONE epoch's order AND augmentation seed."""
+    rng = np.random.default_rng(1)
+    files_x, files_y = [], []
+    for i in range(8):
+        lab = np.zeros((40, 36), np.int16)
+        lab[10 + i, 12] = 1
+        lab[20, 8 + i] = 2
+        fx, fy = str(tmp_path / ('x%d.npy' % i)), str(tmp_path / ('y%d.npy' % i))
+        np.save(fx, rng.random((40, 36)).astype(np.float32))
+        np.save(fy, lab)
+        files_x.append(fx)
+        files_y.append(fy)
+    cfg = dict(DIM=[32, 32], BATCHSIZE=4, MASK_VALUES=[1, 2], AUGMENT=True, AUGMENT_PROB=1.0, SHUFFLE=True, SEED=7, GAUS=True, SIGMA=2)
+    ref, gen = G.DataGenerator(files_x, files_y, cfg), G.DataGenerator(files_x, files_y, cfg)
+    want_x, want_y = ref[1]
+
+    class _Racing(type(gen)):
+        def __data_generation__(self, idxs, epoch=None):       # the other thread's on_epoch_end() lands inside the fetch
+            type(gen).on_epoch_end(self)
+            return super().__data_generation__(idxs, epoch)
+    gen.__class__ = _Racing
+    x, y = gen[1]
+    np.testing.assert_array_equal(x, want_x)
+    np.testing.assert_array_equal(y, want_y)
+    ref.on_epoch_end()
+    gen.__class__ = type(ref)
+    np.testing.assert_array_equal(gen[1][0], ref[1][0])         # and the next epoch is the next epoch
+
+
 def test_single_threaded_ring_of_four_slots_never_waits_forever():
     """evaluate() / predict() drive a ring from ONE thread (engine.EvalRing: stage, feed, next batch) with four slots: staging batch
     k needs slot k % 4, which feeding batch k - 2 handed back -- also when no upload ever reports completion early, and for inputs
