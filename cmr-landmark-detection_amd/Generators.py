@@ -73,7 +73,7 @@ class BaseGenerator:
 
     def __getitem__(self, index):
         epoch, order = self._order          # ONE read: a fetch that overlaps on_epoch_end() (stager thread) keeps its epoch's order and seed
-        return self.__data_generation__(order[index * self.BATCHSIZE:(index + 1) * self.BATCHSIZE], epoch)
+        return self._generate(order[index * self.BATCHSIZE:(index + 1) * self.BATCHSIZE], epoch)
 
     def batch_slice(self, index, lo, hi):
         """Samples lo..hi-1 of batch `index` only.  The reference is ONE process under MirroredStrategy (Unets.py:70-75): every
@@ -84,7 +84,16 @@ class BaseGenerator:
             raise IndexError('slice %d:%d of a batch of %d' % (lo, hi, self.BATCHSIZE))
         base = index * self.BATCHSIZE
         epoch, order = self._order
-        return self.__data_generation__(order[base + lo:base + hi], epoch)
+        return self._generate(order[base + lo:base + hi], epoch)
+
+    def _generate(self, idxs, epoch):
+        """__data_generation__ (the reference's name and signature, which subclasses override) under the reshuffle count the fetch
+        started with: per-sample seeds read it from the fetching thread's slot, not from the generator's mutable state."""
+        self._tls.epoch = epoch
+        try:
+            return self.__data_generation__(idxs)
+        finally:
+            del self._tls.epoch
 
     def __iter__(self):
         for i in range(len(self)):
@@ -100,8 +109,7 @@ class BaseGenerator:
         self._epochs_seen += 1
         self._order = (self._epochs_seen, self.INDICES)      # published together (tuple assignment is atomic)
 
-    def __data_generation__(self, idxs, epoch=None):
-        self._tls.epoch = self._epochs_seen if epoch is None else epoch
+    def __data_generation__(self, idxs):
         x = np.empty((len(idxs), *self.DIM, 1), dtype=np.float32)
         y = np.empty((len(idxs), *self.DIM, self.N_CLASSES), dtype=np.float32)
         for i, ID in enumerate(idxs):

@@ -316,6 +316,16 @@ __global__ void bn_infer_coeffs_kernel(const float* gamma, const float* beta, co
 // ------------------------------------------------------------------------------------------------
 // y = dropout(act(scale*z + shift)) [+ 2x2 max-pool]
 // ------------------------------------------------------------------------------------------------
+// The forward apply passes walk their tensor from the END (RVIP_REV bit 0, default on; bit 1 = the BN-backward apply pass, default off):
+// the igemm in front of the pass has just written the end of z, and the igemm behind it starts at the beginning of y, which this pass
+// then wrote last -- a line stays in the 256 MiB Infinity Cache while the bytes moved since its last use fit it (MI355X_MICROARCH.md),
+// so at the 256^2 level (134 MB per tensor) two passes in the same direction find nothing of a hand-over and two in opposite directions
+// about half.  Measured, same box, five alternating runs: bn_apply 0.450 -> 0.432 ms per step, step 4.149 -> 4.132 ms; the backward
+// apply pass reversed: 0.610 -> 0.622 ms (not taken).  Results are the same bits either way (the partial rows keep their chunk's place).
+static int rev_flags() {
+    static const int f = [] { const char* e = getenv("RVIP_REV"); return e ? atoi(e) : 1; }();
+    return f;
+}
 struct ApplyArgs {
     const unsigned char* z; unsigned char* y; unsigned char* pooled;
     uint16_t* argmax;          // pooled + column-split kernel only: [windows][C / VE], 2 bits per channel = 2 * row + col of the first maximum
@@ -323,6 +333,7 @@ struct ApplyArgs {
     const float* scale; const float* shift;
     int act; float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
     int n, h, w, c;
+    int rev = 0;               // walk the tensor from its END (see rev_flags)
 };
 
 // ACT / DROP: compile-time activation (RVIP_ACT_*) and dropout mode (0 none, 1 counter stream, 2 mask array) of the hot
@@ -375,8 +386,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
             float v[UNR][VE]; size_t e0[UNR]; bool ok[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const long long r = (g + u * G) * rpi + prow;
-                ok[u] = (g + u * G) < ngroups && r < rows;
+                const long long gi = g + u * G, r = (a.rev ? ngroups - 1 - gi : gi) * rpi + prow;
+                ok[u] = gi < ngroups && r < rows;
                 e0[u] = (size_t)r * a.c + cv * VE;
                 if (ok[u]) Vec<T>::load_nt(a.z + e0[u] * sizeof(T), v[u]);     // z is not read again before the backward pass
             }
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs a, int cg, int 
                     // word of a pixel and 32-channel block: channel c sits at bit 8 * ((c & 15) >> 2) + 4 * (c >> 4) + (c & 3)
                     // (rvip_hip.h: the order in which the MFMA epilogue's lanes hold a pixel's channels).  Every thread places its
                     // bits in a word; the threads of a block (adjacent lanes: cv = tid % cg) OR their words; the first one stores.
-                    const long long r = (g + u * G) * rpi + prow;
+                    const long long gi = g + u * G, r = (a.rev ? ngroups - 1 - gi : gi) * rpi + prow;
                     constexpr int TPB = 32 / VE;            // threads per 32-channel block: 4 (16-bit types) or 8 (f32)
                     const int m = cv & (TPB - 1);           // this thread's channels are VE * m .. VE * m + VE - 1 of the block
                     unsigned word;                          // (two shifts instead of a loop over the bits: RVIP_BIT_OF_CHANNEL is nibble-wise)
@@ -467,9 +478,9 @@ __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(ApplyArgs a, int cg
         float v[UNR][2][VE]; size_t e0[UNR][2]; bool ok[UNR]; long long qi[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const long long q = (g + u * G) * wpi + wslot;
+            const long long gi = g + u * G, q = (a.rev ? ngroups - 1 - gi : gi) * wpi + wslot;
             qi[u] = q;
-            ok[u] = (g + u * G) < ngroups && q < quads;            // the same for both lanes of a window
+            ok[u] = gi < ngroups && q < quads;                     // the same for both lanes of a window
             int ox, oy; long long img;
             split_xy(q, ow, oh, ox, oy, img);
 #pragma unroll
@@ -534,6 +545,7 @@ struct BnBwdArgs {
     int act, act_after_bn, has_bn;
     float inv_keep; uint32_t thr; const uint8_t* mask; const uint32_t* state; int layer_id; int drop;
     long long rows; int c;
+    int rev = 0;                                 // chunk of a workgroup counted from the END of the tensor (see rev_flags)
 };
 
 // g = dL/d(BN-side output before dropout) [times act'(y) when the activation follows BN]
@@ -658,7 +670,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
     __shared__ float lds[256 * VE];
     const int tid = threadIdx.x, cgi = tid % gm.cg, prow = tid / gm.cg;
     const bool active = prow < gm.rpi;
-    const long long r0 = blockIdx.x * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
+    const long long cb = a.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;      // this workgroup's chunk (its partial row keeps the chunk's place)
+    const long long r0 = cb * gm.chunk, r1 = (r0 + gm.chunk < a.rows) ? r0 + gm.chunk : a.rows;
     const uint32_t key = (a.drop && !a.mask) ? dropout_key(a.state[RVIP_STATE_SEED], a.state[RVIP_STATE_STEP], (uint32_t)a.layer_id) : 0u;
     float part[1][VE], c1[VE], c2[VE], c3[VE];
 #pragma unroll
@@ -699,7 +712,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, RedGeom 
             }
         }
     }
-    block_fold<1, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws + (size_t)blockIdx.x * a.c);
+    block_fold<1, VE>(part, active, prow * gm.cg + cgi, a.c, gm.rpi, lds, ws + (size_t)cb * a.c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1549,6 +1562,7 @@ extern "C" int rvip_bn_apply(const rvip_apply_desc* d, void* stream) {
     a.n = d->n; a.h = d->h; a.w = d->w; a.c = d->c;
     a.argmax = nullptr;
     a.keep_bits = nullptr;
+    a.rev = rev_flags() & 1;
     if (d->keep_bits) {
         if (d->pooled || !drop || d->c % 8 || ((d->c % 32) && (32 % d->c)) || ((uintptr_t)d->keep_bits & 3)) return RVIP_EINVAL;      // whole 32-channel blocks, or one partial block of 8 / 16
         a.keep_bits = d->keep_bits;
@@ -1990,6 +2004,7 @@ extern "C" int rvip_bn_bwd_apply(const rvip_bnbwd_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     float* ws = defer ? d->bias_rows : (float*)d->workspace;
     const int fast = bnbwd_fast(a);
+    a.rev = (rev_flags() >> 1) & 1;
     by_dtype(d->dtype, [&](auto t) {
         using T = decltype(t);
         if (fast == 1 && a.dp) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RVIP_ACT_RELU, 0, 0, 1>), dim3(g.nblk), dim3(256), 0, s, a, g, ws);

@@ -277,9 +277,9 @@ def test_a_fetch_keeps_the_epoch_it_started_under(tmp_path):
     want_x, want_y = ref[1]
 
     class _Racing(type(gen)):
-        def __data_generation__(self, idxs, epoch=None):       # the other thread's on_epoch_end() lands inside the fetch
+        def __data_generation__(self, idxs):                   # the other thread's on_epoch_end() lands inside the fetch
             type(gen).on_epoch_end(self)
-            return super().__data_generation__(idxs, epoch)
+            return super().__data_generation__(idxs)
     gen.__class__ = _Racing
     x, y = gen[1]
     np.testing.assert_array_equal(x, want_x)
@@ -287,6 +287,22 @@ def test_a_fetch_keeps_the_epoch_it_started_under(tmp_path):
     ref.on_epoch_end()
     gen.__class__ = type(ref)
     np.testing.assert_array_equal(gen[1][0], ref[1][0])         # and the next epoch is the next epoch
+
+
+def test_every_generator_class_serves_fetches_and_slices():
+    """The fetch path calls __data_generation__ with the reference's one-argument signature, also where a subclass overrides it."""
+    x = np.arange(6 * 4 * 4, dtype=np.float32).reshape(6, 4, 4, 1)
+    y = np.stack([x[..., 0], -x[..., 0]], -1)
+    for shuffle in (False, True):
+        g = G.ArrayGenerator(x, y, 2, shuffle=shuffle)
+        xb, yb = g[1]
+        order = list(g.INDICES[2:4])
+        np.testing.assert_array_equal(xb, x[order])
+        np.testing.assert_array_equal(yb, y[order])
+        np.testing.assert_array_equal(g.batch_slice(1, 1, 2)[0], x[order[1:]])
+    s = G.SyntheticSAXGenerator(4, dict(DIM=[16, 16], BATCHSIZE=2, MASK_VALUES=[1, 2], GAUS=True, SIGMA=2))
+    xb, yb = s[0]
+    assert xb.shape == (2, 16, 16, 1) and yb.shape == (2, 16, 16, 2)
 
 
 def test_single_threaded_ring_of_four_slots_never_waits_forever():
