@@ -124,9 +124,17 @@ template <> __device__ __forceinline__ f32x4 mfma16x16<bf16_t>(const uint4& a, c
 template <> __device__ __forceinline__ f32x4 mfma16x16<f16_t>(const uint4& a, const uint4& b, const f32x4& acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0); }
 
+// ReLU as ONE v_max_f32.  fmaxf() costs two -- the compiler first quiets a possible signalling NaN (v_max_f32 v, v, v), which no value
+// computed on the device is; for every other input, quiet NaN included (-> 0), the value is fmaxf's.  The epilogues and the VALU-bound
+// passes (first layer, head) run 64 of these per lane and tile.
+__device__ __forceinline__ float relu1(float t) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(t));
+    return r;
+}
 __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
-        case RVIP_ACT_RELU: return fmaxf(x, 0.f);
+        case RVIP_ACT_RELU: return relu1(x);
         case RVIP_ACT_ELU: return x > 0.f ? x : expm1f(x);
         case RVIP_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
         default: return x;

@@ -787,7 +787,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv3x3_igemm_ws(ConvArgs2 
         };
         if (a.down2) epilogue_down2<T, TW, NCT, NPT, STATS>(acc, wv * (NPT * 32), j, hf, n, ty0, tx0, co0, a, ry, st_sum);
         else if constexpr (STATS >= 2) epilogue([](float t) { return t; });      // data gradients carry no activation (host-checked)
-        else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
+        else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return relu1(t); });
         else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
         else epilogue([&](float t) { return act_fwd(t, a.act); });
     }
@@ -1257,11 +1257,14 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
                     if constexpr (STATS == 1) {                                 // statistics of what is stored: the packed words, widened
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2) {
-                            const float ux[4] = {Vec<T>::lo(pk[0][c2][0]), Vec<T>::hi(pk[0][c2][0]), Vec<T>::lo(pk[0][c2][1]), Vec<T>::hi(pk[0][c2][1])};
-                            const float uy[4] = {Vec<T>::lo(pk[1][c2][0]), Vec<T>::hi(pk[1][c2][0]), Vec<T>::lo(pk[1][c2][1]), Vec<T>::hi(pk[1][c2][1])};
+                            // a pixel outside the image counts as zero: selected on the packed words (+0 is all-zero bits), one select per channel pair
+                            const unsigned x0 = ok[0] ? pk[0][c2][0] : 0u, x1 = ok[0] ? pk[0][c2][1] : 0u;
+                            const unsigned y0 = ok[1] ? pk[1][c2][0] : 0u, y1 = ok[1] ? pk[1][c2][1] : 0u;
+                            const float ux[4] = {Vec<T>::lo(x0), Vec<T>::hi(x0), Vec<T>::lo(x1), Vec<T>::hi(x1)};
+                            const float uy[4] = {Vec<T>::lo(y0), Vec<T>::hi(y0), Vec<T>::lo(y1), Vec<T>::hi(y1)};
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const float u0 = ok[0] ? ux[r] : 0.f, u1 = ok[1] ? uy[r] : 0.f;
+                                const float u0 = ux[r], u1 = uy[r];
                                 qs[c2][r] += u0 + u1;
                                 qq[c2][r] = fmaf(u0, u0, fmaf(u1, u1, qq[c2][r]));
                             }
@@ -1330,7 +1333,7 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
         if (a.dbg & 32) {}                                                       // (ablation: no epilogue)
         else if (a.down2) epilogue_down2_16();
         else if constexpr (STATS >= 2) epilogue([](float t) { return t; });      // data gradients carry no activation (host-checked)
-        else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return fmaxf(t, 0.f); });
+        else if (a.act == RVIP_ACT_RELU) epilogue([](float t) { return relu1(t); });
         else if (a.act == RVIP_ACT_NONE) epilogue([](float t) { return t; });
         else epilogue([&](float t) { return act_fwd(t, a.act); });
     }
