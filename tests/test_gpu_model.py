@@ -1319,3 +1319,43 @@ def test_pipelined_predict_and_evaluate_equal_the_batch_calls(precision):
     assert np.abs(ref2 - ref).max() > 0
     np.testing.assert_array_equal(model.predict(x, batch_size=16), ref2)
     np.testing.assert_allclose(model.evaluate(x[:64], y[:64]), model.test_on_batch(x[:64], y[:64]), rtol=2e-6, atol=1e-9)
+
+
+_REV_CHILD = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+import cmr_landmark_detection_amd as rvip
+M = rvip.Loss_and_metrics
+cfg = dict(DIM=[48, 40], FILTERS=16, DEPTH=2, BATCH_NORMALISATION=True, ACTIVATION='relu', MASK_CLASSES=2, LEARNING_RATE=1e-3,
+           DROPOUT_MIN=0.3, DROPOUT_MAX=0.5, RVIP_PRECISION=%r, LOSS_FUNCTION=M.mse, SEED=5)
+rng = np.random.default_rng(3)
+x = rng.random((6, 48, 40, 1)).astype(np.float32)
+y = rng.random((6, 48, 40, 2)).astype(np.float32)
+m = rvip.get_model(cfg, metrics=[])
+losses = [float(np.ravel(m.train_on_batch(x, y))[0]) for _ in range(3)]
+h = hashlib.sha256()
+for w in m.get_weights():
+    h.update(np.ascontiguousarray(w).tobytes())
+h.update(np.asarray(m.predict(x, batch_size=6)).tobytes())
+print('RESULT', h.hexdigest(), ' '.join('%%.9g' %% l for l in losses))
+'''
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_direction_of_the_apply_passes_does_not_change_a_bit(precision):
+    """RVIP_REV (csrc/rvip_pointwise.hip: the element-wise passes walk their tensor from its end, for the Infinity Cache) only reorders
+    work: three training steps (dropout, pooling with argmax, keep bits, deferred bias rows) and a prediction are the same bits with the
+    forward passes reversed (default), nothing reversed, and the backward pass reversed as well.  The switch is read once per process,
+    hence the children (one at a time)."""
+    import subprocess
+    import sys
+    seen = {}
+    for rev in ('0', '1', '3'):
+        env = dict(os.environ, RVIP_REV=rev)
+        out = subprocess.run([sys.executable, '-c', _REV_CHILD % (ROOT, precision)], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
+        assert line, out.stdout[-2000:]
+        seen[rev] = line[-1]
+    assert seen['0'] == seen['1'] == seen['3'], seen
