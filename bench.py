@@ -205,6 +205,24 @@ def main():
     loss = float(eng.loss.item())
     assert np.isfinite(loss) or os.environ.get('RVIP_DBG'), 'training diverged in the benchmark'     # RVIP_DBG: timing ablations compute garbage
 
+    # ---- data-parallel runs: where the step's time goes, segment by segment (every rank runs the same ten steps after the timed
+    # region; events on the launch stream, Engine.train_step(marks=)).  'segment 1' is the encoder's backward pass with gradient
+    # bucket 0 in flight beside it, 'collectives landed' what the launch stream then still waits for both buckets.
+    dp_segments = None
+    if world > 1 or one_rank_pg:
+        acc = {}
+        n_seg_steps = 10
+        for _ in range(n_seg_steps):
+            marks = []
+            eng.train_step(marks=marks)
+            torch.cuda.synchronize()
+            for (_, e0), (what, e1) in zip(marks[:-1], marks[1:]):
+                acc[what] = acc.get(what, 0.0) + e0.elapsed_time(e1)
+            acc['step'] = acc.get('step', 0.0) + marks[0][1].elapsed_time(marks[-1][1])
+        dp_segments = {k + ' ms': round(v / n_seg_steps, 4) for k, v in acc.items()}
+        dp_segments['note'] = 'rank 0, mean of %d steps after the timed region; a host synchronisation between steps' % n_seg_steps
+        barrier()
+
     # ---- inference (Model.predict: BN on the moving statistics, no dropout), forward only, eager launches; and the HBM the
     # whole training state of this configuration occupies.  Informational keys beside `value`.
     predict_rate = hbm_gb = fit_rate = fit_info = None
@@ -427,8 +445,9 @@ def main():
             'hbm_bytes_per_step': hbm_step, 'algorithmic_bytes_per_step': round(plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * B),
             'wasted_traffic_ratio': round(hbm_step / (plan.ideal_bytes_per_slice(2 if args.precision != 'fp32' else 4) * B), 3) if hbm_step else None,
             'mfma_util_whole_step': round(value / world * step_flops / (PEAK_BF16_TFLOPS * 1e12), 4),
-            'loss': loss, 'steps_executed_total': max(2, min(args.warmup, 3)) + args.warmup + args.steps + (0 if args.no_roofline_pass else 3),
+            'loss': loss, 'steps_executed_total': max(2, min(args.warmup, 3)) + args.warmup + args.steps + (0 if args.no_roofline_pass else 3) + (10 if dp_segments else 0),
             'other_configs': other,
+            'dp_segments': dp_segments,
             'roofline': roof,
             'kernels': per_kernel,
         }

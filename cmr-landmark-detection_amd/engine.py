@@ -1347,25 +1347,39 @@ class Engine(InputRing):
             self.reset_input_ring()
             self.pin_x = self.pin_y = self.pin_x_np = self.pin_y_np = None
 
-    def train_step(self):
+    def train_step(self, marks=None):
         """stage input + fwd + loss + bwd + [all-reduce] + Adam on the batch in ``x_stage`` / ``y_true``.  The first call runs
-        eagerly (warm-up), the second captures the step, every later one replays it (RVIP_GRAPH=0: always eager)."""
+        eagerly (warm-up), the second captures the step, every later one replays it (RVIP_GRAPH=0: always eager).
+
+        ``marks`` (a list; bench.py's ``dp_segments``): timing events recorded on the launch stream at the step's start, behind
+        every segment and behind the wait for the collectives -- the same launches in the same order, nothing else changes."""
         if self._graphs is None and self._eager_steps >= 1 and self.launch_mode == 'eager' and os.environ.get('RVIP_GRAPH', '1') != '0':
             self.capture()
         parts, buckets = self._step_parts() if self._graphs is None else ([g.replay for g in self._graphs], self._step_parts()[1])
         if self._graphs is None:
             self._eager_steps += 1
+
+        def mark(what):
+            if marks is not None:
+                torch = _torch()
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream())
+                marks.append((what, ev))
         pending = []
+        mark('start')
         for i, run in enumerate(parts):
             run()
+            mark('segment %d' % i)
             if i < len(buckets):
                 if buckets[i] is None:
                     self.allreduce_grads()
+                    mark('all-reduce')
                 else:
                     pending.append(self.allreduce_bucket_async(buckets[i]))
-            if i == len(parts) - 2:                        # every collective must have landed before the optimiser segment
+            if i == len(parts) - 2 and pending:            # every collective must have landed before the optimiser segment
                 for w in pending:
                     w.wait()
+                mark('collectives landed')
 
     def landmarks(self, thr=0.5, want_mask=False):
         torch = _torch()

@@ -1085,8 +1085,13 @@ def _rccl_worker(port, q):
         eng = model._engine(4)
         t = torch.ones(1 << 20, device='cuda')
         dist.all_reduce(t)                                        # the communicator itself: sum over one rank is the identity
-        q.put((losses, [w.copy() for w in model.get_weights()], eng.launch_mode, bool(eng.overlap_ok()), eng.P.grad.numel() * 4,
-               dist.get_backend(), float(t.sum().item())))
+        weights = [w.copy() for w in model.get_weights()]
+        marks = []                                                # one more step with bench.py's segment marks
+        eng.train_step(marks=marks)
+        torch.cuda.synchronize()
+        spans = [(b[0], a[1].elapsed_time(b[1])) for a, b in zip(marks[:-1], marks[1:])]
+        q.put((losses, weights, eng.launch_mode, bool(eng.overlap_ok()), eng.P.grad.numel() * 4,
+               dist.get_backend(), float(t.sum().item()), spans))
     finally:
         dist.destroy_process_group()
 
@@ -1110,9 +1115,12 @@ def test_rccl_one_rank_data_parallel_schedule_equals_the_single_graph_step():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(29900 + os.getpid() % 2000, q))
     p.start()
-    losses, w, mode, overlap, grad_bytes, backend, tsum = q.get(timeout=300)
+    losses, w, mode, overlap, grad_bytes, backend, tsum, spans = q.get(timeout=300)
     p.join(60)
     assert backend == 'nccl' and tsum == float(1 << 20)
+    # Engine.train_step(marks=): the step's segments as bench.py's `dp_segments` reports them at N > 1
+    assert [k for k, _ in spans] == ['segment 0', 'segment 1', 'collectives landed', 'segment 2'], spans
+    assert all(ms >= 0.0 for _, ms in spans) and spans[0][1] > spans[3][1]
     assert mode == 'hipGraph x3 + RCCL between' and overlap, mode
     assert grad_bytes > 30e6                                      # the 34.5 MB gradient block of the F = 32 / depth 4 graph
     assert losses == ref_losses, (losses, ref_losses)
