@@ -22,7 +22,12 @@ __device__ __forceinline__ float f16_to_f32(uint16_t b) { return (float)__builti
 // RNE of the FP32 VALUE, overflow -> inf.  The empty asm pins that value: without it the compiler may fold a preceding fma into
 // v_fma_mixlo_f16, which rounds the exact product-sum ONCE -- a different result in rare double-rounding cases, and then the
 // fused and the separate kernels (and the storage-rounding emulation in tests/) no longer store the same bits.
-__device__ __forceinline__ uint16_t f32_to_f16(float f) { asm volatile("" : "+v"(f)); return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// IEEE half SATURATES here (one v_med3_f32 in front of the convert) instead of overflowing to infinity: with the moving statistics of the
+// first epochs an evaluation pass can compound a factor per BatchNormalization over 18 layers past 65504, and one infinity turns the
+// next layer's sums into NaN (tools/soak_probe.py: val_loss 93.7, 6.9, nan, 0.15 ...).  A saturated value stays a large finite number
+// in the fp32 accumulators behind it.
+__device__ __forceinline__ float sat_f16(float f) { return __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { f = sat_f16(f); asm volatile("" : "+v"(f)); return __builtin_bit_cast(uint16_t, (_Float16)f); }
 
 // two fp32 -> one packed 32-bit word (lo = a, hi = b), RNE: ONE v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32.  Converting the halves one by
 // one and OR-ing them (the obvious form) is four instructions on gfx950: cvt, cvt, shift, or.
@@ -32,6 +37,7 @@ typedef _Float16 rvip_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
     const rvip_f32x2 v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rvip_bf16x2)); }
 __device__ __forceinline__ uint32_t pack2_f16(float a, float b) {
+    a = sat_f16(a); b = sat_f16(b);
     asm volatile("" : "+v"(a), "+v"(b));              // see f32_to_f16
     const rvip_f32x2 v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rvip_f16x2)); }
 

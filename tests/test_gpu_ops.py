@@ -1381,3 +1381,29 @@ def test_first_layer_weight_gradient_on_the_matrix_cores(shape, dtype, monkeypat
     N.call('rvip_conv3x3_c1_wgrad', P(xd), P(dyd), None, n, h, w, co, ndt(dtype), P(rows), C.c_size_t(rows.numel() * 4), stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(rows.cpu().numpy().reshape(nr, 3, 3, 1, co).astype(np.float64).sum(0), got, rtol=0, atol=2e-6 * mag.max())
+
+
+def test_half_storage_saturates_instead_of_overflowing():
+    """IEEE half stores clamp at +-65504 (rvip_common.h: sat_f16): with unconverged moving statistics an fp16 evaluation pass can exceed
+    the half range, and one infinity would turn the next layer's sums into NaN (tools/soak_probe.py).  bf16 has the range and rounds as
+    before.  BN apply pass with a large scale, then the values stored."""
+    n, h, w, c = 1, 4, 8, 16
+    z = np.zeros((n, h, w, c), np.float32)
+    z[0, 0, 0, :4] = [1000.0, -1000.0, 3.0, 0.5]
+    scale = np.full(c, 100.0, np.float32)
+    shift = np.zeros(c, np.float32)
+    want = {'f16': [65504.0, -65504.0, 300.0, 50.0], 'bf16': [99840.0, -99840.0, 300.0, 50.0]}
+    for dtype in ('f16', 'bf16'):
+        zd = up(z, dtype)
+        y = torch.empty((n, h, w, c), dtype=tdt(dtype), device=dev())
+        a = N.ApplyDesc()
+        a.z, a.y, a.pooled = zd.data_ptr(), y.data_ptr(), None
+        a.act = 0
+        a.drop_rate, a.mask, a.state, a.layer_id = 0.0, None, None, 0
+        a.n, a.h, a.w, a.c, a.dtype = n, h, w, c, ndt(dtype)
+        sc, sh = f32(scale), f32(shift)
+        a.scale, a.shift = sc.data_ptr(), sh.data_ptr()
+        N.call('rvip_bn_apply', C.byref(a), stream())
+        got = down(y)[0, 0, 0, :4]
+        assert np.isfinite(down(y)).all()
+        np.testing.assert_array_equal(got, np.asarray(want[dtype], np.float32))
