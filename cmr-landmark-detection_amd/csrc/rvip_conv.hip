@@ -923,7 +923,7 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
         unsigned p_mb = OOB;
         int mb_par = 0;
         auto prep_tile = [&](int tile) __attribute__((always_inline)) {
-            unsigned bx = (unsigned)((STATS >= 2 && (a.dbg & 128)) ? a.ntiles - 1 - tile : tile);      // (experiment: data gradients walk the tensor from its end)
+            unsigned bx = (unsigned)tile;
             const unsigned tx_i = bx % (unsigned)a.tiles_x; bx /= (unsigned)a.tiles_x;
             const unsigned ty_i = bx % (unsigned)a.tiles_y;
             const int n_out = (int)(bx / (unsigned)a.tiles_y);
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void igemm_ws16_body(const ConvArgs2& a, const int bx
 
     int it = 0, stg = 0;
     for (int tile = first_tile; tile < a.ntiles; tile += gdx_, mb_par = (mb_par + 1 == a.nstg ? 0 : mb_par + 1)) {
-        int bx = (STATS >= 2 && (a.dbg & 128)) ? a.ntiles - 1 - tile : tile;
+        int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
         const int n = bx / a.tiles_y;

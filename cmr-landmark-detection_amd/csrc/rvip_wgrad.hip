@@ -509,7 +509,7 @@ __device__ __forceinline__ void wgrad3x3_ws_body(const WgArgs2& a, const unsigne
     }
     auto issue = [&](int tile, int stage) __attribute__((always_inline)) -> int {     // returns the VMEM instructions this wave issued
         int nvm = 0;
-        int bx = (a.dbg & 128) ? a.ntiles - 1 - tile : tile;      // (experiment: from the tensor's end)
+        int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
         const int n = bx / a.tiles_y;
